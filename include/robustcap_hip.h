@@ -1,0 +1,140 @@
+/*
+ * robustcap_hip.h -- C ABI of the MI355X (gfx950) implementation of RobustCap's sig_mp per-frame path.
+ *
+ * The reference (shaohua-pan/RobustCap) is pure Python/PyTorch and has no FFI of its own; every entry point
+ * below names the reference Python interface it replaces (paths relative to the reference repo root). The
+ * Python host (robustcap_amd/) binds these with ctypes; see INTEGRATION.md for the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - All tensors are float32, row-major, resident in device memory unless a parameter says "host".
+ *   - The caller owns every I/O buffer and passes raw device pointers plus the HIP stream to enqueue on
+ *     (hipStream_t is passed as void*). The library owns only its context (packed weights, recurrent state,
+ *     scratch). No call synchronises the device except rc_create / rc_finalize_weights / rc_set_body /
+ *     rc_get_state / rc_destroy.
+ *   - Every function returns 0 on success or a negative rc_status; rc_last_error() gives a message. Nothing
+ *     throws across the boundary. A context is not re-entrant; distinct contexts on distinct streams are
+ *     independent.
+ *   - "row" = one body (one sequence/camera) of the batch; rows never interact.
+ */
+#ifndef ROBUSTCAP_HIP_H
+#define ROBUSTCAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rc_ctx rc_ctx;
+
+typedef enum {
+    RC_OK = 0,
+    RC_ERR_INVALID = -1,    /* bad argument                                  */
+    RC_ERR_HIP = -2,        /* a HIP runtime call failed                     */
+    RC_ERR_STATE = -3,      /* call order (weights / body not loaded yet)    */
+    RC_ERR_UNKNOWN_KEY = -4 /* rc_load_weight: not a sig_mp state_dict key   */
+} rc_status;
+
+/* Behaviour switches = the class attributes callers poke on the reference Net (net/sig_mp.py:27-45, 91-93). */
+typedef struct {
+    double conf_lo, conf_hi;       /* Net.conf_range: (0.7, 0.8); (0.85, 0.9) when constructed live      */
+    float contact_threshold;       /* 0.7                                                                */
+    float distance_threshold;      /* Net.distrance_threshold = 10                                       */
+    float height_threshold;        /* Net.height_threhold = 0.15                                         */
+    double tran_filter_num;        /* 0.05; 0.01 when constructed live                                   */
+    int32_t use_flat_floor;        /* 1                                                                  */
+    int32_t use_vision_updater;    /* 1                                                                  */
+    int32_t use_imu_updater;       /* 1                                                                  */
+    int32_t live;                  /* Net.live: landmark refresh every update_vision_freq+1 frames       */
+    int32_t update_vision_freq;    /* 30                                                                 */
+    int32_t reserved;
+} rc_params;
+
+/* rc_step flags */
+#define RC_FLAG_FIRST_FRAME 1u /* forward_online(first_frame=True), net/sig_mp.py:114,149,155,208,224 */
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------ */
+/* Replaces Net() / Net().to(device) (net/sig_mp.py:47-93). batch = number of independent rows (>= 1).
+ * live_at_construction mirrors "Net.live = True" BEFORE construction (evaluate.py:392). */
+int rc_create(int32_t batch, int32_t live_at_construction, rc_ctx** out);
+int rc_destroy(rc_ctx* ctx);
+const char* rc_last_error(const rc_ctx* ctx); /* ctx may be NULL: last error of a failed rc_create */
+int rc_default_params(int32_t live_at_construction, rc_params* out);
+int rc_get_params(const rc_ctx* ctx, rc_params* out);
+int rc_set_params(rc_ctx* ctx, const rc_params* p);
+
+/* Replaces Net.load_state_dict (evaluate.py:58): one call per state_dict entry, key names and shapes as in
+ * the reference ("rnn2.rnn.weight_ih_l0", "rnn4.linear1.bias", "rnn2.init_net.4.weight", ...).
+ * `host` points to numel float32 values in HOST memory (torch layout). rc_finalize_weights repacks everything
+ * to the kernel layout and uploads; it fails if a key is missing. */
+int rc_load_weight(rc_ctx* ctx, const char* key, const float* host, int64_t numel);
+int rc_finalize_weights(rc_ctx* ctx);
+
+/* Replaces art.ParametricModel(paths.smpl_file) as consumed by the path (articulate/model.py:29-40,78-93 and
+ * config.mp_mask): parent[24] (parent[0] ignored), rest joints J[24,3], and for the 33 landmark vertices the
+ * skinning weights w33[33,24] and template positions v33[33,3]. HOST pointers. */
+int rc_set_body(rc_ctx* ctx, const int32_t* parent, const float* J, const float* w33, const float* v33);
+
+/* Replaces "net.gravityc = ..." (evaluate.py:73): per-row gravity direction in the camera frame, HOST [batch,3]. */
+int rc_set_gravity(rc_ctx* ctx, const float* gravity_host);
+
+/* Replaces Net.reset_states (net/sig_mp.py:95-104). row_mask: DEVICE uint8[batch] (non-zero = reset) or NULL
+ * for all rows. Like the reference it does not touch update_vision_count / j_temp / gravity. */
+int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream);
+
+/* ---- the hot path --------------------------------------------------------------------------------------- */
+/* Replaces Net.forward_online (net/sig_mp.py:113-274) for `batch` rows at once; row b == the reference run
+ * alone on sequence b. j2dc[batch,33,3] (x/z, y/z, conf), accc[batch,6,3], oric[batch,6,3,3]; first_tran
+ * [batch,3] or NULL; pose_out[batch,24,3,3] (local rotations, root = camera-frame IMU), tran_out[batch,3].
+ * Enqueues ~14 kernels on `stream`; no host synchronisation, all branching is device side. */
+int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran,
+            uint32_t flags, float* pose_out, float* tran_out, void* stream);
+
+/* The evaluate.py per-sequence loop (evaluate.py:75-83) for all rows: frames t = 0..T-1, inputs and outputs
+ * indexed [row][t] with element strides  row_stride_* (between rows) and T contiguous frames per row:
+ *   j2dc + row*rs_j2d + t*99, accc + row*rs_acc + t*18, oric + row*rs_ori + t*54,
+ *   pose_out + row*rs_pose + t*216, tran_out + row*rs_tran + t*3.
+ * Frame 0 uses first_tran (if not NULL) and `flags`; later frames use neither. */
+int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const float* accc, int64_t rs_acc,
+                const float* oric, int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out,
+                int64_t rs_pose, float* tran_out, int64_t rs_tran, void* stream);
+
+/* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
+/* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264): r6d[n,6] -> R[n,3,3]. */
+int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream);
+/* ParametricModel.inverse_kinematics_R (articulate/math/spatial.py:197-221): Rg[n,24,3,3] -> Rl[n,24,3,3]. */
+int rc_ik_r(rc_ctx* ctx, const float* Rglobal, float* Rlocal, int64_t n, void* stream);
+/* fk() of forward_online (net/sig_mp.py:131-135): joints[n,24,3] from GLOBAL rotations + rest bone vectors. */
+int rc_fk_bone(rc_ctx* ctx, const float* Rglobal, float* joints, int64_t n, void* stream);
+/* ParametricModel.forward_kinematics(calc_mesh=True) restricted to the landmarks + sync_mp3d
+ * (articulate/model.py:209-241, net/sig_mp.py:287-299): pose[n,24,3,3] local, tran[n,3] ->
+ * grot[n,24,3,3] (may be NULL), joint[n,24,3], j33[n,33,3]. */
+int rc_body_fk(rc_ctx* ctx, const float* pose, const float* tran, float* grot, float* joint, float* j33,
+               int64_t n, void* stream);
+/* One step of sub-net `net` ("rnn2".."rnn8") = f(i, x) of forward_online (net/sig_mp.py:126-129) on its
+ * recurrent state: x[batch, in] -> y[batch, out]. row_mask DEVICE uint8[batch] or NULL (all rows). */
+int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* row_mask, float* y, void* stream);
+/* smplify forward residual (net/smplify/temporal_smplify.py:198-220 -> losses.py:36-37,43-46): pose[T,24,3,3],
+ * tran[T,3], kp[T,33,3] in pixels, K[3,3] (DEVICE) -> loss[T,33]. The confidences of landmarks
+ * {1..9,31,32} count as zero. */
+int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K,
+                       float sigma, float* loss, int64_t T, void* stream);
+
+/* ---- state access (tests / checkpointing of a running sequence) ------------------------------------------ */
+/* Copy the (h, c) state of sub-net `net` to HOST buffers h[2,batch,H], c[2,batch,H]. Synchronises `stream`. */
+int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, void* stream);
+/* Per-row branch trace of the last step, HOST int32[batch,8]:
+ * {regime (0 low,1 mid,2 high), rnn4 steps, rnn6 steps, floor samples held, reach fired, used velocity branch,
+ *  stance foot, jump reset}. Synchronises `stream`. */
+int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream);
+
+/* Timing hook for bench.py: accumulate HIP-event time of the gate-GEMM launches on their own stream.
+ * enable != 0 starts recording; rc_gemm_timing_read returns total milliseconds and launch count so far. */
+int rc_gemm_timing(rc_ctx* ctx, int32_t enable);
+int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBUSTCAP_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of librobustcap_hip.so (include/robustcap_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the product path raises.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C robustcap_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librobustcap_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "robustcap_hip.h")
+
+RC_FLAG_FIRST_FRAME = 1
+
+
+class RcParams(C.Structure):
+    _fields_ = [("conf_lo", C.c_double), ("conf_hi", C.c_double),
+                ("contact_threshold", C.c_float), ("distance_threshold", C.c_float),
+                ("height_threshold", C.c_float), ("tran_filter_num", C.c_double),
+                ("use_flat_floor", C.c_int32), ("use_vision_updater", C.c_int32),
+                ("use_imu_updater", C.c_int32), ("live", C.c_int32),
+                ("update_vision_freq", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RobustcapLibraryError(RuntimeError):
+    pass
+
+
+_P, _I32, _I64, _U32, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_float
+SIGNATURES = {
+    "rc_create": (_I32, [_I32, _I32, C.POINTER(_P)]),
+    "rc_destroy": (_I32, [_P]),
+    "rc_last_error": (C.c_char_p, [_P]),
+    "rc_default_params": (_I32, [_I32, C.POINTER(RcParams)]),
+    "rc_get_params": (_I32, [_P, C.POINTER(RcParams)]),
+    "rc_set_params": (_I32, [_P, C.POINTER(RcParams)]),
+    "rc_load_weight": (_I32, [_P, C.c_char_p, _P, _I64]),
+    "rc_finalize_weights": (_I32, [_P]),
+    "rc_set_body": (_I32, [_P, _P, _P, _P, _P]),
+    "rc_set_gravity": (_I32, [_P, _P]),
+    "rc_reset": (_I32, [_P, _P, _P]),
+    "rc_step": (_I32, [_P, _P, _P, _P, _P, _U32, _P, _P, _P]),
+    "rc_sequence": (_I32, [_P, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _U32, _P, _I64, _P, _I64, _P]),
+    "rc_r6d_to_rotmat": (_I32, [_P, _P, _I64, _P]),
+    "rc_ik_r": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_fk_bone": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_body_fk": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),
+    "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
+    "rc_get_state": (_I32, [_P, C.c_char_p, _P, _P, _P]),
+    "rc_get_trace": (_I32, [_P, _P, _P]),
+    "rc_gemm_timing": (_I32, [_P, _I32]),
+    "rc_gemm_timing_read": (_I32, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once and attach prototypes. Raises RobustcapLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RobustcapLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` at the repo root. There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RobustcapLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError here = header / library mismatch: fail loudly
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc, what):
+    if rc != 0:
+        msg = load().rc_last_error(ctx)
+        raise RobustcapLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device/host pointer of a contiguous torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

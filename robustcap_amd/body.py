@@ -1,0 +1,115 @@
+"""Body-model constants of the path and the ``ParametricModel`` call surface on top of the HIP kernels.
+
+Mirrors the part of ``articulate/model.py`` the sig_mp path uses (``ParametricModel``: L21-40 loading, L78-93
+rest pose, L95-165 FK/IK wrappers, L209-241 ``forward_kinematics``), restricted to the 33 landmark vertices
+``config.mp_mask`` that ``sync_mp3d`` gathers (net/sig_mp.py:287-299). All arithmetic runs in
+``librobustcap_hip.so``; this file only prepares constants and marshals pointers.
+"""
+import ctypes as C
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import config as cfg
+
+
+def load_smpl_pickle(path):
+    """Read an official SMPL pickle into the dict layout used here (J, v_template, weights, parent).
+    Same fields as articulate/model.py:29-39 (needs scipy for the pickled sparse J_regressor)."""
+    with open(path, "rb") as f:
+        data = pickle.load(f, encoding="latin1")
+    parent = np.asarray(data["kintree_table"][0]).astype(np.int64).copy()
+    parent[0] = -1
+    return {"J": np.asarray(data["J"], np.float32), "v_template": np.asarray(data["v_template"], np.float32),
+            "weights": np.asarray(data["weights"], np.float32), "parent": parent}
+
+
+def body_arrays(body):
+    """(parent int32[24], J f32[24,3], w33 f32[33,24], v33 f32[33,3]) for rc_set_body."""
+    ids = list(cfg.mp_mask)
+    parent = np.asarray(body["parent"]).astype(np.int32).copy()
+    parent[0] = 0
+    return (np.ascontiguousarray(parent), np.ascontiguousarray(body["J"], dtype=np.float32),
+            np.ascontiguousarray(np.asarray(body["weights"], np.float32)[ids]),
+            np.ascontiguousarray(np.asarray(body["v_template"], np.float32)[ids]))
+
+
+def set_body(ctx, body):
+    lib = _lib.load()
+    parent, J, w33, v33 = body_arrays(body)
+    rc = lib.rc_set_body(ctx, parent.ctypes.data_as(C.c_void_p), J.ctypes.data_as(C.c_void_p),
+                         w33.ctypes.data_as(C.c_void_p), v33.ctypes.data_as(C.c_void_p))
+    _lib.check(ctx, rc, "rc_set_body")
+
+
+def _f32c(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class ParametricModel:
+    """Drop-in for the methods of ``art.ParametricModel`` that the path calls; device tensors in and out."""
+
+    def __init__(self, official_model_file=None, use_pose_blendshape=False, device="cuda", body=None):
+        if use_pose_blendshape:
+            raise NotImplementedError("pose blendshapes are off on the sig_mp path (model.py:237, default False)")
+        self._body = body if body is not None else load_smpl_pickle(official_model_file)
+        self.parent = [None] + [int(p) for p in self._body["parent"][1:]]
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        _lib.check(None, self._lib.rc_create(1, 0, C.byref(self._ctx)), "rc_create")
+        set_body(self._ctx, self._body)
+
+    def __del__(self):
+        if getattr(self, "_ctx", None):
+            self._lib.rc_destroy(self._ctx)
+            self._ctx = None
+
+    def inverse_kinematics_R(self, R_global):
+        Rg = _f32c(R_global, self.device).view(-1, 24, 3, 3)
+        out = torch.empty_like(Rg)
+        _lib.check(self._ctx, self._lib.rc_ik_r(self._ctx, _lib.ptr(Rg), _lib.ptr(out), Rg.shape[0], _lib.stream_ptr()), "rc_ik_r")
+        return out
+
+    def bone_fk(self, R_global):
+        """fk() of forward_online (net/sig_mp.py:131-135): joints from GLOBAL rotations, root at the origin."""
+        Rg = _f32c(R_global, self.device).view(-1, 24, 3, 3)
+        out = torch.empty(Rg.shape[0], 24, 3, device=self.device)
+        _lib.check(self._ctx, self._lib.rc_fk_bone(self._ctx, _lib.ptr(Rg), _lib.ptr(out), Rg.shape[0], _lib.stream_ptr()), "rc_fk_bone")
+        return out
+
+    def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
+        """(global rotations, joints[, landmarks]). With ``calc_mesh`` the third output is the 33-landmark set
+        ``sync_mp3d(vert, joint)`` -- the only part of the 6890-vertex mesh the path consumes."""
+        if shape is not None:
+            raise NotImplementedError("shape=None (mean shape) on this path, model.py:86-87")
+        pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
+        n = pose.shape[0]
+        tran = torch.zeros(n, 3, device=self.device) if tran is None else _f32c(tran, self.device).view(n, 3)
+        grot = torch.empty_like(pose)
+        joint = torch.empty(n, 24, 3, device=self.device)
+        j33 = torch.empty(n, 33, 3, device=self.device)
+        _lib.check(self._ctx, self._lib.rc_body_fk(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(grot), _lib.ptr(joint),
+                                                   _lib.ptr(j33), n, _lib.stream_ptr()), "rc_body_fk")
+        return (grot, joint, j33) if calc_mesh else (grot, joint)
+
+    def reprojection_residual(self, pose, tran, keypoints_2d, cam_k, sigma=100.0):
+        """``TemporalSMPLify.get_fitting_loss`` (temporal_smplify.py:198-220): [T,33] robust reprojection loss."""
+        pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
+        T = pose.shape[0]
+        tran, kp, K = _f32c(tran, self.device).view(T, 3), _f32c(keypoints_2d, self.device).view(T, 33, 3), _f32c(cam_k, self.device).view(3, 3)
+        loss = torch.empty(T, 33, device=self.device)
+        _lib.check(self._ctx, self._lib.rc_reproj_residual(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(kp), _lib.ptr(K),
+                                                           C.c_float(sigma), _lib.ptr(loss), T, _lib.stream_ptr()), "rc_reproj_residual")
+        return loss
+
+
+def r6d_to_rotation_matrix(r6d, device="cuda"):
+    """art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264) on the GPU."""
+    x = _f32c(r6d, torch.device(device)).view(-1, 6)
+    out = torch.empty(x.shape[0], 3, 3, device=x.device)
+    lib = _lib.load()
+    _lib.check(None, lib.rc_r6d_to_rotmat(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_r6d_to_rotmat")
+    return out

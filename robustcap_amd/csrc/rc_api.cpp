@@ -1,0 +1,603 @@
+// C ABI of librobustcap_hip.so (see include/robustcap_hip.h): context, weight repacking, per-frame launch plan.
+//
+// Host logic only; all arithmetic runs in rc_gemm.hip / rc_frame.hip. The launch plan of one frame mirrors the
+// data flow of Net.forward_online (net/sig_mp.py:113-274):
+//   prep -> {rnn2, rnn4}            (4 fused launches: linear1, LSTM l0, LSTM l1, linear2)
+//        -> [first frame: rnn6 on every row, L155-156]
+//        -> fuse -> {rnn3, rnn6, rnn7, rnn8, rnn2.init_net}   (4 fused launches)
+//        -> tail -> {rnn6, rnn4} on re-projected landmarks  (3 fused launches, outputs unused)
+// Independent sub-nets share a launch ("problems" of one rc_gemm_kernel grid) so the chip sees 500-1300
+// workgroups per launch instead of 128-640.
+#include "../../include/robustcap_hip.h"
+#include "rc_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct NetSpec { const char* name; int in, H, out; };
+const NetSpec kNets[6] = {{"rnn2", 72, 512, 69},  {"rnn3", 141, 512, 3},   {"rnn4", 171, 1280, 69},
+                          {"rnn6", 240, 1024, 3}, {"rnn7", 141, 512, 144}, {"rnn8", 141, 512, 2}};
+enum { N2 = 0, N3 = 1, N4 = 2, N6 = 3, N7 = 4, N8 = 5 };
+const int kInit[3][2] = {{69, 512}, {512, 1024}, {1024, 2048}};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Dense {       // packed dense layer
+    float* W = nullptr; float* b = nullptr;
+    int K = 0, N = 0, Kp = 0, Np = 0;
+};
+struct NetDev {
+    Dense lin1, lin2;
+    float* Wl[2] = {nullptr, nullptr};   // LSTM layers, K' = 2H, N' = 4H (tile-interleaved gates)
+    float* bl[2] = {nullptr, nullptr};
+    float* h = nullptr;                  // [layer][parity][B][H]
+    float* c = nullptr;                  // [layer][B][H]
+    int* steps = nullptr;                // [B]
+    float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
+    int in = 0, H = 0, out = 0;
+};
+
+}  // namespace
+
+struct rc_ctx {
+    int B = 0;
+    int dev = 0;
+    rc_params prm{};
+    NetDev net[6];
+    Dense init[3];
+    float *hid1 = nullptr, *hid2 = nullptr, *xtmp = nullptr;
+    FrameBuffers fb{};
+    BodyConst* body = nullptr;
+    bool have_body = false, have_weights = false;
+    std::map<std::string, std::vector<float>> staged;
+    std::vector<void*> allocs;
+    std::string err;
+    // timing of the gate GEMM launches
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double timed_ms = 0.0;
+    long long timed_launches = 0;
+};
+
+namespace {
+
+int fail(rc_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, RC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, count * sizeof(T)));
+    if (zero) HIP_TRY(ctx, hipMemset(q, 0, count * sizeof(T)));
+    ctx->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return RC_OK;
+}
+
+// MFMA-B fragment order: for 32-column block nb and 8-wide k-chunk q, lane l = kh*32 + j holds the float4
+// W'[nb*32 + j][8q + 4kh + 0..3]; blocks are laid out [nb][q][lane][4] so that a wave's K slice is one
+// contiguous stream of 1 KiB pieces. getW(n, k) returns the (padded) logical weight W'[n][k].
+template <typename F>
+std::vector<float> pack_weights(int Np, int Kp, F getW) {
+    std::vector<float> out((size_t)Np * Kp);
+    const int Q = Kp / 8;
+    for (int nb = 0; nb < Np / 32; ++nb)
+        for (int q = 0; q < Q; ++q)
+            for (int l = 0; l < 64; ++l) {
+                const int kh = l >> 5, j = l & 31;
+                float* d = &out[(((size_t)nb * Q + q) * 64 + l) * 4];
+                for (int s = 0; s < 4; ++s) d[s] = getW(nb * 32 + j, 8 * q + 4 * kh + s);
+            }
+    return out;
+}
+
+int upload(rc_ctx* ctx, float** dst, const std::vector<float>& v) {
+    if (int rc = dev_alloc(ctx, dst, v.size(), false)) return rc;
+    HIP_TRY(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RC_OK;
+}
+
+int make_dense(rc_ctx* ctx, Dense& d, const std::vector<float>& W, const std::vector<float>& b, int N, int K) {
+    d.N = N; d.K = K; d.Kp = round_up(K, RC_KALIGN); d.Np = round_up(N, RC_NT);
+    auto get = [&](int n, int k) -> float { return (n < N && k < K) ? W[(size_t)n * K + k] : 0.0f; };
+    std::vector<float> bp(d.Np, 0.0f);
+    for (int n = 0; n < N; ++n) bp[n] = b[n];
+    if (int rc = upload(ctx, &d.W, pack_weights(d.Np, d.Kp, get))) return rc;
+    return upload(ctx, &d.b, bp);
+}
+
+const std::vector<float>* staged(rc_ctx* ctx, const std::string& key, size_t numel) {
+    auto it = ctx->staged.find(key);
+    if (it == ctx->staged.end() || it->second.size() != numel) return nullptr;
+    return &it->second;
+}
+
+int net_index(const char* name) {
+    for (int i = 0; i < 6; ++i) if (!std::strcmp(name, kNets[i].name)) return i;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------ problem builders
+GemmSeg seg(const float* base, int ld, int K, int mode = RC_PAR_NONE, long long stride = 0) {
+    GemmSeg s{};
+    s.base = base; s.ld = ld; s.K = K; s.par_mode = mode; s.par_stride = stride;
+    return s;
+}
+
+GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, float* out, int ldo, bool relu, int flag_bit,
+                          const unsigned char* flags, int* steps, bool open_step) {
+    GemmProblem p{};
+    a.K = d.Kp;
+    p.seg[0] = a;
+    p.seg[1] = seg(a.base, a.ld, 0);
+    p.W = d.W; p.bias = d.b; p.out = out; p.ldo = ldo; p.N = d.N;
+    p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
+    p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
+    p.open_step = open_step ? 1 : 0;
+    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp;
+    return p;
+}
+
+struct Stage {                 // which rows of which net, reading which input buffer
+    int net; int flag_bit; const float* x; int ldx; float* y; int ldy;
+};
+
+GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
+    const NetDev& n = c->net[s.net];
+    return dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), n.x1, n.H, true, s.flag_bit, c->fb.flags, n.steps, true);
+}
+GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
+    const NetDev& n = c->net[s.net];
+    const long long BH = (long long)c->B * n.H;
+    GemmProblem p{};
+    if (layer == 0) p.seg[0] = seg(n.x1, n.H, n.H);
+    else p.seg[0] = seg(n.h, n.H, n.H, RC_PAR_DST, BH);                     // h of layer 0, just written
+    p.seg[1] = seg(n.h + layer * 2 * BH, n.H, n.H, RC_PAR_SRC, BH);         // own h, previous step
+    p.W = n.Wl[layer]; p.bias = n.bl[layer];
+    p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * BH; p.h_par_stride = BH; p.H = n.H;
+    p.steps = n.steps; p.flags = c->fb.flags; p.flag_bit = s.flag_bit;
+    p.epi = RC_EPI_LSTM;
+    p.n_tiles = n.H / RC_UNITS; p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H;
+    return p;
+}
+GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
+    const NetDev& n = c->net[s.net];
+    const long long BH = (long long)c->B * n.H;
+    return dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, s.ldy, false, s.flag_bit, c->fb.flags,
+                         n.steps, false);
+}
+
+int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st) {
+    if (ps.empty()) return RC_OK;
+    GemmLaunch L{};
+    L.B = ctx->B;
+    // XCD-aligned problems first so that (block id % 8) is the XCD for them
+    std::vector<GemmProblem> ordered;
+    for (auto& p : ps) if ((p.n_tiles & 7) == 0) ordered.push_back(p);
+    for (auto& p : ps) if ((p.n_tiles & 7) != 0) ordered.push_back(p);
+    if ((int)ordered.size() > RC_MAX_PROB) return fail(ctx, RC_ERR_INVALID, "too many fused problems");
+    int base = 0;
+    for (size_t i = 0; i < ordered.size(); ++i) {
+        ordered[i].wg_base = base;
+        if (flags_override) ordered[i].flags = flags_override;
+        base += round_up(ordered[i].n_tiles * ordered[i].m_tiles, 8);
+        L.p[i] = ordered[i];
+    }
+    L.n = (int)ordered.size();
+    if (ctx->timing) {
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(ctx, hipEventCreate(&a));
+            HIP_TRY(ctx, hipEventCreate(&b));
+            ctx->ev_pool.emplace_back(a, b);
+        }
+        auto& ev = ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(ctx, hipEventRecord(ev.first, st));
+        rc_launch_gemm(L, base, st);
+        HIP_TRY(ctx, hipEventRecord(ev.second, st));
+    } else {
+        rc_launch_gemm(L, base, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const std::vector<GemmProblem>* extra, hipStream_t st) {
+    for (int phase = 0; phase < (with_lin2 ? 4 : 3); ++phase) {
+        std::vector<GemmProblem> ps;
+        for (const Stage& s : nets) {
+            if (phase == 0) ps.push_back(lin1_problem(ctx, s));
+            else if (phase == 3) ps.push_back(lin2_problem(ctx, s));
+            else ps.push_back(lstm_problem(ctx, s, phase - 1));
+        }
+        if (extra && phase < (int)extra->size()) ps.push_back((*extra)[phase]);
+        if (int rc = launch_problems(ctx, ps, nullptr, st)) return rc;
+    }
+    return RC_OK;
+}
+
+rc_params_dev dev_params(const rc_params& p) {
+    rc_params_dev d{};
+    d.conf_lo = p.conf_lo; d.conf_hi = p.conf_hi; d.tran_filter_num = p.tran_filter_num;
+    d.contact_threshold = p.contact_threshold; d.distance_threshold = p.distance_threshold;
+    d.height_threshold = p.height_threshold;
+    d.use_flat_floor = p.use_flat_floor; d.use_vision_updater = p.use_vision_updater;
+    d.use_imu_updater = p.use_imu_updater; d.live = p.live; d.update_vision_freq = p.update_vision_freq;
+    return d;
+}
+
+int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
+    const int B = ctx->B;
+    const FrameBuffers& fb = ctx->fb;
+    const rc_params_dev prm = dev_params(ctx->prm);
+    const int first = (flags & RC_FLAG_FIRST_FRAME) ? 1 : 0;
+
+    rc_launch_prep(fb, io, prm, B, first, st);
+    // inertial pose branch + visual pose branch (L144, L153)
+    if (int rc = run_stage(ctx, {{N2, 0, fb.x2, 128, fb.x3 + 72, 256}, {N4, (int)RC_ROW_VIS, fb.x4, 256, fb.x6 + 171, 256}}, true,
+                           nullptr, st)) return rc;
+    if (first) {                                                           // L155-156: rnn6 on every row
+        if (int rc = run_stage(ctx, {{N6, 0, fb.x6, 256, fb.pc, 4}}, true, nullptr, st)) return rc;
+    }
+    rc_launch_fuse(fb, io, prm, B, st);
+    // velocity, visual translation, pose, contact (L145, L161/165, L169-170) + rnn2.init_net (L181-182)
+    std::vector<GemmProblem> init;
+    if (ctx->prm.use_imu_updater) {
+        init.push_back(dense_problem(ctx, ctx->init[0], seg(fb.xi, 128, 0), ctx->hid1, 512, true, RC_ROW_REACH, fb.flags, nullptr, false));
+        init.push_back(dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), ctx->hid2, 1024, true, RC_ROW_REACH, fb.flags, nullptr, false));
+        init.push_back(dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), fb.init_out, 2048, false, RC_ROW_REACH, fb.flags, nullptr, false));
+    }
+    if (int rc = run_stage(ctx, {{N3, 0, fb.x3, 256, fb.vr, 4}, {N6, (int)RC_ROW_PC, fb.x6, 256, fb.pc, 4},
+                                 {N7, 0, fb.x78, 256, fb.r6d, 144}, {N8, 0, fb.x78, 256, fb.contact, 2}}, true, &init, st)) return rc;
+    rc_launch_tail(fb, io, prm, ctx->body, B, first, st);
+    // vision updater (L264-271): state-only steps, linear2 skipped
+    if (ctx->prm.use_vision_updater) {
+        if (int rc = run_stage(ctx, {{N6, (int)RC_ROW_UPD, fb.x6l, 256, nullptr, 0}, {N4, (int)RC_ROW_UPD, fb.x4l, 256, nullptr, 0}},
+                               false, nullptr, st)) return rc;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int check_ready(rc_ctx* ctx) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "weights not finalized (rc_finalize_weights)");
+    if (!ctx->have_body) return fail(ctx, RC_ERR_STATE, "body constants not set (rc_set_body)");
+    return RC_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int rc_default_params(int32_t live, rc_params* out) {
+    if (!out) return RC_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->conf_lo = live ? 0.85 : 0.7;            // net/sig_mp.py:28, 91-93
+    out->conf_hi = live ? 0.9 : 0.8;
+    out->contact_threshold = 0.7f;
+    out->distance_threshold = 10.0f;
+    out->height_threshold = 0.15f;
+    out->tran_filter_num = live ? 0.01 : 0.05;
+    out->use_flat_floor = 1; out->use_vision_updater = 1; out->use_imu_updater = 1;
+    out->live = live ? 1 : 0;
+    out->update_vision_freq = 30;
+    return RC_OK;
+}
+
+int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
+    if (!out || batch < 1 || batch > 65535) return fail(nullptr, RC_ERR_INVALID, "rc_create: bad batch");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, RC_ERR_HIP, "rc_create: no HIP device");
+    rc_ctx* ctx = new rc_ctx();
+    ctx->B = batch;
+    hipGetDevice(&ctx->dev);
+    rc_default_params(live, &ctx->prm);
+    const size_t B = (size_t)batch;
+    int rc = RC_OK;
+    FrameBuffers& fb = ctx->fb;
+#define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
+    for (int i = 0; i < 6 && !rc; ++i) {
+        NetDev& n = ctx->net[i];
+        n.in = kNets[i].in; n.H = kNets[i].H; n.out = kNets[i].out;
+        A(n.h, 4 * B * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, B * n.H);
+    }
+    A(ctx->hid1, B * 512); A(ctx->hid2, B * 1024); A(ctx->xtmp, B * 256);
+    A(fb.x2, B * 128); A(fb.x3, B * 256); A(fb.x4, B * 256); A(fb.x6, B * 256); A(fb.x78, B * 256);
+    A(fb.x4l, B * 256); A(fb.x6l, B * 256); A(fb.xi, B * 128);
+    A(fb.vr, B * 4); A(fb.pc, B * 4); A(fb.r6d, B * 144); A(fb.contact, B * 2); A(fb.init_out, B * 2048);
+    A(fb.flags, B); A(fb.regime, B); A(fb.kconf, B); A(fb.gravity, B * 3);
+    A(fb.last_pfoot, B * 6); A(fb.last_tran, B * 3); A(fb.floor, B * 33); A(fb.j_temp, B * 99);
+    A(fb.has_last, B); A(fb.n_floor, B); A(fb.first_reach, B); A(fb.uv_count, B); A(fb.trace, B * 8);
+    A(ctx->body, 1);
+#undef A
+    if (rc) { g_create_error = ctx->err; rc_destroy(ctx); return rc; }
+    fb.h2 = ctx->net[N2].h; fb.c2 = ctx->net[N2].c; fb.steps2 = ctx->net[N2].steps;
+    fb.h2_par_stride = (long long)B * 512; fb.h2_layer_stride = 2ll * B * 512; fb.c2_layer_stride = (long long)B * 512;
+    std::vector<float> g(B * 3);
+    for (size_t b = 0; b < B; ++b) { g[3 * b] = -0.0029f; g[3 * b + 1] = 0.9980f; g[3 * b + 2] = -0.0273f; }   // sig_mp.py:36
+    std::vector<int> ones(B, 1);
+    if (hipMemcpy(fb.gravity, g.data(), g.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(fb.first_reach, ones.data(), B * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        g_create_error = "rc_create: hipMemcpy failed"; rc_destroy(ctx); return RC_ERR_HIP;
+    }
+    *out = ctx;
+    return RC_OK;
+}
+
+int rc_destroy(rc_ctx* ctx) {
+    if (!ctx) return RC_OK;
+    for (void* p : ctx->allocs) hipFree(p);
+    for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete ctx;
+    return RC_OK;
+}
+
+const char* rc_last_error(const rc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rc_get_params(const rc_ctx* ctx, rc_params* out) {
+    if (!ctx || !out) return RC_ERR_INVALID;
+    *out = ctx->prm;
+    return RC_OK;
+}
+int rc_set_params(rc_ctx* ctx, const rc_params* p) {
+    if (!ctx || !p) return RC_ERR_INVALID;
+    if (!(p->conf_hi > p->conf_lo) || p->update_vision_freq < 0) return fail(ctx, RC_ERR_INVALID, "rc_set_params: bad range");
+    ctx->prm = *p;
+    return RC_OK;
+}
+
+int rc_load_weight(rc_ctx* ctx, const char* key, const float* host, int64_t numel) {
+    if (!ctx || !key || !host || numel <= 0) return RC_ERR_INVALID;
+    // validate the key against the reference state_dict layout
+    std::string k(key);
+    int64_t want = -1;
+    for (int i = 0; i < 6 && want < 0; ++i) {
+        const NetSpec& s = kNets[i];
+        const std::string p = std::string(s.name) + ".";
+        if (k.compare(0, p.size(), p)) continue;
+        const std::string r = k.substr(p.size());
+        const int64_t H = s.H;
+        if (r == "linear1.weight") want = H * s.in;
+        else if (r == "linear1.bias") want = H;
+        else if (r == "linear2.weight") want = (int64_t)s.out * H;
+        else if (r == "linear2.bias") want = s.out;
+        else if (r == "rnn.weight_ih_l0" || r == "rnn.weight_hh_l0" || r == "rnn.weight_ih_l1" || r == "rnn.weight_hh_l1") want = 4 * H * H;
+        else if (r == "rnn.bias_ih_l0" || r == "rnn.bias_hh_l0" || r == "rnn.bias_ih_l1" || r == "rnn.bias_hh_l1") want = 4 * H;
+        else if (i == N2) {
+            for (int q = 0; q < 3; ++q) {
+                if (r == "init_net." + std::to_string(2 * q) + ".weight") want = (int64_t)kInit[q][0] * kInit[q][1];
+                if (r == "init_net." + std::to_string(2 * q) + ".bias") want = kInit[q][1];
+            }
+        }
+    }
+    if (want < 0) return fail(ctx, RC_ERR_UNKNOWN_KEY, "rc_load_weight: unknown key " + k);
+    if (want != numel) return fail(ctx, RC_ERR_INVALID, "rc_load_weight: " + k + " expects " + std::to_string(want) + " values");
+    ctx->staged[k].assign(host, host + numel);
+    ctx->have_weights = false;
+    return RC_OK;
+}
+
+int rc_finalize_weights(rc_ctx* ctx) {
+    if (!ctx) return RC_ERR_INVALID;
+    for (int i = 0; i < 6; ++i) {
+        const NetSpec& s = kNets[i];
+        NetDev& n = ctx->net[i];
+        const std::string p = std::string(s.name) + ".";
+        const size_t H = s.H;
+        auto need = [&](const std::string& r, size_t numel) { return staged(ctx, p + r, numel); };
+        const auto *w1 = need("linear1.weight", H * s.in), *b1 = need("linear1.bias", H);
+        const auto *w2 = need("linear2.weight", (size_t)s.out * H), *b2 = need("linear2.bias", s.out);
+        if (!w1 || !b1 || !w2 || !b2) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing linear weights of " + p);
+        if (int rc = make_dense(ctx, n.lin1, *w1, *b1, s.H, s.in)) return rc;
+        if (int rc = make_dense(ctx, n.lin2, *w2, *b2, s.out, s.H)) return rc;
+        for (int l = 0; l < 2; ++l) {
+            const std::string sl = std::to_string(l);
+            const auto *wi = need("rnn.weight_ih_l" + sl, 4 * H * H), *wh = need("rnn.weight_hh_l" + sl, 4 * H * H);
+            const auto *bi = need("rnn.bias_ih_l" + sl, 4 * H), *bh = need("rnn.bias_hh_l" + sl, 4 * H);
+            if (!wi || !wh || !bi || !bh) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing LSTM weights of " + p);
+            // column n' of tile t = [i | f | g | o] x 16 units  <->  torch row g*H + t*16 + u (gate order i,f,g,o)
+            auto orig = [&](int np) { const int t = np / RC_NT, g = (np % RC_NT) / RC_UNITS, u = np % RC_UNITS; return (size_t)g * H + t * RC_UNITS + u; };
+            auto get = [&](int np, int k) -> float {
+                const size_t r = orig(np);
+                return k < (int)H ? (*wi)[r * H + k] : (*wh)[r * H + (k - H)];
+            };
+            std::vector<float> bp(4 * H);
+            for (size_t np = 0; np < 4 * H; ++np) bp[np] = (*bi)[orig((int)np)] + (*bh)[orig((int)np)];
+            if (int rc = upload(ctx, &n.Wl[l], pack_weights(4 * s.H, 2 * s.H, get))) return rc;
+            if (int rc = upload(ctx, &n.bl[l], bp)) return rc;
+        }
+    }
+    for (int q = 0; q < 3; ++q) {
+        const std::string p = "rnn2.init_net." + std::to_string(2 * q) + ".";
+        const auto *w = staged(ctx, p + "weight", (size_t)kInit[q][0] * kInit[q][1]), *b = staged(ctx, p + "bias", kInit[q][1]);
+        if (!w || !b) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing " + p);
+        if (int rc = make_dense(ctx, ctx->init[q], *w, *b, kInit[q][1], kInit[q][0])) return rc;
+    }
+    ctx->staged.clear();
+    ctx->have_weights = true;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return RC_OK;
+}
+
+int rc_set_body(rc_ctx* ctx, const int32_t* parent, const float* J, const float* w33, const float* v33) {
+    if (!ctx || !parent || !J || !w33 || !v33) return RC_ERR_INVALID;
+    BodyConst b{};
+    for (int i = 0; i < 24; ++i) {
+        b.parent[i] = i == 0 ? 0 : parent[i];
+        if (i > 0 && (parent[i] < 0 || parent[i] >= i)) return fail(ctx, RC_ERR_INVALID, "rc_set_body: parent[i] must be in [0, i)");
+        b.level[i] = i == 0 ? 0 : b.level[parent[i]] + 1;
+        if (b.level[i] > 9) return fail(ctx, RC_ERR_INVALID, "rc_set_body: kinematic tree deeper than 9");
+    }
+    for (int i = 0; i < 24; ++i)
+        for (int c = 0; c < 3; ++c) {
+            b.jrest[i][c] = J[3 * i + c] - J[c];                                   // model.py:87
+            b.bone[i][c] = i == 0 ? b.jrest[0][c] : (J[3 * i + c] - J[c]) - (J[3 * parent[i] + c] - J[c]);   // spatial.py:148-167
+        }
+    for (int v = 0; v < 33; ++v) {
+        b.override_joint[v] = -1;
+        for (int c = 0; c < 3; ++c) b.v33[v][c] = v33[3 * v + c] - J[c];
+        for (int j = 0; j < 24; ++j) b.w33[v][j] = w33[24 * v + j];
+    }
+    const int ov[12][2] = {{11, 16}, {12, 17}, {13, 18}, {14, 19}, {15, 20}, {16, 21},      // sig_mp.py:295-298
+                           {23, 1},  {24, 2},  {25, 4},  {26, 5},  {27, 7},  {28, 8}};
+    for (auto& o : ov) b.override_joint[o[0]] = o[1];
+    HIP_TRY(ctx, hipMemcpy(ctx->body, &b, sizeof(b), hipMemcpyHostToDevice));
+    ctx->have_body = true;
+    return RC_OK;
+}
+
+int rc_set_gravity(rc_ctx* ctx, const float* g) {
+    if (!ctx || !g) return RC_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpy(ctx->fb.gravity, g, (size_t)ctx->B * 3 * sizeof(float), hipMemcpyHostToDevice));
+    return RC_OK;
+}
+
+int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream) {
+    if (!ctx) return RC_ERR_INVALID;
+    float* h[6]; float* c[6]; int H[6];
+    for (int i = 0; i < 6; ++i) { h[i] = ctx->net[i].h; c[i] = ctx->net[i].c; H[i] = ctx->net[i].H; }
+    rc_launch_reset(ctx->fb, h, c, H, row_mask, ctx->B, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran, uint32_t flags,
+            float* pose_out, float* tran_out, void* stream) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (!j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_step: null buffer");
+    FrameIO io{j2dc, accc, oric, first_tran, pose_out, tran_out, 99, 18, 54, 216, 3};
+    return step_impl(ctx, io, flags, (hipStream_t)stream);
+}
+
+int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const float* accc, int64_t rs_acc, const float* oric,
+                int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out, int64_t rs_pose, float* tran_out,
+                int64_t rs_tran, void* stream) {
+    if (int rc = check_ready(ctx)) return rc;
+    if (T < 0 || !j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_sequence: bad argument");
+    for (int t = 0; t < T; ++t) {
+        FrameIO io{j2dc + (int64_t)t * 99, accc + (int64_t)t * 18, oric + (int64_t)t * 54, t == 0 ? first_tran : nullptr,
+                   pose_out + (int64_t)t * 216, tran_out + (int64_t)t * 3, rs_j2d, rs_acc, rs_ori, rs_pose, rs_tran};
+        if (int rc = step_impl(ctx, io, t == 0 ? flags : 0u, (hipStream_t)stream)) return rc;
+    }
+    return RC_OK;
+}
+
+int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!r6d || !R || n < 0) return RC_ERR_INVALID;
+    rc_launch_r6d(r6d, R, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_ik_r(rc_ctx* ctx, const float* Rg, float* Rl, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_ik_r: body not set") : RC_ERR_INVALID;
+    rc_launch_ik(ctx->body, Rg, Rl, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_fk_bone(rc_ctx* ctx, const float* Rg, float* joints, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_fk_bone: body not set") : RC_ERR_INVALID;
+    rc_launch_fk_bone(ctx->body, Rg, joints, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_body_fk(rc_ctx* ctx, const float* pose, const float* tran, float* grot, float* joint, float* j33, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_body_fk: body not set") : RC_ERR_INVALID;
+    if (!pose || !tran || !joint || !j33) return fail(ctx, RC_ERR_INVALID, "rc_body_fk: null buffer");
+    rc_launch_body_fk(ctx->body, pose, tran, grot, joint, j33, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K, float sigma, float* loss,
+                       int64_t T, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_reproj_residual: body not set") : RC_ERR_INVALID;
+    if (!pose || !tran || !kp || !K || !loss) return fail(ctx, RC_ERR_INVALID, "rc_reproj_residual: null buffer");
+    rc_launch_residual(ctx->body, pose, tran, kp, K, sigma, loss, T, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+
+int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* row_mask, float* y, void* stream) {
+    if (!ctx || !net || !x || !y) return RC_ERR_INVALID;
+    if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "rc_lstm_step: weights not finalized");
+    const int ni = net_index(net);
+    if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_lstm_step: unknown net ") + net);
+    hipStream_t st = (hipStream_t)stream;
+    const NetDev& n = ctx->net[ni];
+    // stage x into a zero-padded [B, 256] buffer (K is padded to 128/256 and loads are 16-byte aligned)
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->xtmp, 256 * sizeof(float), x, n.in * sizeof(float), n.in * sizeof(float), ctx->B,
+                                  hipMemcpyDeviceToDevice, st));
+    Stage s{ni, row_mask ? 255 : 0, ctx->xtmp, 256, y, n.out};
+    for (int phase = 0; phase < 4; ++phase) {
+        GemmProblem p = phase == 0 ? lin1_problem(ctx, s) : (phase == 3 ? lin2_problem(ctx, s) : lstm_problem(ctx, s, phase - 1));
+        if (int rc = launch_problems(ctx, {p}, row_mask, st)) return rc;
+    }
+    return RC_OK;
+}
+
+int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, void* stream) {
+    if (!ctx || !net || !h_host || !c_host) return RC_ERR_INVALID;
+    const int ni = net_index(net);
+    if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_get_state: unknown net ") + net);
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    const NetDev& n = ctx->net[ni];
+    const size_t B = ctx->B, H = n.H;
+    std::vector<float> h(4 * B * H);
+    std::vector<int> steps(B);
+    HIP_TRY(ctx, hipMemcpy(h.data(), n.h, h.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(steps.data(), n.steps, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(c_host, n.c, 2 * B * H * 4, hipMemcpyDeviceToHost));
+    for (size_t l = 0; l < 2; ++l)
+        for (size_t b = 0; b < B; ++b)
+            std::memcpy(h_host + (l * B + b) * H, h.data() + ((l * 2 + (steps[b] & 1)) * B + b) * H, H * 4);
+    return RC_OK;
+}
+
+int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream) {
+    if (!ctx || !trace_host) return RC_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(ctx, hipMemcpy(trace_host, ctx->fb.trace, (size_t)ctx->B * 8 * 4, hipMemcpyDeviceToHost));
+    return RC_OK;
+}
+
+int rc_gemm_timing(rc_ctx* ctx, int32_t enable) {
+    if (!ctx) return RC_ERR_INVALID;
+    ctx->timing = enable != 0;
+    if (enable) { ctx->ev_used = 0; ctx->timed_ms = 0.0; ctx->timed_launches = 0; }
+    return RC_OK;
+}
+
+int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches) {
+    if (!ctx || !total_ms || !launches) return RC_ERR_INVALID;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pool[i].second));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        ctx->timed_ms += ms;
+        ctx->timed_launches += 1;
+    }
+    ctx->ev_used = 0;
+    *total_ms = ctx->timed_ms;
+    *launches = ctx->timed_launches;
+    return RC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,631 @@
+// Per-frame fusion logic of sig_mp on gfx950: everything of Net.forward_online (net/sig_mp.py:113-274) that is
+// not a sub-net GEMM, as three wave-per-body kernels with all branching on device (the reference syncs the host
+// with .item() six times per frame):
+//   rc_prep_kernel  L138-152  mean confidence -> regime / row flags, root-frame IMU transform, bbox
+//                             normalisation, concatenated sub-net inputs
+//   rc_fuse_kernel  L154-167, L178-180  camera->root rotation of rnn4's joints, lerp, init_net trigger
+//   rc_tail_kernel  L173-273  6D->R, IK, foot FK, translation / contact / floor logic, full FK + 33-landmark
+//                             skinning + sync_mp3d, vision-updater inputs, init_net state write
+// One 64-lane wave owns one body: lanes map to keypoints (33), joints (24) or matrix entries; reductions are
+// DPP/shuffle butterflies; intermediates live in LDS. HBM traffic per body-frame is the 171-float input row,
+// the 219-float output row and ~3 KB of padded sub-net input rows -- these kernels are latency-, not
+// bandwidth-bound, which is why they are kept to three launches.
+#include "rc_internal.h"
+
+#define LD_X2 128
+#define LD_X3 256
+#define LD_X4 256
+#define LD_X6 256
+#define LD_X78 256
+#define LD_XI 128
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float norm3(const float* v) { return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+
+// C = A * B (3x3 row-major)
+__device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+}
+// C = A^T * B
+__device__ __forceinline__ void mat3T_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = (A[r] * B[c] + A[3 + r] * B[3 + c]) + A[6 + r] * B[6 + c];
+}
+// y = A * x
+__device__ __forceinline__ void mat3_vec(const float* A, const float* x, float* y) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[r] = (A[3 * r] * x[0] + A[3 * r + 1] * x[1]) + A[3 * r + 2] * x[2];
+}
+
+// articulate/math/angular.py:249-264: columns (c0, c1, c0 x c1), NaN -> 0, no epsilon.
+__device__ __forceinline__ void r6d_to_R(const float* v, float* R) {
+    const float a[3] = {v[0], v[1], v[2]}, b[3] = {v[3], v[4], v[5]};
+    const float na = norm3(a);
+    const float c0[3] = {a[0] / na, a[1] / na, a[2] / na};
+    const float d = (c0[0] * b[0] + c0[1] * b[1]) + c0[2] * b[2];
+    const float t[3] = {b[0] - d * c0[0], b[1] - d * c0[1], b[2] - d * c0[2]};
+    const float nt = norm3(t);
+    const float c1[3] = {t[0] / nt, t[1] / nt, t[2] / nt};
+    const float c2[3] = {c0[1] * c1[2] - c0[2] * c1[1], c0[2] * c1[0] - c0[0] * c1[2], c0[0] * c1[1] - c0[1] * c1[0]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        R[3 * r + 0] = (c0[r] != c0[r]) ? 0.0f : c0[r];
+        R[3 * r + 1] = (c1[r] != c1[r]) ? 0.0f : c1[r];
+        R[3 * r + 2] = (c2[r] != c2[r]) ? 0.0f : c2[r];
+    }
+}
+
+struct WaveScratch {
+    float Rg[24][9];    // global rotations predicted by rnn7
+    float Rl[24][9];    // local rotations (pose)
+    float G[24][9];     // global rotations re-chained from the local pose
+    float P[24][3];     // joint positions, root at the origin
+    float T[24][3];     // P_j - G_j * jrest_j   (articulate/model.py:235)
+    float J33[33][3];   // landmarks
+};
+
+// joint `j` of fk(glb_pose) (net/sig_mp.py:131-135): sum of parent-rotated rest bone vectors, root -> leaf order.
+__device__ __forceinline__ void bone_chain(const BodyConst* body, const float (*Rg)[9], int j, float* out) {
+    int path[12], n = 0;
+    for (int q = j; q > 0; q = body->parent[q]) path[n++] = q;
+    out[0] = out[1] = out[2] = 0.0f;
+    for (int t = n - 1; t >= 0; --t) {
+        const int q = path[t];
+        float pb[3];
+        mat3_vec(Rg[body->parent[q]], body->bone[q], pb);
+        if (t == n - 1) { out[0] = pb[0]; out[1] = pb[1]; out[2] = pb[2]; }
+        else { out[0] += pb[0]; out[1] += pb[1]; out[2] += pb[2]; }
+    }
+}
+
+// ParametricModel.forward_kinematics(calc_mesh=True) restricted to 33 landmarks + sync_mp3d
+// (articulate/model.py:229-241, net/sig_mp.py:287-299). Expects s.Rl filled and synced; one wave.
+__device__ __forceinline__ void wave_body_fk(const BodyConst* body, WaveScratch& s, const float* tran, int lane) {
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.G[0][k] = s.Rl[0][k];
+        s.P[0][0] = s.P[0][1] = s.P[0][2] = 0.0f;
+    }
+    __syncthreads();
+    const int lvl = lane < 24 ? body->level[lane] : -1;
+    for (int l = 1; l < 10; ++l) {
+        if (lvl == l) {
+            const int p = body->parent[lane];
+            float g[9], pb[3];
+            mat3_mul(s.G[p], s.Rl[lane], g);
+            mat3_vec(s.G[p], body->bone[lane], pb);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s.G[lane][k] = g[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s.P[lane][k] = pb[k] + s.P[p][k];
+        }
+        __syncthreads();
+    }
+    if (lane < 24) {
+        float gj[3];
+        mat3_vec(s.G[lane], body->jrest[lane], gj);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s.T[lane][k] = s.P[lane][k] - gj[k];
+    }
+    __syncthreads();
+    if (lane < 33) {
+        float out[3];
+        const int oj = body->override_joint[lane];
+        if (oj >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = s.P[oj][k] + tran[k];
+        } else {
+            float A[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) A[k] = 0.0f;
+            for (int j = 0; j < 24; ++j) {
+                const float w = body->w33[lane][j];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    A[4 * r + 0] += w * s.G[j][3 * r + 0];
+                    A[4 * r + 1] += w * s.G[j][3 * r + 1];
+                    A[4 * r + 2] += w * s.G[j][3 * r + 2];
+                    A[4 * r + 3] += w * s.T[j][r];
+                }
+            }
+            const float* v = body->v33[lane];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                out[r] = (((A[4 * r] * v[0] + A[4 * r + 1] * v[1]) + A[4 * r + 2] * v[2]) + A[4 * r + 3]) + tran[r];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s.J33[lane][k] = out[k];
+    }
+    __syncthreads();
+}
+
+// bbox-normalised keypoints of lane `lane` (< 33): xy / max(width, height), rows != 23 relative to row 23.
+__device__ __forceinline__ void bbox_normalise(float x, float y, int lane, float& xn, float& yn) {
+    const bool on = lane < 33;
+    const float inf = __builtin_inff();
+    const float w = wave_max(on ? x : -inf) - wave_min(on ? x : inf);
+    const float h = wave_max(on ? y : -inf) - wave_min(on ? y : inf);
+    const float sc = fmaxf(w, h);
+    xn = x / sc;
+    yn = y / sc;
+    const float hx = __shfl(xn, 23), hy = __shfl(yn, 23);
+    if (lane != 23) { xn -= hx; yn -= hy; }
+}
+
+// =========================================================================================== prep (L138-152)
+__global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* kp = io.j2d + row * io.s_j2d;
+    const float* acc = io.acc + row * io.s_acc;
+    const float* ori = io.ori + row * io.s_ori;
+    float x = 0.f, y = 0.f, cf = 0.f;
+    if (lane < 33) { x = kp[3 * lane]; y = kp[3 * lane + 1]; cf = kp[3 * lane + 2]; }
+    const float c = wave_sum(cf) / 33.0f;                                 // L138
+    const double c64 = (double)c;                                         // python-double compares
+    const bool gt_lo = c64 > prm.conf_lo, is_hi = c64 >= prm.conf_hi;
+    const bool refresh = !prm.live || fb.uv_count[row] == 0;
+    float xn, yn;
+    bbox_normalise(x, y, lane, xn, yn);                                   // L150-152
+    float Rcr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];                     // L139
+    if (lane == 0) {
+        unsigned f = 0;
+        if (gt_lo || first_frame) f |= RC_ROW_VIS;                        // L149
+        if (gt_lo) f |= RC_ROW_PC;                                        // L161 / L165
+        if (!gt_lo && refresh && prm.use_vision_updater) f |= RC_ROW_UPD; // L264
+        fb.flags[row] = (unsigned char)f;
+        fb.regime[row] = is_hi ? 2 : (gt_lo ? 1 : 0);
+        fb.kconf[row] = (c64 - prm.conf_lo) / (prm.conf_hi - prm.conf_lo);   // L163
+        int* tr = fb.trace + row * 8;
+        tr[0] = is_hi ? 2 : (gt_lo ? 1 : 0);
+        tr[1] = 0; tr[2] = 0; tr[4] = 0; tr[5] = 0; tr[6] = 0; tr[7] = 0;
+    }
+    if (lane < 18) {                                                      // accr = accc . Rcr, L142
+        const int i = lane / 3, j = lane % 3;
+        const float v = (acc[3 * i] * Rcr[j] + acc[3 * i + 1] * Rcr[3 + j]) + acc[3 * i + 2] * Rcr[6 + j];
+        fb.x2[row * LD_X2 + lane] = v;
+        fb.x3[row * LD_X3 + lane] = v;
+        fb.x78[row * LD_X78 + lane] = v;
+        const float a = acc[lane];
+        fb.x4[row * LD_X4 + lane] = a;
+        fb.x6[row * LD_X6 + lane] = a;
+        fb.x4l[row * LD_X4 + lane] = a;
+        fb.x6l[row * LD_X6 + lane] = a;
+    }
+    if (lane < 54) {                                                      // orir = Rcr^T . oric, L143
+        const int i = lane / 9, r = (lane % 9) / 3, cc = lane % 3;
+        const float* o = ori + 9 * i;
+        const float v = (Rcr[r] * o[cc] + Rcr[3 + r] * o[3 + cc]) + Rcr[6 + r] * o[6 + cc];
+        fb.x2[row * LD_X2 + 18 + lane] = v;
+        fb.x3[row * LD_X3 + 18 + lane] = v;
+        fb.x78[row * LD_X78 + 18 + lane] = v;
+        const float a = ori[lane];
+        fb.x4[row * LD_X4 + 18 + lane] = a;
+        fb.x6[row * LD_X6 + 18 + lane] = a;
+        fb.x4l[row * LD_X4 + 18 + lane] = a;
+        fb.x6l[row * LD_X6 + 18 + lane] = a;
+    }
+    if (lane < 33) {
+        float* d4 = fb.x4 + row * LD_X4 + 72 + 3 * lane;
+        d4[0] = xn; d4[1] = yn; d4[2] = cf;
+        float* d6 = fb.x6 + row * LD_X6 + 72 + 3 * lane;
+        d6[0] = x; d6[1] = y; d6[2] = cf;
+    }
+}
+
+// =================================================================================== fuse (L154-167, L178-180)
+__global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int row = idx / 24, j = idx % 24;
+    if (row >= B) return;
+    const int regime = fb.regime[row];
+    if (j == 23) {                                                        // L178-180
+        if (regime == 2 && prm.use_imu_updater && fb.first_reach[row]) {
+            fb.first_reach[row] = 0;
+            fb.flags[row] |= RC_ROW_REACH;
+            fb.trace[row * 8 + 4] = 1;
+        }
+        return;
+    }
+    const float* R = io.ori + row * io.s_ori + 45;
+    const float* vc = fb.x6 + row * LD_X6 + 171 + 3 * j;                  // j3dc (rnn4 output)
+    const float* vi = fb.x3 + row * LD_X3 + 72 + 3 * j;                   // j3dr_i (rnn2 output)
+    float out[3];
+    if (regime == 0) {
+        out[0] = vi[0]; out[1] = vi[1]; out[2] = vi[2];
+    } else {
+        float v[3];                                                        // j3dc.view(23,3).mm(Rcr), L154
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (vc[0] * R[c] + vc[1] * R[3 + c]) + vc[2] * R[6 + c];
+        if (regime == 2) {
+            out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+        } else {                                                           // lerp with a python-double weight, L163-164
+            const double k = fb.kconf[row];
+            const float w1 = (float)(1.0 - k), w2 = (float)k;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = vi[c] * w1 + v[c] * w2;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fb.x78[row * LD_X78 + 72 + 3 * j + c] = out[c];
+        fb.xi[row * LD_XI + 3 * j + c] = out[c];
+    }
+}
+
+// ============================================================================================ tail (L173-273)
+__global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
+                                                     const BodyConst* __restrict__ body, int B, int first_frame) {
+    __shared__ WaveScratch s;
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float* ori = io.ori + row * io.s_ori;
+    float Rcr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];
+
+    // L173: 6D -> global rotations (root-relative frame)
+    if (lane < 24) {
+        float R[9];
+        r6d_to_R(fb.r6d + row * 144 + 6 * lane, R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.Rg[lane][k] = R[k];
+    }
+    __syncthreads();
+    // L174-175: local rotations, root replaced by the pelvis IMU orientation
+    if (lane < 24) {
+        float R[9];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = Rcr[k];
+        } else {
+            mat3T_mul(s.Rg[body->parent[lane]], s.Rg[lane], R);
+        }
+        float* po = io.pose_out + row * io.s_pose + 9 * lane;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s.Rl[lane][k] = R[k]; po[k] = R[k]; }
+    }
+    // L186: feet from the predicted GLOBAL rotations, rotated to the camera frame
+    float pf[2][3];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float jf[3];
+        bone_chain(body, s.Rg, 10 + f, jf);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pf[f][c] = (jf[0] * Rcr[3 * c] + jf[1] * Rcr[3 * c + 1]) + jf[2] * Rcr[3 * c + 2];
+    }
+
+    // L187-203: root translation
+    const float c0 = sigmoidf_(fb.contact[row * 2]), c1 = sigmoidf_(fb.contact[row * 2 + 1]);   // L170
+    const float cmax = fmaxf(c0, c1);
+    const int foot = c1 > c0 ? 1 : 0;
+    const bool has_last = fb.has_last[row] != 0;
+    const bool use_vel = (cmax < prm.contact_threshold) || !has_last;
+    const int regime = fb.regime[row];
+    const double k64 = fb.kconf[row];
+    const float pc[3] = {fb.pc[row * 4], fb.pc[row * 4 + 1], fb.pc[row * 4 + 2]};
+    float tran[3];
+    {
+        const float* vr = fb.vr + row * 4;
+        float v[3];
+        if (use_vel) {
+            mat3_vec(Rcr, vr, v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = v[c] * 3.0f / 60.0f;        // vel_scale / 60, L188
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = fb.last_pfoot[row * 6 + 3 * foot + c] - pf[foot][c];   // L190
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tran[c] = has_last ? fb.last_tran[row * 3 + c] + v[c] : v[c];
+    }
+    bool far = false;
+    if (regime == 2) {                                                     // L196-203
+        const double kf = k64 > 1.0 ? 1.0 : k64;
+        const float d[3] = {pc[0] - tran[0], pc[1] - tran[1], pc[2] - tran[2]};
+        far = norm3(d) > prm.distance_threshold || prm.tran_filter_num > 1.0;
+        if (far) {
+            tran[0] = pc[0]; tran[1] = pc[1]; tran[2] = pc[2];
+        } else {
+            const double w = prm.tran_filter_num * kf;
+            const float w1 = (float)(1.0 - w), w2 = (float)w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tran[c] = tran[c] * w1 + pc[c] * w2;
+        }
+    }
+    // L206-221: floor height along gravity
+    const float* g = fb.gravity + row * 3;
+    const bool on_ground = cmax > prm.contact_threshold;
+    const bool ft_given = io.first_tran != nullptr;
+    int n_floor = fb.n_floor[row];
+    float p0[3], p1[3], pick[3] = {0.f, 0.f, 0.f};
+    int appended = -1;
+    {
+        const float d0 = ((pf[0][0] + tran[0]) * g[0] + (pf[0][1] + tran[1]) * g[1]) + (pf[0][2] + tran[2]) * g[2];
+        const float d1 = ((pf[1][0] + tran[0]) * g[0] + (pf[1][1] + tran[1]) * g[1]) + (pf[1][2] + tran[2]) * g[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p0[c] = d0 * g[c]; p1[c] = d1 * g[c]; }
+    }
+    const bool p0_lt_p1 = norm3(p0) < norm3(p1);
+    if (n_floor < 11 && !first_frame && !ft_given && on_ground && prm.use_flat_floor && regime == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pick[c] = p0_lt_p1 ? p1[c] : p0[c];
+        appended = n_floor;
+        n_floor += 1;
+    }
+    if (prm.use_flat_floor && n_floor > 10 && on_ground) {
+        float m[3] = {0.f, 0.f, 0.f};
+        for (int q = 5; q < 11; ++q) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float e = (q == appended) ? pick[c] : fb.floor[row * 33 + 3 * q + c];
+                m[c] = (q == 5) ? e : m[c] + e;
+            }
+        }
+        float d0[3], d1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { m[c] = m[c] / 6.0f; d1[c] = m[c] - p1[c]; d0[c] = m[c] - p0[c]; }
+        if (p0_lt_p1 && norm3(d1) < prm.height_threshold) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tran[c] += d1[c];
+        } else if (norm3(d0) < prm.height_threshold) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tran[c] += d0[c];
+        }
+    }
+    if (ft_given) {                                                        // L222-225
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tran[c] = io.first_tran[row * 3 + c];
+    } else if (first_frame) {
+        tran[0] = pc[0]; tran[1] = pc[1]; tran[2] = pc[2];
+    }
+    const unsigned flags = fb.flags[row];
+    const bool live = prm.live != 0;
+    const int uvc = fb.uv_count[row];
+    const bool refresh = !live || uvc == 0;
+    __syncthreads();   // all lanes have read the per-row state; lane 0 may now overwrite it
+    if (lane == 0) {                                                       // L227, L273
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fb.last_pfoot[row * 6 + c] = pf[0][c];
+            fb.last_pfoot[row * 6 + 3 + c] = pf[1][c];
+            fb.last_tran[row * 3 + c] = tran[c];
+            io.tran_out[row * io.s_tran + c] = tran[c];
+        }
+        fb.has_last[row] = 1;
+        fb.n_floor[row] = n_floor;
+        if (appended >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fb.floor[row * 33 + 3 * appended + c] = pick[c];
+        }
+        if (live) fb.uv_count[row] = refresh ? prm.update_vision_freq : uvc - 1;   // L234-242
+        int* tr = fb.trace + row * 8;
+        tr[1] = ((flags & RC_ROW_VIS) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
+        tr[2] = (first_frame ? 1 : 0) + ((flags & RC_ROW_PC) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
+        tr[3] = n_floor;
+        tr[5] = use_vel ? 1 : 0;
+        tr[6] = foot;
+        tr[7] = (far && regime == 2) ? 1 : 0;
+    }
+
+    // L228-242: mesh landmarks from the LOCAL pose chained from the camera-frame root
+    wave_body_fk(body, s, tran, lane);
+    if (live) {
+        if (lane < 33) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (refresh) fb.j_temp[row * 99 + 3 * lane + c] = s.J33[lane][c];
+                else s.J33[lane][c] = fb.j_temp[row * 99 + 3 * lane + c];
+            }
+        }
+        __syncthreads();
+    }
+
+    // L264-271: inputs of the vision updater (rnn6 on raw re-projection, rnn4 on the normalised one)
+    if (flags & RC_ROW_UPD) {
+        float x = 0.f, y = 0.f, z1 = 0.f;
+        if (lane < 33) {
+            const float z = s.J33[lane][2];
+            x = s.J33[lane][0] / z; y = s.J33[lane][1] / z; z1 = z / z;    // L265
+            float* d6 = fb.x6l + row * LD_X6 + 72 + 3 * lane;
+            d6[0] = x; d6[1] = y; d6[2] = z1;
+        }
+        if (lane >= 1 && lane < 24) {                                     // L266: joint[1:] - joint[:1]
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                fb.x6l[row * LD_X6 + 171 + 3 * (lane - 1) + c] = (s.P[lane][c] + tran[c]) - (s.P[0][c] + tran[c]);
+        }
+        float xn, yn;
+        bbox_normalise(x, y, lane, xn, yn);                                // L268-270
+        if (lane < 33) {
+            float* d4 = fb.x4l + row * LD_X4 + 72 + 3 * lane;
+            d4[0] = xn; d4[1] = yn; d4[2] = z1;
+        }
+    }
+    // L181-183: rnn2 state <- init_net(j3dr); takes effect from the next frame
+    if (flags & RC_ROW_REACH) {
+        const int cur = fb.steps2[row] & 1;
+        const float* src = fb.init_out + row * 2048;
+        for (int e = lane; e < 512; e += 64) {
+            fb.h2[cur * fb.h2_par_stride + row * 512 + e] = src[e];
+            fb.h2[fb.h2_layer_stride + cur * fb.h2_par_stride + row * 512 + e] = src[512 + e];
+            fb.c2[row * 512 + e] = src[1024 + e];
+            fb.c2[fb.c2_layer_stride + row * 512 + e] = src[1536 + e];
+        }
+    }
+}
+
+// ================================================================================================== reset
+struct ResetArgs {
+    float* h[6];
+    float* c[6];
+    long long h_elems[6];   // elements of h per (layer, parity) = B * H
+    int H[6];
+};
+__global__ __launch_bounds__(256) void rc_reset_kernel(FrameBuffers fb, ResetArgs a, const unsigned char* mask, int B) {
+    const int row = blockIdx.x;
+    if (mask && !mask[row]) return;
+    for (int n = 0; n < 6; ++n) {
+        const int H = a.H[n];
+        for (int e = threadIdx.x; e < H; e += 256) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.h[n][q * a.h_elems[n] + (long long)row * H + e] = 0.0f;   // 2 layers x 2 parities
+            a.c[n][(long long)row * H + e] = 0.0f;
+            a.c[n][a.h_elems[n] + (long long)row * H + e] = 0.0f;
+        }
+    }
+    if (threadIdx.x == 0) {                                               // net/sig_mp.py:95-104
+        fb.has_last[row] = 0;
+        fb.n_floor[row] = 0;
+        fb.first_reach[row] = 1;
+    }
+}
+
+// ============================================================================================ per-op kernels
+__global__ void rc_r6d_kernel(const float* r6d, float* R, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[6], M[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = r6d[6 * i + k];
+    r6d_to_R(v, M);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[9 * i + k] = M[k];
+}
+
+__global__ void rc_ik_kernel(const BodyConst* __restrict__ body, const float* Rg, float* Rl, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = idx / 24;
+    const int j = (int)(idx % 24);
+    if (b >= n) return;
+    const float* g = Rg + (b * 24 + j) * 9;
+    float M[9];
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M[k] = g[k];
+    } else {
+        mat3T_mul(Rg + (b * 24 + body->parent[j]) * 9, g, M);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rl[(b * 24 + j) * 9 + k] = M[k];
+}
+
+__global__ __launch_bounds__(64) void rc_fk_bone_kernel(const BodyConst* __restrict__ body, const float* Rg, float* joints, long long n) {
+    __shared__ float sR[24][9];
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 216; e += 64) sR[e / 9][e % 9] = Rg[b * 216 + e];
+    __syncthreads();
+    if (lane < 24) {
+        float o[3];
+        bone_chain(body, sR, lane, o);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) joints[(b * 24 + lane) * 3 + c] = o[c];
+    }
+}
+
+__global__ __launch_bounds__(64) void rc_body_fk_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
+                                                        float* grot, float* joint, float* j33) {
+    __shared__ WaveScratch s;
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 216; e += 64) s.Rl[e / 9][e % 9] = pose[b * 216 + e];
+    const float t[3] = {tran[b * 3], tran[b * 3 + 1], tran[b * 3 + 2]};
+    __syncthreads();
+    wave_body_fk(body, s, t, lane);
+    if (grot) for (int e = lane; e < 216; e += 64) grot[b * 216 + e] = s.G[e / 9][e % 9];
+    if (lane < 24) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) joint[(b * 24 + lane) * 3 + c] = s.P[lane][c] + t[c];
+    }
+    if (lane < 33) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) j33[(b * 33 + lane) * 3 + c] = s.J33[lane][c];
+    }
+}
+
+// smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
+// (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
+__global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
+                                                         const float* kp, const float* K, float sigma, float* loss) {
+    __shared__ WaveScratch s;
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 216; e += 64) s.Rl[e / 9][e % 9] = pose[b * 216 + e];
+    const float t[3] = {tran[b * 3], tran[b * 3 + 1], tran[b * 3 + 2]};
+    __syncthreads();
+    wave_body_fk(body, s, t, lane);
+    if (lane < 33) {
+        const float z = s.J33[lane][2];
+        const float q[3] = {s.J33[lane][0] / z, s.J33[lane][1] / z, z / z};
+        const float u = (K[0] * q[0] + K[1] * q[1]) + K[2] * q[2];
+        const float v = (K[3] * q[0] + K[4] * q[1]) + K[5] * q[2];
+        const float* k3 = kp + (b * 33 + lane) * 3;
+        const bool ign = (lane >= 1 && lane <= 9) || lane == 31 || lane == 32;
+        const float cf = ign ? 0.0f : k3[2];
+        const float s2 = sigma * sigma;
+        const float dx = u - k3[0], dy = v - k3[1];
+        const float ex = (s2 * (dx * dx)) / (s2 + dx * dx), ey = (s2 * (dy * dy)) / (s2 + dy * dy);
+        loss[b * 33 + lane] = (cf * cf) * (ex + ey);
+    }
+}
+
+// ================================================================================================ launchers
+void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t st) {
+    hipLaunchKernelGGL(rc_prep_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, B, first_frame);
+}
+void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t st) {
+    hipLaunchKernelGGL(rc_fuse_kernel, dim3((B * 24 + 255) / 256), dim3(256), 0, st, fb, io, prm, B);
+}
+void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
+                    int first_frame, hipStream_t st) {
+    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame);
+}
+void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
+                     int B, hipStream_t st) {
+    ResetArgs a;
+    for (int n = 0; n < 6; ++n) { a.h[n] = h[n]; a.c[n] = c[n]; a.H[n] = hidden[n]; a.h_elems[n] = (long long)B * hidden[n]; }
+    hipLaunchKernelGGL(rc_reset_kernel, dim3(B), dim3(256), 0, st, fb, a, mask, B);
+}
+void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rc_r6d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r6d, R, n);
+}
+void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rc_ik_kernel, dim3((unsigned)((n * 24 + 255) / 256)), dim3(256), 0, st, body, Rg, Rl, n);
+}
+void rc_launch_fk_bone(const BodyConst* body, const float* Rg, float* joints, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rc_fk_bone_kernel, dim3((unsigned)n), dim3(64), 0, st, body, Rg, joints, n);
+}
+void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tran, float* grot, float* joint, float* j33,
+                       long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rc_body_fk_kernel, dim3((unsigned)n), dim3(64), 0, st, body, pose, tran, grot, joint, j33);
+}
+void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K, float sigma,
+                        float* loss, long long T, hipStream_t st) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(rc_residual_kernel, dim3((unsigned)T), dim3(64), 0, st, body, pose, tran, kp, K, sigma, loss);
+}

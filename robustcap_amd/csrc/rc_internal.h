@@ -1,0 +1,115 @@
+// Internal declarations shared by the HIP translation units of librobustcap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- GEMM tiling -------------------------------------------------------------------------------------------
+// One workgroup = RC_NW waves = one 32-row x 64-column output tile; the K range is split across the waves
+// (in-workgroup split-K) and reduced through LDS. Each wave runs v_mfma_f32_32x32x2_f32 on two 32-column
+// blocks that share the A operand.
+#define RC_MT 32          // rows per workgroup tile
+#define RC_NT 64          // columns per workgroup tile (LSTM: 16 hidden units x 4 gates)
+#define RC_NW 4           // waves per workgroup (K split)
+#define RC_G 4            // 8-wide k-chunks fetched per prefetch group
+#define RC_KALIGN (8 * RC_G * RC_NW)   // padded K granularity = 128
+#define RC_UNITS 16       // hidden units per LSTM tile
+#define RC_MAX_PROB 6     // problems fused in one launch
+
+enum { RC_EPI_DENSE = 0, RC_EPI_RELU = 1, RC_EPI_LSTM = 2 };
+enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
+
+// row flags (one byte per row, rebuilt every frame)
+#define RC_ROW_VIS 1u     // rnn4 steps on the camera keypoints   (c > lo or first_frame)
+#define RC_ROW_PC 2u      // rnn6 steps on the camera keypoints   (c > lo)
+#define RC_ROW_UPD 4u     // vision updater: rnn6/rnn4 step on re-projected landmarks (c <= lo)
+#define RC_ROW_REACH 8u   // rnn2 state re-initialised by init_net this frame
+#define RC_ROW_MASK 16u   // caller-supplied mask (rc_lstm_step)
+
+struct GemmSeg {
+    const float* base;      // activation matrix [rows, ld]
+    long long par_stride;   // elements between the two parity copies (0 if not double-buffered)
+    int ld;
+    int K;                  // padded length of this K segment (multiple of RC_KALIGN; 0 = absent)
+    int par_mode;           // RC_PAR_*
+    int pad_;
+};
+
+struct GemmProblem {
+    GemmSeg seg[2];         // A = [seg0 | seg1] along K
+    const float* W;         // packed weights, see pack_weights() in rc_api.cpp
+    const float* bias;      // [n_tiles * 64] in packed column order
+    float* out;             // dense: out[row * ldo + n]
+    float* hstate;          // lstm: h[parity][row][H]
+    float* cstate;          // lstm: c[row][H]
+    int* steps;             // per-row step counter of this net (parity = steps & 1)
+    const unsigned char* flags;
+    long long h_par_stride;
+    int ldo, N, H;
+    int flag_bit;           // 0 = all rows
+    int epi;                // RC_EPI_*
+    int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
+    int n_tiles, m_tiles, wg_base, Kp;
+};
+
+struct GemmLaunch {
+    int n;                  // problems
+    int B;                  // rows in the batch
+    GemmProblem p[RC_MAX_PROB];
+};
+
+// ---- per-frame small kernels -------------------------------------------------------------------------------
+struct BodyConst {          // device copy of the body constants the path needs
+    int parent[24];
+    int level[24];          // depth in the kinematic tree
+    float bone[24][3];      // rest bone vectors  (j_rest[i] - j_rest[parent[i]])
+    float jrest[24][3];     // rest joints, root at the origin
+    float w33[33][24];
+    float v33[33][3];       // landmark vertices, root-relative
+    int override_joint[33]; // sync_mp3d: landmark row -> joint id, or -1
+};
+
+struct FrameBuffers {       // device pointers owned by the context (all [B, ld] row-major)
+    float *x2, *x3, *x4, *x6, *x78, *x4l, *x6l, *xi;   // concatenated sub-net inputs (padded, pads stay zero)
+    float *vr, *pc, *r6d, *contact;                     // sub-net outputs consumed by the fusion logic
+    float *init_out;                                    // rnn2.init_net output [B, 2048]
+    unsigned char* flags;                               // RC_ROW_* per row
+    unsigned char* regime;                              // 0 low / 1 mid / 2 high
+    double* kconf;                                      // (c - lo) / (hi - lo) per row
+    float* gravity;                                     // [B,3]
+    // per-row fusion state (net/sig_mp.py:85-90)
+    float *last_pfoot, *last_tran, *floor, *j_temp;
+    int *has_last, *n_floor, *first_reach, *uv_count;
+    int* trace;                                         // [B,8]
+    // rnn2 state for the init_net write
+    float *h2, *c2;
+    int* steps2;
+    long long h2_par_stride, h2_layer_stride, c2_layer_stride;
+};
+
+struct FrameIO {
+    const float *j2d, *acc, *ori, *first_tran;
+    float *pose_out, *tran_out;
+    long long s_j2d, s_acc, s_ori, s_pose, s_tran;      // row strides (elements)
+};
+
+struct rc_params_dev {
+    double conf_lo, conf_hi, tran_filter_num;
+    float contact_threshold, distance_threshold, height_threshold;
+    int use_flat_floor, use_vision_updater, use_imu_updater, live, update_vision_freq;
+};
+
+void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
+void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
+void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);
+void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
+                    int first_frame, hipStream_t s);
+void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
+                     int B, hipStream_t s);
+
+void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
+void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);
+void rc_launch_fk_bone(const BodyConst* body, const float* Rg, float* joints, long long n, hipStream_t s);
+void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tran, float* grot, float* joint,
+                       float* j33, long long n, hipStream_t s);
+void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
+                        float sigma, float* loss, long long T, hipStream_t s);

@@ -1,0 +1,236 @@
+"""``Net`` -- the reference's sig_mp call surface on top of librobustcap_hip.so (MI355X / gfx950).
+
+Drop-in for the inference half of ``net/sig_mp.py:23-274``:
+
+    net = Net()                         # Net(body=..., batch=B) for the batched API
+    net.load_state_dict(sd); net.eval()
+    net.gravityc = Tcw[:3, :3] @ [0, -1, 0]           (evaluate.py:73)
+    pose, tran = net.forward_online(j2dc[33,3], accc[6,3], oric[6,3,3], first_tran=None, first_frame=False)
+    net.reset_states()
+
+plus what the reference lacks: ``forward_batch`` (B bodies per call, outputs stay on the device) and
+``forward_sequence`` ([B, T, ...] in one call, no host round trips). Row b of a batch equals the reference's
+``forward_online`` run alone on sequence b.
+
+Nothing is computed in Python or torch here: tensors are only allocated, made contiguous and handed to the C ABI
+as raw device pointers on torch's current HIP stream. Without the HIP library this module fails at import of
+``_lib.load()`` -- there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import body as _body
+from .. import config as cfg
+
+_PARAM_ATTRS = {"use_flat_floor", "use_vision_updater", "use_imu_updater", "live", "conf_range", "tran_filter_num",
+                "contact_threshold", "distrance_threshold", "height_threhold", "update_vision_freq"}
+
+
+class Net:
+    # class attributes callers read or poke on the reference (net/sig_mp.py:27-45)
+    hidden_size = 512
+    conf_range = (0.7, 0.8)
+    contact_threshold = 0.7
+    smooth = 1
+    use_flat_floor = True
+    use_reproj_opt = False
+    use_vision_updater = True
+    use_imu_updater = True
+    name = "sig_mp"
+    gravityc = torch.tensor([-0.0029, 0.9980, -0.0273])
+    imu_num = 6
+    height_threhold = 0.15
+    distrance_threshold = 10
+    tran_filter_num = 0.05
+    live = False
+    update_vision_freq = 30
+
+    def __init__(self, body=None, batch=1, device="cuda"):
+        """body: dict(J, v_template, weights, parent) (robustcap_amd.synth.make_body / body.load_smpl_pickle);
+        None loads the reference's default ``models/SMPL_male.pkl`` (config.paths.smpl_file)."""
+        self.__dict__["_ready"] = False
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.RobustcapLibraryError("robustcap_amd.Net runs on a HIP device only (no CPU fallback)")
+        self.batch = int(batch)
+        live_ctor = bool(type(self).live)                                  # sig_mp.py:91-93
+        self._ctx = C.c_void_p()
+        _lib.check(None, self._lib.rc_create(self.batch, int(live_ctor), C.byref(self._ctx)), "rc_create")
+        if body is None:
+            path = os.path.join("models", "SMPL_male.pkl")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} not found; pass body=... (the SMPL pickle is an external download)")
+            body = _body.load_smpl_pickle(path)
+        _body.set_body(self._ctx, body)
+        if live_ctor:
+            self.__dict__["conf_range"] = (0.85, 0.9)
+            self.__dict__["tran_filter_num"] = 0.01
+        if self.use_reproj_opt:
+            raise NotImplementedError("use_reproj_opt (sig_mp.py:245-261) is off by default and not built yet")
+        self._sd_cpu = {}
+        self._loaded = False
+        self._gravity_key = None
+        self.__dict__["_ready"] = True
+        self._push_params()
+
+    # ------------------------------------------------------------------------------------------ attribute pokes
+    def __setattr__(self, key, value):
+        self.__dict__[key] = value
+        if self.__dict__.get("_ready") and key in _PARAM_ATTRS:
+            self._push_params()
+
+    def _push_params(self):
+        p = _lib.RcParams()
+        _lib.check(self._ctx, self._lib.rc_get_params(self._ctx, C.byref(p)), "rc_get_params")
+        p.conf_lo, p.conf_hi = float(self.conf_range[0]), float(self.conf_range[1])
+        p.contact_threshold = float(self.contact_threshold)
+        p.distance_threshold = float(self.distrance_threshold)
+        p.height_threshold = float(self.height_threhold)
+        p.tran_filter_num = float(self.tran_filter_num)
+        p.use_flat_floor = int(bool(self.use_flat_floor))
+        p.use_vision_updater = int(bool(self.use_vision_updater))
+        p.use_imu_updater = int(bool(self.use_imu_updater))
+        p.live = int(bool(self.live))
+        p.update_vision_freq = int(self.update_vision_freq)
+        _lib.check(self._ctx, self._lib.rc_set_params(self._ctx, C.byref(p)), "rc_set_params")
+
+    def _sync_gravity(self):
+        g = self.gravityc                                                   # instance attr, else the class attr
+        g = torch.as_tensor(g, dtype=torch.float32).detach().cpu().reshape(-1, 3)
+        key = g.numpy().tobytes()
+        if key == self._gravity_key:
+            return
+        g = g.expand(self.batch, 3).contiguous() if g.shape[0] == 1 else g.contiguous()
+        if g.shape[0] != self.batch:
+            raise ValueError(f"gravityc must be [3] or [{self.batch}, 3]")
+        _lib.check(self._ctx, self._lib.rc_set_gravity(self._ctx, _lib.ptr(g)), "rc_set_gravity")
+        self.__dict__["_gravity_key"] = key
+
+    # ------------------------------------------------------------------------------------- torch.nn.Module-like
+    def to(self, device=None, *a, **k):
+        if device is not None and torch.device(device).type != "cuda":
+            raise _lib.RobustcapLibraryError("robustcap_amd.Net runs on a HIP device only (no CPU fallback)")
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Same key names / shapes as the reference ``Net.state_dict()``. Values: torch tensors or
+        numpy arrays. Repacks to the kernel layout and uploads."""
+        want = dict(cfg.state_dict_spec())
+        missing = [k for k in want if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for Net: missing {missing[:4]} unexpected {unexpected[:4]}")
+        for k, shape in want.items():
+            if k not in state_dict:
+                continue
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            _lib.check(self._ctx, self._lib.rc_load_weight(self._ctx, k.encode(), v.ctypes.data_as(C.c_void_p), v.size), "rc_load_weight")
+        _lib.check(self._ctx, self._lib.rc_finalize_weights(self._ctx), "rc_finalize_weights")
+        self.__dict__["_loaded"] = True
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def reset_states(self, rows=None):
+        """net/sig_mp.py:95-104. rows: optional bool/uint8 mask [batch] (batched API)."""
+        m = None
+        if rows is not None:
+            m = torch.as_tensor(rows).to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self._ctx, self._lib.rc_reset(self._ctx, _lib.ptr(m), _lib.stream_ptr()), "rc_reset")
+        if m is not None:
+            torch.cuda.current_stream().synchronize()                       # keep `m` alive until the kernel ran
+
+    # ---------------------------------------------------------------------------------------------- hot path
+    def _prep(self, t, shape):
+        return t.to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
+
+    @torch.no_grad()
+    def forward_batch(self, j2dc, accc, oric, first_tran=None, first_frame=False):
+        """B bodies, one frame. Inputs [B,33,3], [B,6,3], [B,6,3,3]; returns device tensors pose [B,24,3,3], tran [B,3]."""
+        B = self.batch
+        self._sync_gravity()
+        j2dc, accc, oric = self._prep(j2dc, (B, 33, 3)), self._prep(accc, (B, 6, 3)), self._prep(oric, (B, 6, 3, 3))
+        ft = None if first_tran is None else self._prep(first_tran, (B, 3))
+        pose = torch.empty(B, 24, 3, 3, device=self.device)
+        tran = torch.empty(B, 3, device=self.device)
+        rc = self._lib.rc_step(self._ctx, _lib.ptr(j2dc), _lib.ptr(accc), _lib.ptr(oric), _lib.ptr(ft),
+                               _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, _lib.ptr(pose), _lib.ptr(tran), _lib.stream_ptr())
+        _lib.check(self._ctx, rc, "rc_step")
+        self.__dict__["_keep"] = (j2dc, accc, oric, ft)                    # inputs must outlive the async launches
+        return pose, tran
+
+    @torch.no_grad()
+    def forward_online(self, j2dc, accc, oric, first_tran=None, first_frame=False):
+        """net/sig_mp.py:113-274: one body, one frame; returns CPU tensors like the reference (L274)."""
+        if self.batch != 1:
+            raise ValueError("forward_online is the batch-1 call; use forward_batch")
+        pose, tran = self.forward_batch(j2dc, accc, oric, first_tran, first_frame)
+        return pose[0].cpu(), tran[0].cpu()
+
+    @torch.no_grad()
+    def forward_sequence(self, j2dc, accc, oric, first_tran=None, first_frame=False):
+        """The evaluate.py frame loop (evaluate.py:75-83) for B sequences of T frames in one call.
+        Inputs [B,T,33,3], [B,T,6,3], [B,T,6,3,3]; returns device tensors pose [B,T,24,3,3], tran [B,T,3]."""
+        B = self.batch
+        T = j2dc.shape[1]
+        self._sync_gravity()
+        j2dc, accc, oric = self._prep(j2dc, (B, T, 99)), self._prep(accc, (B, T, 18)), self._prep(oric, (B, T, 54))
+        ft = None if first_tran is None else self._prep(first_tran, (B, 3))
+        pose = torch.empty(B, T, 24, 3, 3, device=self.device)
+        tran = torch.empty(B, T, 3, device=self.device)
+        rc = self._lib.rc_sequence(self._ctx, T, _lib.ptr(j2dc), T * 99, _lib.ptr(accc), T * 18, _lib.ptr(oric), T * 54, _lib.ptr(ft),
+                                   _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, _lib.ptr(pose), T * 216, _lib.ptr(tran), T * 3,
+                                   _lib.stream_ptr())
+        _lib.check(self._ctx, rc, "rc_sequence")
+        self.__dict__["_keep"] = (j2dc, accc, oric, ft)
+        return pose, tran
+
+    # ------------------------------------------------------------------------------------------- introspection
+    def lstm_step(self, net, x, rows=None):
+        """One step f(i, x) of a sub-net on the context's state (net/sig_mp.py:126-129); for component tests."""
+        spec = {n: (i, h, o) for n, i, h, o in cfg.NETS}[net]
+        x = self._prep(x, (self.batch, spec[0]))
+        m = None if rows is None else torch.as_tensor(rows).to(device=self.device, dtype=torch.uint8).contiguous()
+        y = torch.zeros(self.batch, spec[2], device=self.device)
+        _lib.check(self._ctx, self._lib.rc_lstm_step(self._ctx, net.encode(), _lib.ptr(x), _lib.ptr(m), _lib.ptr(y), _lib.stream_ptr()), "rc_lstm_step")
+        torch.cuda.current_stream().synchronize()
+        return y
+
+    def get_state(self, net):
+        """(h, c) of a sub-net as CPU tensors [2, batch, H]."""
+        H = {n: h for n, _, h, _ in cfg.NETS}[net]
+        h = torch.empty(2, self.batch, H)
+        c = torch.empty(2, self.batch, H)
+        _lib.check(self._ctx, self._lib.rc_get_state(self._ctx, net.encode(), _lib.ptr(h), _lib.ptr(c), _lib.stream_ptr()), "rc_get_state")
+        return h, c
+
+    def get_trace(self):
+        """int32 [batch, 8] branch trace of the last frame (see rc_get_trace in the header)."""
+        t = torch.empty(self.batch, 8, dtype=torch.int32)
+        _lib.check(self._ctx, self._lib.rc_get_trace(self._ctx, _lib.ptr(t), _lib.stream_ptr()), "rc_get_trace")
+        return t
+
+    def gemm_timing(self, enable):
+        _lib.check(self._ctx, self._lib.rc_gemm_timing(self._ctx, int(enable)), "rc_gemm_timing")
+
+    def gemm_timing_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self._ctx, self._lib.rc_gemm_timing_read(self._ctx, C.byref(ms), C.byref(n)), "rc_gemm_timing_read")
+        return ms.value, n.value
+
+    def __del__(self):
+        ctx = self.__dict__.get("_ctx")
+        if ctx:
+            self._lib.rc_destroy(ctx)
+            self.__dict__["_ctx"] = None
+

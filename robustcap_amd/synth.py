@@ -139,14 +139,13 @@ def _rodrigues(aa):
 
 
 def _smooth(x, n):
-    """moving average along axis 0 with reflection, keeps length."""
-    if n <= 1:
+    """moving average of window n along axis 0 (edge-padded), keeps length; works for any length >= 1."""
+    if n <= 1 or x.shape[0] < 2:
         return x
-    pad = np.concatenate([x[n - 1:0:-1], x, x[-2:-n - 1:-1]], 0)
+    lo = n // 2
+    pad = np.concatenate([np.repeat(x[:1], lo, 0), x, np.repeat(x[-1:], n - 1 - lo, 0)], 0)
     c = np.cumsum(np.concatenate([np.zeros_like(pad[:1]), pad], 0), 0)
-    y = (c[n:] - c[:-n]) / n
-    off = (y.shape[0] - x.shape[0]) // 2
-    return y[off:off + x.shape[0]]
+    return (c[n:] - c[:-n]) / n
 
 
 def body_fk_numpy(body, pose, tran, vertex_ids):

@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI) against the reference-captured golden vectors and the CPU oracle.
+
+Run on the GPU box: python -m pytest tests -m gpu. Tolerances (north star): joint positions 1e-4 m, joint
+angles 0.1 deg (float64 atan2 form); per-op kernels 2e-6; branch traces exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+t = torch.from_numpy
+
+
+def maxdiff(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+@pytest.fixture(scope="module")
+def pm(synth_assets):
+    from robustcap_amd.body import ParametricModel
+    return ParametricModel(body=synth_assets["body"])
+
+
+def make_net(synth_assets, batch=1, live_ctor=False):
+    """live_ctor mirrors `Net.live = True` BEFORE construction (evaluate.py:392). Like the reference, `live` stays
+    a class attribute that the instance reads at call time, so the caller resets it when the scenario is over."""
+    from robustcap_amd.net.sig_mp import Net
+    Net.live = live_ctor
+    net = Net(body=synth_assets["body"], batch=batch)
+    net.load_state_dict(synth_assets["state_dict"])
+    return net
+
+
+@pytest.fixture(autouse=True)
+def _reset_class_live():
+    yield
+    from robustcap_amd.net.sig_mp import Net
+    Net.live = False
+
+
+def make_oracle(synth_assets, batch=1, live_ctor=False):
+    from oracle import sig_mp_oracle as O
+    o = O.OracleNet(synth_assets["body"], batch=batch, live=live_ctor)
+    o.load_numpy_state_dict(synth_assets["state_dict"])
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------- per-op
+def test_library_is_the_hip_one():
+    from robustcap_amd import _lib
+    lib = _lib.load()
+    assert os.path.samefile(lib._name, _lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "librobustcap_hip.so" in maps and "libamdhip64" in maps
+
+
+def test_r6d(ops):
+    from robustcap_amd.body import r6d_to_rotation_matrix
+    out = r6d_to_rotation_matrix(t(ops["r6d_in"]))
+    assert maxdiff(out, ops["r6d_out"]) <= 2e-6
+    assert float(out[-1, :, 0].abs().max()) == 0.0 and not torch.isnan(out).any()
+    assert r6d_to_rotation_matrix(torch.zeros(0, 6)).shape == (0, 3, 3)            # empty input
+
+
+def test_ik_and_bone_fk(ops, pm):
+    assert maxdiff(pm.inverse_kinematics_R(t(ops["ik_in"])), ops["ik_out"]) <= 2e-6
+    from oracle import sig_mp_oracle as O
+    ob = O.OracleBody(pm._body)
+    Rg = t(ops["fk_grot"])
+    assert maxdiff(pm.bone_fk(Rg), ob.bone_fk(Rg)) <= 2e-6
+    # bone FK of zero-pose globals = rest joints
+    eye = torch.eye(3).expand(1, 24, 3, 3).contiguous()
+    assert maxdiff(pm.bone_fk(eye)[0], ob.j_rest) <= 1e-6
+
+
+def test_body_fk_landmarks(ops, pm):
+    G, J, L = pm.forward_kinematics(t(ops["fk_pose"]), tran=t(ops["fk_tran"]), calc_mesh=True)
+    assert maxdiff(G, ops["fk_grot"]) <= 2e-6
+    assert maxdiff(J, ops["fk_joint"]) <= 2e-6
+    assert maxdiff(L, ops["fk_j33"]) <= 2e-6
+    G2, J2 = pm.forward_kinematics(t(ops["fk_pose"]))                                 # tran=None
+    assert maxdiff(J2 + t(ops["fk_tran"]).cuda().view(-1, 1, 3), ops["fk_joint"]) <= 2e-6
+
+
+def test_reprojection_residual(ops, pm):
+    r = pm.reprojection_residual(t(ops["res_pose"]), t(ops["res_tran"]), t(ops["res_kp"]), t(ops["res_K"]))
+    scale = float(np.abs(ops["res_loss"]).max())
+    assert maxdiff(r, ops["res_loss"]) <= 2e-6 * scale
+    assert float(r[:, [1, 5, 9, 31, 32]].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------------------------- sub-net steps
+@pytest.mark.parametrize("name", ["rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8"])
+def test_lstm_step_vs_torch(name, synth_assets):
+    """f(i, x) of one sub-net for 5 steps incl. a masked step, vs torch.nn.LSTM on the CPU (oracle module)."""
+    from robustcap_amd import config as C, synth
+    B = 37                                                      # ragged: not a multiple of the 32-row tile
+    nin = {n: i for n, i, _, _ in C.NETS}[name]
+    net = make_net(synth_assets, batch=B)
+    ora = make_oracle(synth_assets, batch=B)
+    for step in range(5):
+        x = t(synth.normal(50 + step, 1, B * nin).reshape(B, nin))
+        rows = None
+        if step == 3:
+            rows = torch.zeros(B, dtype=torch.bool)
+            rows[[0, 5, 31, 32, 36]] = True
+        y = net.lstm_step(name, x, rows)
+        idx = None if rows is None else rows.nonzero().flatten()
+        yo = ora._step(name, x, idx)
+        got = y.cpu() if rows is None else y.cpu()[idx]
+        assert maxdiff(got, yo) <= 2e-5, (name, step)
+    h, c = net.get_state(name)
+    assert maxdiff(h, ora.h[name]) <= 2e-5 and maxdiff(c, ora.c[name]) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------- full sequences
+SEQS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "seq_*.npz")))
+
+
+def joint_positions(body, pose, tran):
+    from oracle import sig_mp_oracle as O
+    ob = O.OracleBody(body)
+    return ob.forward_kinematics(pose.reshape(-1, 24, 3, 3), tran.reshape(-1, 3))[1]
+
+
+@pytest.mark.parametrize("path", SEQS, ids=[os.path.basename(p)[4:-4] for p in SEQS])
+def test_sequence_vs_reference_capture(path, synth_assets):
+    """forward_online (batch 1, frame by frame, like evaluate.py) against the REFERENCE's own outputs."""
+    from oracle import sig_mp_oracle as O
+    s = np.load(path)
+    live = str(s["live"])
+    net = make_net(synth_assets, 1, live_ctor=(live == "pre"))
+    if live == "post":
+        net.live = True
+    net.use_flat_floor = bool(s["use_flat_floor"])
+    net.gravityc = t(s["gravityc"])
+    ft = t(s["first_tran"]) if s["first_tran"].size else None
+    T = s["pose"].shape[0]
+    poses, trans = [], []
+    for i in range(T):
+        p, tr = net.forward_online(t(s["j2dc"][i]), t(s["accc"][i]), t(s["oric"][i]), ft if i == 0 else None,
+                                   bool(s["first_frame"]) and i == 0)
+        tc = net.get_trace()[0].tolist()
+        exp = s["trace"][i]
+        assert tc[1] == int(exp[1]) and tc[2] == int(exp[2]), f"frame {i}: rnn4/rnn6 step counts {tc} vs {exp}"
+        assert tc[3] == int(exp[4]) and tc[4] == int(exp[5]), f"frame {i}: floor/reach {tc} vs {exp}"
+        poses.append(p), trans.append(tr)
+    pose, tran = torch.stack(poses), torch.stack(trans)
+    rp, rt = t(s["pose"]), t(s["tran"])
+    assert maxdiff(tran, rt) <= 1e-4
+    assert float(O.rotation_angle_deg(pose, rp).max()) <= 0.1
+    assert maxdiff(joint_positions(synth_assets["body"], pose, tran), joint_positions(synth_assets["body"], rp, rt)) <= 1e-4
+    for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8"):
+        h, c = net.get_state(n)
+        assert maxdiff(h[:, 0], s["h_" + n]) <= 1e-4 and maxdiff(c[:, 0], s["c_" + n]) <= 2e-4, n
+
+
+def test_batched_sequence_vs_oracle(synth_assets):
+    """forward_sequence on a ragged batch in mixed regimes == the oracle, row by row, incl. the branch trace."""
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd import synth
+    B, T = 11, 72
+    m = synth.make_motion(77, B, T, synth_assets["body"], conf="mixed")
+    m["j2dc"][3, :20, :, 2] = 0.45
+    net = make_net(synth_assets, B)
+    ora = make_oracle(synth_assets, B)
+    net.gravityc = t(m["gravityc"])
+    ora.gravityc = t(m["gravityc"])
+    pose, tran = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_tran=t(m["first_tran"]))
+    op, ot = [], []
+    for i in range(T):
+        p, tr = ora.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]), t(m["first_tran"]) if i == 0 else None)
+        op.append(p), ot.append(tr)
+    op, ot = torch.stack(op, 1), torch.stack(ot, 1)
+    assert maxdiff(tran, ot) <= 1e-4
+    assert float(O.rotation_angle_deg(pose.cpu(), op).max()) <= 0.1
+    assert maxdiff(joint_positions(synth_assets["body"], pose.cpu(), tran.cpu()), joint_positions(synth_assets["body"], op, ot)) <= 1e-4
+    tr = net.get_trace()
+    assert tr[:, 3].tolist() == ora.trace["n_floor"].tolist()
+
+
+def test_step_api_equals_sequence_api_bitwise(synth_assets):
+    from robustcap_amd import synth
+    B, T = 5, 24
+    m = synth.make_motion(91, B, T, synth_assets["body"], conf="mixed")
+    a, b = make_net(synth_assets, B), make_net(synth_assets, B)
+    a.gravityc = b.gravityc = t(m["gravityc"])
+    ps, ts = a.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    for i in range(T):
+        p, tr = b.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]), None, i == 0)
+        assert torch.equal(p, ps[:, i]) and torch.equal(tr, ts[:, i])
+
+
+def test_reset_states_and_row_mask(synth_assets):
+    """reset_states() restores a fresh sequence; a row mask resets only those rows (bitwise)."""
+    from robustcap_amd import synth
+    B, T = 4, 16
+    m = synth.make_motion(93, B, T, synth_assets["body"], conf="high")
+    net = make_net(synth_assets, B)
+    net.gravityc = t(m["gravityc"])
+    args = (t(m["j2dc"]), t(m["accc"]), t(m["oric"]))
+    p1, t1 = net.forward_sequence(*args)
+    net.reset_states()
+    p2, t2 = net.forward_sequence(*args)
+    assert torch.equal(p1, p2) and torch.equal(t1, t2)
+    # continue rows 0,2; restart rows 1,3
+    net.reset_states(rows=torch.tensor([0, 1, 0, 1]))
+    p3, t3 = net.forward_sequence(*args)
+    assert torch.equal(p3[[1, 3]], p1[[1, 3]]) and torch.equal(t3[[1, 3]], t1[[1, 3]])
+    assert not torch.equal(t3[[0, 2]], t1[[0, 2]])
+
+
+def test_error_behaviour(synth_assets):
+    from robustcap_amd import _lib
+    from robustcap_amd.net.sig_mp import Net
+    net = Net(body=synth_assets["body"], batch=1)
+    with pytest.raises(_lib.RobustcapLibraryError):            # weights not loaded -> loud error, no fallback
+        net.forward_online(torch.zeros(33, 3), torch.zeros(6, 3), torch.eye(3).repeat(6, 1, 1))
+    bad = dict(synth_assets["state_dict"])
+    bad.pop("rnn4.linear1.bias")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad)
+    with pytest.raises(_lib.RobustcapLibraryError):
+        Net(body=synth_assets["body"], batch=1, device="cpu")
