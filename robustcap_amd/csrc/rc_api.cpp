@@ -49,6 +49,7 @@ struct NetDev {
 
 struct rc_ctx {
     int B = 0;
+    int Bp = 0;                          // B rounded up to the 32-row tile (row count of rc_pk buffers)
     int dev = 0;
     rc_params prm{};
     NetDev net[6];
@@ -141,13 +142,15 @@ GemmSeg seg(const float* base, int ld, int K, int mode = RC_PAR_NONE, long long 
     return s;
 }
 
-GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, float* out, int ldo, bool relu, int flag_bit,
+struct Out { float* p; int ld; int col0; bool packed; };   // destination of a dense layer
+
+GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out, bool relu, int flag_bit,
                           const unsigned char* flags, int* steps, bool open_step) {
     GemmProblem p{};
     a.K = d.Kp;
     p.seg[0] = a;
     p.seg[1] = seg(a.base, a.ld, 0);
-    p.W = d.W; p.bias = d.b; p.out = out; p.ldo = ldo; p.N = d.N;
+    p.W = d.W; p.bias = d.b; p.out = out.p; p.ldo = out.ld; p.N = d.N; p.out_col0 = out.col0; p.out_packed = out.packed ? 1 : 0;
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
@@ -155,23 +158,23 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, float* o
     return p;
 }
 
-struct Stage {                 // which rows of which net, reading which input buffer
-    int net; int flag_bit; const float* x; int ldx; float* y; int ldy;
+struct Stage {                 // which rows of which net, reading which (rc_pk) input buffer, writing where
+    int net; int flag_bit; const float* x; int ldx; Out y;
 };
 
 GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
-    return dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), n.x1, n.H, true, s.flag_bit, c->fb.flags, n.steps, true);
+    return dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit, c->fb.flags, n.steps, true);
 }
 GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     const NetDev& n = c->net[s.net];
-    const long long BH = (long long)c->B * n.H;
+    const long long BH = (long long)c->Bp * n.H;
     GemmProblem p{};
     if (layer == 0) p.seg[0] = seg(n.x1, n.H, n.H);
     else p.seg[0] = seg(n.h, n.H, n.H, RC_PAR_DST, BH);                     // h of layer 0, just written
     p.seg[1] = seg(n.h + layer * 2 * BH, n.H, n.H, RC_PAR_SRC, BH);         // own h, previous step
     p.W = n.Wl[layer]; p.bias = n.bl[layer];
-    p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * BH; p.h_par_stride = BH; p.H = n.H;
+    p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
     p.n_tiles = n.H / RC_UNITS; p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H;
@@ -179,8 +182,8 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
-    const long long BH = (long long)c->B * n.H;
-    return dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, s.ldy, false, s.flag_bit, c->fb.flags,
+    const long long BH = (long long)c->Bp * n.H;
+    return dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit, c->fb.flags,
                          n.steps, false);
 }
 
@@ -251,26 +254,27 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
 
     rc_launch_prep(fb, io, prm, B, first, st);
     // inertial pose branch + visual pose branch (L144, L153)
-    if (int rc = run_stage(ctx, {{N2, 0, fb.x2, 128, fb.x3 + 72, 256}, {N4, (int)RC_ROW_VIS, fb.x4, 256, fb.x6 + 171, 256}}, true,
-                           nullptr, st)) return rc;
+    if (int rc = run_stage(ctx, {{N2, 0, fb.x2, 128, Out{fb.x3, 256, 72, true}},
+                                 {N4, (int)RC_ROW_VIS, fb.x4, 256, Out{fb.x6, 256, 171, true}}}, true, nullptr, st)) return rc;
     if (first) {                                                           // L155-156: rnn6 on every row
-        if (int rc = run_stage(ctx, {{N6, 0, fb.x6, 256, fb.pc, 4}}, true, nullptr, st)) return rc;
+        if (int rc = run_stage(ctx, {{N6, 0, fb.x6, 256, Out{fb.pc, 4, 0, false}}}, true, nullptr, st)) return rc;
     }
     rc_launch_fuse(fb, io, prm, B, st);
     // velocity, visual translation, pose, contact (L145, L161/165, L169-170) + rnn2.init_net (L181-182)
     std::vector<GemmProblem> init;
     if (ctx->prm.use_imu_updater) {
-        init.push_back(dense_problem(ctx, ctx->init[0], seg(fb.xi, 128, 0), ctx->hid1, 512, true, RC_ROW_REACH, fb.flags, nullptr, false));
-        init.push_back(dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), ctx->hid2, 1024, true, RC_ROW_REACH, fb.flags, nullptr, false));
-        init.push_back(dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), fb.init_out, 2048, false, RC_ROW_REACH, fb.flags, nullptr, false));
+        init.push_back(dense_problem(ctx, ctx->init[0], seg(fb.xi, 128, 0), Out{ctx->hid1, 512, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false));
+        init.push_back(dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), Out{ctx->hid2, 1024, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false));
+        init.push_back(dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), Out{fb.init_out, 2048, 0, false}, false, RC_ROW_REACH, fb.flags, nullptr, false));
     }
-    if (int rc = run_stage(ctx, {{N3, 0, fb.x3, 256, fb.vr, 4}, {N6, (int)RC_ROW_PC, fb.x6, 256, fb.pc, 4},
-                                 {N7, 0, fb.x78, 256, fb.r6d, 144}, {N8, 0, fb.x78, 256, fb.contact, 2}}, true, &init, st)) return rc;
+    if (int rc = run_stage(ctx, {{N3, 0, fb.x3, 256, Out{fb.vr, 4, 0, false}}, {N6, (int)RC_ROW_PC, fb.x6, 256, Out{fb.pc, 4, 0, false}},
+                                 {N7, 0, fb.x78, 256, Out{fb.r6d, 144, 0, false}}, {N8, 0, fb.x78, 256, Out{fb.contact, 2, 0, false}}},
+                           true, &init, st)) return rc;
     rc_launch_tail(fb, io, prm, ctx->body, B, first, st);
     // vision updater (L264-271): state-only steps, linear2 skipped
     if (ctx->prm.use_vision_updater) {
-        if (int rc = run_stage(ctx, {{N6, (int)RC_ROW_UPD, fb.x6l, 256, nullptr, 0}, {N4, (int)RC_ROW_UPD, fb.x4l, 256, nullptr, 0}},
-                               false, nullptr, st)) return rc;
+        if (int rc = run_stage(ctx, {{N6, (int)RC_ROW_UPD, fb.x6l, 256, Out{nullptr, 0, 0, false}},
+                                     {N4, (int)RC_ROW_UPD, fb.x4l, 256, Out{nullptr, 0, 0, false}}}, false, nullptr, st)) return rc;
     }
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
@@ -309,20 +313,21 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, RC_ERR_HIP, "rc_create: no HIP device");
     rc_ctx* ctx = new rc_ctx();
     ctx->B = batch;
+    ctx->Bp = round_up(batch, RC_MT);
     hipGetDevice(&ctx->dev);
     rc_default_params(live, &ctx->prm);
-    const size_t B = (size_t)batch;
+    const size_t B = (size_t)batch, Bp = (size_t)ctx->Bp;
     int rc = RC_OK;
     FrameBuffers& fb = ctx->fb;
 #define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
     for (int i = 0; i < 6 && !rc; ++i) {
         NetDev& n = ctx->net[i];
         n.in = kNets[i].in; n.H = kNets[i].H; n.out = kNets[i].out;
-        A(n.h, 4 * B * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, B * n.H);
+        A(n.h, 4 * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
     }
-    A(ctx->hid1, B * 512); A(ctx->hid2, B * 1024); A(ctx->xtmp, B * 256);
-    A(fb.x2, B * 128); A(fb.x3, B * 256); A(fb.x4, B * 256); A(fb.x6, B * 256); A(fb.x78, B * 256);
-    A(fb.x4l, B * 256); A(fb.x6l, B * 256); A(fb.xi, B * 128);
+    A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);
+    A(fb.x2, Bp * 128); A(fb.x3, Bp * 256); A(fb.x4, Bp * 256); A(fb.x6, Bp * 256); A(fb.x78, Bp * 256);
+    A(fb.x4l, Bp * 256); A(fb.x6l, Bp * 256); A(fb.xi, Bp * 128);
     A(fb.vr, B * 4); A(fb.pc, B * 4); A(fb.r6d, B * 144); A(fb.contact, B * 2); A(fb.init_out, B * 2048);
     A(fb.flags, B); A(fb.regime, B); A(fb.kconf, B); A(fb.gravity, B * 3);
     A(fb.last_pfoot, B * 6); A(fb.last_tran, B * 3); A(fb.floor, B * 33); A(fb.j_temp, B * 99);
@@ -331,7 +336,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
 #undef A
     if (rc) { g_create_error = ctx->err; rc_destroy(ctx); return rc; }
     fb.h2 = ctx->net[N2].h; fb.c2 = ctx->net[N2].c; fb.steps2 = ctx->net[N2].steps;
-    fb.h2_par_stride = (long long)B * 512; fb.h2_layer_stride = 2ll * B * 512; fb.c2_layer_stride = (long long)B * 512;
+    fb.h2_par_stride = (long long)Bp * 512; fb.h2_layer_stride = 2ll * Bp * 512; fb.c2_layer_stride = (long long)B * 512;
     std::vector<float> g(B * 3);
     for (size_t b = 0; b < B; ++b) { g[3 * b] = -0.0029f; g[3 * b + 1] = 0.9980f; g[3 * b + 2] = -0.0273f; }   // sig_mp.py:36
     std::vector<int> ones(B, 1);
@@ -542,10 +547,9 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
     if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_lstm_step: unknown net ") + net);
     hipStream_t st = (hipStream_t)stream;
     const NetDev& n = ctx->net[ni];
-    // stage x into a zero-padded [B, 256] buffer (K is padded to 128/256 and loads are 16-byte aligned)
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->xtmp, 256 * sizeof(float), x, n.in * sizeof(float), n.in * sizeof(float), ctx->B,
-                                  hipMemcpyDeviceToDevice, st));
-    Stage s{ni, row_mask ? 255 : 0, ctx->xtmp, 256, y, n.out};
+    // stage x into the zero-padded rc_pk-ordered [B, 256] buffer the GEMM reads
+    rc_launch_pack_rows(x, n.in, n.in, ctx->xtmp, 256, ctx->B, st);
+    Stage s{ni, row_mask ? 255 : 0, ctx->xtmp, 256, Out{y, n.out, 0, false}};
     for (int phase = 0; phase < 4; ++phase) {
         GemmProblem p = phase == 0 ? lin1_problem(ctx, s) : (phase == 3 ? lin2_problem(ctx, s) : lstm_problem(ctx, s, phase - 1));
         if (int rc = launch_problems(ctx, {p}, row_mask, st)) return rc;
@@ -559,15 +563,17 @@ int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, voi
     if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_get_state: unknown net ") + net);
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     const NetDev& n = ctx->net[ni];
-    const size_t B = ctx->B, H = n.H;
-    std::vector<float> h(4 * B * H);
+    const size_t B = ctx->B, Bp = ctx->Bp, H = n.H;
+    std::vector<float> h(4 * Bp * H);
     std::vector<int> steps(B);
     HIP_TRY(ctx, hipMemcpy(h.data(), n.h, h.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(steps.data(), n.steps, B * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(c_host, n.c, 2 * B * H * 4, hipMemcpyDeviceToHost));
     for (size_t l = 0; l < 2; ++l)
-        for (size_t b = 0; b < B; ++b)
-            std::memcpy(h_host + (l * B + b) * H, h.data() + ((l * 2 + (steps[b] & 1)) * B + b) * H, H * 4);
+        for (size_t b = 0; b < B; ++b) {
+            const float* src = h.data() + (l * 2 + (steps[b] & 1)) * Bp * H;
+            for (size_t e = 0; e < H; ++e) h_host[(l * B + b) * H + e] = src[rc_pk((long long)b, (int)e, (int)H)];
+        }
     return RC_OK;
 }
 

@@ -204,33 +204,32 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
     if (lane < 18) {                                                      // accr = accc . Rcr, L142
         const int i = lane / 3, j = lane % 3;
         const float v = (acc[3 * i] * Rcr[j] + acc[3 * i + 1] * Rcr[3 + j]) + acc[3 * i + 2] * Rcr[6 + j];
-        fb.x2[row * LD_X2 + lane] = v;
-        fb.x3[row * LD_X3 + lane] = v;
-        fb.x78[row * LD_X78 + lane] = v;
+        fb.x2[rc_pk(row, lane, LD_X2)] = v;
+        fb.x3[rc_pk(row, lane, LD_X3)] = v;
+        fb.x78[rc_pk(row, lane, LD_X78)] = v;
         const float a = acc[lane];
-        fb.x4[row * LD_X4 + lane] = a;
-        fb.x6[row * LD_X6 + lane] = a;
-        fb.x4l[row * LD_X4 + lane] = a;
-        fb.x6l[row * LD_X6 + lane] = a;
+        fb.x4[rc_pk(row, lane, LD_X4)] = a;
+        fb.x6[rc_pk(row, lane, LD_X6)] = a;
+        fb.x4l[rc_pk(row, lane, LD_X4)] = a;
+        fb.x6l[rc_pk(row, lane, LD_X6)] = a;
     }
     if (lane < 54) {                                                      // orir = Rcr^T . oric, L143
         const int i = lane / 9, r = (lane % 9) / 3, cc = lane % 3;
         const float* o = ori + 9 * i;
         const float v = (Rcr[r] * o[cc] + Rcr[3 + r] * o[3 + cc]) + Rcr[6 + r] * o[6 + cc];
-        fb.x2[row * LD_X2 + 18 + lane] = v;
-        fb.x3[row * LD_X3 + 18 + lane] = v;
-        fb.x78[row * LD_X78 + 18 + lane] = v;
+        fb.x2[rc_pk(row, 18 + lane, LD_X2)] = v;
+        fb.x3[rc_pk(row, 18 + lane, LD_X3)] = v;
+        fb.x78[rc_pk(row, 18 + lane, LD_X78)] = v;
         const float a = ori[lane];
-        fb.x4[row * LD_X4 + 18 + lane] = a;
-        fb.x6[row * LD_X6 + 18 + lane] = a;
-        fb.x4l[row * LD_X4 + 18 + lane] = a;
-        fb.x6l[row * LD_X6 + 18 + lane] = a;
+        fb.x4[rc_pk(row, 18 + lane, LD_X4)] = a;
+        fb.x6[rc_pk(row, 18 + lane, LD_X6)] = a;
+        fb.x4l[rc_pk(row, 18 + lane, LD_X4)] = a;
+        fb.x6l[rc_pk(row, 18 + lane, LD_X6)] = a;
     }
     if (lane < 33) {
-        float* d4 = fb.x4 + row * LD_X4 + 72 + 3 * lane;
-        d4[0] = xn; d4[1] = yn; d4[2] = cf;
-        float* d6 = fb.x6 + row * LD_X6 + 72 + 3 * lane;
-        d6[0] = x; d6[1] = y; d6[2] = cf;
+        const int k = 72 + 3 * lane;
+        fb.x4[rc_pk(row, k, LD_X4)] = xn; fb.x4[rc_pk(row, k + 1, LD_X4)] = yn; fb.x4[rc_pk(row, k + 2, LD_X4)] = cf;
+        fb.x6[rc_pk(row, k, LD_X6)] = x; fb.x6[rc_pk(row, k + 1, LD_X6)] = y; fb.x6[rc_pk(row, k + 2, LD_X6)] = cf;
     }
 }
 
@@ -249,8 +248,12 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
         return;
     }
     const float* R = io.ori + row * io.s_ori + 45;
-    const float* vc = fb.x6 + row * LD_X6 + 171 + 3 * j;                  // j3dc (rnn4 output)
-    const float* vi = fb.x3 + row * LD_X3 + 72 + 3 * j;                   // j3dr_i (rnn2 output)
+    float vc[3], vi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        vc[c] = fb.x6[rc_pk(row, 171 + 3 * j + c, LD_X6)];               // j3dc (rnn4 output)
+        vi[c] = fb.x3[rc_pk(row, 72 + 3 * j + c, LD_X3)];                // j3dr_i (rnn2 output)
+    }
     float out[3];
     if (regime == 0) {
         out[0] = vi[0]; out[1] = vi[1]; out[2] = vi[2];
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        fb.x78[row * LD_X78 + 72 + 3 * j + c] = out[c];
-        fb.xi[row * LD_XI + 3 * j + c] = out[c];
+        fb.x78[rc_pk(row, 72 + 3 * j + c, LD_X78)] = out[c];
+        fb.xi[rc_pk(row, 3 * j + c, LD_XI)] = out[c];
     }
 }
 
@@ -447,19 +450,19 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         if (lane < 33) {
             const float z = s.J33[lane][2];
             x = s.J33[lane][0] / z; y = s.J33[lane][1] / z; z1 = z / z;    // L265
-            float* d6 = fb.x6l + row * LD_X6 + 72 + 3 * lane;
-            d6[0] = x; d6[1] = y; d6[2] = z1;
+            const int k = 72 + 3 * lane;
+            fb.x6l[rc_pk(row, k, LD_X6)] = x; fb.x6l[rc_pk(row, k + 1, LD_X6)] = y; fb.x6l[rc_pk(row, k + 2, LD_X6)] = z1;
         }
         if (lane >= 1 && lane < 24) {                                     // L266: joint[1:] - joint[:1]
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                fb.x6l[row * LD_X6 + 171 + 3 * (lane - 1) + c] = (s.P[lane][c] + tran[c]) - (s.P[0][c] + tran[c]);
+                fb.x6l[rc_pk(row, 171 + 3 * (lane - 1) + c, LD_X6)] = (s.P[lane][c] + tran[c]) - (s.P[0][c] + tran[c]);
         }
         float xn, yn;
         bbox_normalise(x, y, lane, xn, yn);                                // L268-270
         if (lane < 33) {
-            float* d4 = fb.x4l + row * LD_X4 + 72 + 3 * lane;
-            d4[0] = xn; d4[1] = yn; d4[2] = z1;
+            const int k = 72 + 3 * lane;
+            fb.x4l[rc_pk(row, k, LD_X4)] = xn; fb.x4l[rc_pk(row, k + 1, LD_X4)] = yn; fb.x4l[rc_pk(row, k + 2, LD_X4)] = z1;
         }
     }
     // L181-183: rnn2 state <- init_net(j3dr); takes effect from the next frame
@@ -467,8 +470,8 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         const int cur = fb.steps2[row] & 1;
         const float* src = fb.init_out + row * 2048;
         for (int e = lane; e < 512; e += 64) {
-            fb.h2[cur * fb.h2_par_stride + row * 512 + e] = src[e];
-            fb.h2[fb.h2_layer_stride + cur * fb.h2_par_stride + row * 512 + e] = src[512 + e];
+            fb.h2[cur * fb.h2_par_stride + rc_pk(row, e, 512)] = src[e];
+            fb.h2[fb.h2_layer_stride + cur * fb.h2_par_stride + rc_pk(row, e, 512)] = src[512 + e];
             fb.c2[row * 512 + e] = src[1024 + e];
             fb.c2[fb.c2_layer_stride + row * 512 + e] = src[1536 + e];
         }
@@ -479,7 +482,8 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 struct ResetArgs {
     float* h[6];
     float* c[6];
-    long long h_elems[6];   // elements of h per (layer, parity) = B * H
+    long long h_elems[6];   // elements of h per (layer, parity) = round_up(B, 32) * H   (rc_pk order)
+    long long c_elems[6];   // elements of c per layer = B * H                            (row-major)
     int H[6];
 };
 __global__ __launch_bounds__(256) void rc_reset_kernel(FrameBuffers fb, ResetArgs a, const unsigned char* mask, int B) {
@@ -489,9 +493,9 @@ __global__ __launch_bounds__(256) void rc_reset_kernel(FrameBuffers fb, ResetArg
         const int H = a.H[n];
         for (int e = threadIdx.x; e < H; e += 256) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a.h[n][q * a.h_elems[n] + (long long)row * H + e] = 0.0f;   // 2 layers x 2 parities
+            for (int q = 0; q < 4; ++q) a.h[n][q * a.h_elems[n] + rc_pk(row, e, H)] = 0.0f;   // 2 layers x 2 parities
             a.c[n][(long long)row * H + e] = 0.0f;
-            a.c[n][a.h_elems[n] + (long long)row * H + e] = 0.0f;
+            a.c[n][a.c_elems[n] + (long long)row * H + e] = 0.0f;
         }
     }
     if (threadIdx.x == 0) {                                               // net/sig_mp.py:95-104
@@ -590,7 +594,20 @@ __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __rest
     }
 }
 
+// row-major [B, cols] (leading dimension src_ld) -> rc_pk order with leading dimension ld (rc_lstm_step staging)
+__global__ void rc_pack_rows_kernel(const float* src, int src_ld, int cols, float* dst, int ld, int B) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = idx / cols;
+    const int k = (int)(idx % cols);
+    if (row >= B) return;
+    dst[rc_pk(row, k, ld)] = src[row * src_ld + k];
+}
+
 // ================================================================================================ launchers
+void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t st) {
+    const long long n = (long long)B * cols;
+    hipLaunchKernelGGL(rc_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, src_ld, cols, dst, ld, B);
+}
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t st) {
     hipLaunchKernelGGL(rc_prep_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, B, first_frame);
 }
@@ -604,7 +621,11 @@ void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t st) {
     ResetArgs a;
-    for (int n = 0; n < 6; ++n) { a.h[n] = h[n]; a.c[n] = c[n]; a.H[n] = hidden[n]; a.h_elems[n] = (long long)B * hidden[n]; }
+    const long long Bp = (B + 31) / 32 * 32;
+    for (int n = 0; n < 6; ++n) {
+        a.h[n] = h[n]; a.c[n] = c[n]; a.H[n] = hidden[n];
+        a.h_elems[n] = Bp * hidden[n]; a.c_elems[n] = (long long)B * hidden[n];
+    }
     hipLaunchKernelGGL(rc_reset_kernel, dim3(B), dim3(256), 0, st, fb, a, mask, B);
 }
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t st) {

@@ -30,12 +30,18 @@ struct Frag {                 // one prefetch group: RC_G chunks of 8 k for A an
     f32x4 b1[RC_G];
 };
 
+#ifndef RC_ABLATE
+#define RC_ABLATE 0      // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
+#endif
+
 __device__ __forceinline__ void load_group(Frag& f, const float* pa, const float* pb0, const float* pb1) {
 #pragma unroll
     for (int c = 0; c < RC_G; ++c) {
-        f.a[c] = *reinterpret_cast<const f32x4*>(pa + 8 * c);
-        f.b0[c] = *reinterpret_cast<const f32x4*>(pb0 + 256 * c);
-        f.b1[c] = *reinterpret_cast<const f32x4*>(pb1 + 256 * c);
+        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[c] = *reinterpret_cast<const f32x4*>(pa + 256 * c);
+        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) {
+            f.b0[c] = *reinterpret_cast<const f32x4*>(pb0 + 256 * c);
+            f.b1[c] = *reinterpret_cast<const f32x4*>(pb1 + 256 * c);
+        }
     }
 }
 
@@ -44,8 +50,13 @@ __device__ __forceinline__ void mma_group(const Frag& f, f32x16& acc0, f32x16& a
     for (int c = 0; c < RC_G; ++c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+#if RC_ABLATE == 4
+            acc0[s] += f.a[c][s] + f.b0[c][s];
+            acc1[s] += f.b1[c][s];
+#else
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b0[c][s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b1[c][s], acc1, 0, 0, 0);
+#endif
         }
     }
 }
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
     for (int sgi = 0; sgi < 2; ++sgi) {
         const GemmSeg& sg = P.seg[sgi];
         const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
-        pa_seg[sgi] = sg.base + (long long)par * sg.par_stride + (long long)row * sg.ld + 4 * kh;
+        pa_seg[sgi] = sg.base + (long long)par * sg.par_stride + rc_pk(row, 4 * kh, sg.ld);
     }
     const int Q = P.Kp >> 3, Qw = Q / RC_NW, ng = Qw / RC_G;
     const int K0 = P.seg[0].K;
@@ -128,16 +139,50 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
     f32x16 acc0 = {0}, acc1 = {0};
     auto a_ptr = [&](int g) -> const float* {
         const int k = kbase + g * (8 * RC_G);
-        return k < K0 ? pa_seg[0] + k : pa_seg[1] + (k - K0);
+        return k < K0 ? pa_seg[0] + k * 32 : pa_seg[1] + (k - K0) * 32;      // chunk k/8 -> 256 floats
     };
-    Frag fa, fb;
-    load_group(fa, a_ptr(0), pb0, pb1);
-    for (int g = 0; g < ng; g += 2) {
-        if (g + 1 < ng) load_group(fb, a_ptr(g + 1), pb0 + (g + 1) * (256 * RC_G), pb1 + (g + 1) * (256 * RC_G));
+    // Software pipeline: the loads of group g+1 are issued BEFORE the 32 MFMAs of group g and stay in flight
+    // behind them (12 dwordx4 = 12 KiB per wave; the wait in front of an MFMA block is a counted vmcnt(12)).
+    // Two things are needed for hipcc (ROCm 7.2) to keep it that way: no conditional inside the steady-state
+    // loop (else it waits vmcnt(0) and round-trips the accumulators through VGPRs), and sched_barrier(0)
+    // between the phases (else it hoists both load groups to the loop top and drains them inside the iteration).
+#define LOADG(F, G) load_group(F, a_ptr(G), pb0 + (G) * (256 * RC_G), pb1 + (G) * (256 * RC_G))
+#ifndef RC_PIPE
+#define RC_PIPE 0
+#endif
+#if RC_PIPE
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SB() ((void)0)
+#endif
+    Frag fa = {}, fb = {};
+    int g = 0;
+    LOADG(fa, 0);
+    if (ng & 1) {                       // odd group count (only K' = 128): peel one group
+        SB();
         mma_group(fa, acc0, acc1);
-        if (g + 2 < ng) load_group(fa, a_ptr(g + 2), pb0 + (g + 2) * (256 * RC_G), pb1 + (g + 2) * (256 * RC_G));
-        if (g + 1 < ng) mma_group(fb, acc0, acc1);
+        g = 1;
+        if (ng > 1) LOADG(fa, 1);
     }
+    if (g < ng) {
+        for (; g + 2 < ng; g += 2) {
+            LOADG(fb, g + 1);
+            SB();
+            mma_group(fa, acc0, acc1);
+            SB();
+            LOADG(fa, g + 2);
+            SB();
+            mma_group(fb, acc0, acc1);
+            SB();
+        }
+        LOADG(fb, g + 1);
+        SB();
+        mma_group(fa, acc0, acc1);
+        SB();
+        mma_group(fb, acc0, acc1);
+    }
+#undef LOADG
+#undef SB
 
     // ---- split-K reduction through LDS (C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
 #pragma unroll
@@ -172,7 +217,7 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
                 const float gg = tanhf(gsum[2]), og = sigmoidf_(gsum[3]);
                 const float cn = fg * P.cstate[ci] + ig * gg;
                 P.cstate[ci] = cn;
-                P.hstate[(long long)dst * P.h_par_stride + ci] = og * tanhf(cn);
+                P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf(cn);
             }
         }
     } else {
@@ -185,7 +230,10 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
             for (int w = 1; w < RC_NW; ++w) v += s_part[w][rr][col];
             v += bv;
             if (P.epi == RC_EPI_RELU) v = fmaxf(v, 0.0f);
-            if (n < P.N) P.out[(long long)s_rows[rr] * P.ldo + n] = v;
+            if (n < P.N) {
+                const int r2 = s_rows[rr];
+                P.out[P.out_packed ? rc_pk(r2, P.out_col0 + n, P.ldo) : (long long)r2 * P.ldo + P.out_col0 + n] = v;
+            }
         }
     }
 }

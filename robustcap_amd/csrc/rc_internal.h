@@ -15,6 +15,14 @@
 #define RC_UNITS 16       // hidden units per LSTM tile
 #define RC_MAX_PROB 6     // problems fused in one launch
 
+// Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
+// wave's A load is one contiguous 1 KiB piece, exactly like the packed weights: for 32-row tile t = row / 32 and
+// 8-wide k chunk q = k / 8 the 256 floats [k-half (k/4)&1][row & 31][k & 3] are contiguous. (Row-major rows would
+// make each dwordx4 load touch 32 cache lines; the vector-memory front end, not HBM, was the bound -- profiles/.)
+__host__ __device__ inline long long rc_pk(long long row, int k, int ld) {
+    return (row >> 5) * (32ll * ld) + (long long)(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (row & 31) * 4 + (k & 3);
+}
+
 enum { RC_EPI_DENSE = 0, RC_EPI_RELU = 1, RC_EPI_LSTM = 2 };
 enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
 
@@ -26,7 +34,7 @@ enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
 #define RC_ROW_MASK 16u   // caller-supplied mask (rc_lstm_step)
 
 struct GemmSeg {
-    const float* base;      // activation matrix [rows, ld]
+    const float* base;      // activation matrix [rows, ld] in rc_pk order
     long long par_stride;   // elements between the two parity copies (0 if not double-buffered)
     int ld;
     int K;                  // padded length of this K segment (multiple of RC_KALIGN; 0 = absent)
@@ -38,13 +46,14 @@ struct GemmProblem {
     GemmSeg seg[2];         // A = [seg0 | seg1] along K
     const float* W;         // packed weights, see pack_weights() in rc_api.cpp
     const float* bias;      // [n_tiles * 64] in packed column order
-    float* out;             // dense: out[row * ldo + n]
+    float* out;             // dense: out[row * ldo + col0 + n], or rc_pk(row, col0 + n, ldo) if out_packed
     float* hstate;          // lstm: h[parity][row][H]
     float* cstate;          // lstm: c[row][H]
     int* steps;             // per-row step counter of this net (parity = steps & 1)
     const unsigned char* flags;
     long long h_par_stride;
     int ldo, N, H;
+    int out_col0, out_packed;
     int flag_bit;           // 0 = all rows
     int epi;                // RC_EPI_*
     int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
@@ -69,7 +78,7 @@ struct BodyConst {          // device copy of the body constants the path needs
 };
 
 struct FrameBuffers {       // device pointers owned by the context (all [B, ld] row-major)
-    float *x2, *x3, *x4, *x6, *x78, *x4l, *x6l, *xi;   // concatenated sub-net inputs (padded, pads stay zero)
+    float *x2, *x3, *x4, *x6, *x78, *x4l, *x6l, *xi;   // concatenated sub-net inputs (rc_pk order, padded, pads stay zero)
     float *vr, *pc, *r6d, *contact;                     // sub-net outputs consumed by the fusion logic
     float *init_out;                                    // rnn2.init_net output [B, 2048]
     unsigned char* flags;                               // RC_ROW_* per row
@@ -105,6 +114,8 @@ void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
                     int first_frame, hipStream_t s);
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
+
+void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t s);
 
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);
