@@ -43,6 +43,7 @@ struct NetDev {
     int* steps = nullptr;                // [B]
     float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
     int in = 0, H = 0, out = 0;
+    int nb = 2;                          // 32-column blocks per LSTM tile (8*nb hidden units x 4 gates)
 };
 
 }  // namespace
@@ -154,7 +155,7 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp;
+    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nb = 2;
     return p;
 }
 
@@ -177,7 +178,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
-    p.n_tiles = n.H / RC_UNITS; p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H;
+    p.n_tiles = n.H / (8 * n.nb); p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H; p.nb = n.nb;
     return p;
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
@@ -323,6 +324,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     for (int i = 0; i < 6 && !rc; ++i) {
         NetDev& n = ctx->net[i];
         n.in = kNets[i].in; n.H = kNets[i].H; n.out = kNets[i].out;
+        n.nb = n.H == 1280 ? 5 : (n.H == 1024 ? 4 : 2);      // 256 tiles per layer at batch 256 for every net
         A(n.h, 4 * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
     }
     A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);
@@ -419,8 +421,9 @@ int rc_finalize_weights(rc_ctx* ctx) {
             const auto *wi = need("rnn.weight_ih_l" + sl, 4 * H * H), *wh = need("rnn.weight_hh_l" + sl, 4 * H * H);
             const auto *bi = need("rnn.bias_ih_l" + sl, 4 * H), *bh = need("rnn.bias_hh_l" + sl, 4 * H);
             if (!wi || !wh || !bi || !bh) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing LSTM weights of " + p);
-            // column n' of tile t = [i | f | g | o] x 16 units  <->  torch row g*H + t*16 + u (gate order i,f,g,o)
-            auto orig = [&](int np) { const int t = np / RC_NT, g = (np % RC_NT) / RC_UNITS, u = np % RC_UNITS; return (size_t)g * H + t * RC_UNITS + u; };
+            // column n' of tile t = [i | f | g | o] x UT units  <->  torch row g*H + t*UT + u (gate order i,f,g,o)
+            const int UT = 8 * n.nb, NT = 4 * UT;
+            auto orig = [&](int np) { const int t = np / NT, g = (np % NT) / UT, u = np % UT; return (size_t)g * H + t * UT + u; };
             auto get = [&](int np, int k) -> float {
                 const size_t r = orig(np);
                 return k < (int)H ? (*wi)[r * H + k] : (*wh)[r * H + (k - H)];

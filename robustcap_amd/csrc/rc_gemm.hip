@@ -20,72 +20,77 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define LDS_LD (RC_NT + 16)   // +16 floats: the epilogue's two rows per half-wave land on disjoint banks
+#define LDS_PAD 16            // floats added to a partial-sum row: epilogue rows land on different banks
+
+#ifndef RC_ABLATE
+#define RC_ABLATE 0           // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
+#endif
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-struct Frag {                 // one prefetch group: RC_G chunks of 8 k for A and for both column blocks
+template <int NB>
+struct Frag {                 // one prefetch group: RC_G chunks of 8 k for A and for NB 32-column blocks of W
     f32x4 a[RC_G];
-    f32x4 b0[RC_G];
-    f32x4 b1[RC_G];
+    f32x4 b[NB][RC_G];
 };
 
-#ifndef RC_ABLATE
-#define RC_ABLATE 0      // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
-#endif
-
-__device__ __forceinline__ void load_group(Frag& f, const float* pa, const float* pb0, const float* pb1) {
+template <int NB>
+__device__ __forceinline__ void load_group(Frag<NB>& f, const float* pa, const float* pb, long long bstride) {
 #pragma unroll
     for (int c = 0; c < RC_G; ++c) {
         if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[c] = *reinterpret_cast<const f32x4*>(pa + 256 * c);
-        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) {
-            f.b0[c] = *reinterpret_cast<const f32x4*>(pb0 + 256 * c);
-            f.b1[c] = *reinterpret_cast<const f32x4*>(pb1 + 256 * c);
-        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (!(RC_ABLATE & 2) || RC_ABLATE == 4) f.b[j][c] = *reinterpret_cast<const f32x4*>(pb + j * bstride + 256 * c);
     }
 }
 
-__device__ __forceinline__ void mma_group(const Frag& f, f32x16& acc0, f32x16& acc1) {
+template <int NB>
+__device__ __forceinline__ void mma_group(const Frag<NB>& f, f32x16 (&acc)[NB]) {
 #pragma unroll
     for (int c = 0; c < RC_G; ++c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
 #if RC_ABLATE == 4
-            acc0[s] += f.a[c][s] + f.b0[c][s];
-            acc1[s] += f.b1[c][s];
+                acc[j][s] += f.a[c][s] + f.b[j][c][s];
+#elif RC_ABLATE == 5   // timing probe only (wrong numerics): same FLOPs as two 16x16x4 MFMAs, 1/2 the accumulator traffic
+                {
+                    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                    f32x4_ lo = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]}, hi = {acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
+                    lo = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[c][s], f.b[j][c][s], lo, 0, 0, 0);
+                    hi = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[c][s], f.b[j][c][s], hi, 0, 0, 0);
+                    acc[j][0] = lo[0]; acc[j][1] = lo[1]; acc[j][2] = lo[2]; acc[j][3] = lo[3];
+                    acc[j][4] = hi[0]; acc[j][5] = hi[1]; acc[j][6] = hi[2]; acc[j][7] = hi[3];
+                }
 #else
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b0[c][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b1[c][s], acc1, 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b[j][c][s], acc[j], 0, 0, 0);
 #endif
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L) {
-    __shared__ float s_part[RC_NW][RC_MT][LDS_LD];
-    __shared__ int s_rows[RC_MT];
-    __shared__ int s_cnt[RC_NW];
-
+// One workgroup = one 32-row x (32*NB)-column tile, K split over the RC_NW waves.
+//   NB = 2: 16 hidden units x 4 gates (H = 512 nets, dense layers)      384 B loaded per MFMA
+//   NB = 4: 32 units (rnn6, H = 1024)                                   320 B
+//   NB = 5: 40 units (rnn4, H = 1280)                                   307 B
+// so that every LSTM layer of every net is exactly 256 workgroups at batch 256 (one per CU) and the big nets
+// load fewer bytes per MFMA: measured on MI355X, a CU delivers ~256 B of operands per 64-cycle MFMA slot while
+// the matrix pipe is busy, which caps a 32x64 tile at 67 % MFMA utilisation (profiles/r01_gemm_probe.txt).
+// PIPE pins a software pipeline (loads of group g+1 issued before the MFMAs of group g) with sched_barrier;
+// without it hipcc issues both groups' loads at the top of an iteration and drains them inside it.
+template <int NB, bool PIPE>
+__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile, const int n_tile, float* s_mem) {
+    constexpr int NT = 32 * NB, UT = 8 * NB, LD = NT + LDS_PAD;
+    int* s_rows = reinterpret_cast<int*>(s_mem);                   // [RC_MT]
+    int* s_cnt = s_rows + RC_MT;                                    // [RC_NW] (+ padding to 64 ints)
+    float* s_part = s_mem + 64;                                     // [RC_NW][RC_MT][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int pi = 0;
-#pragma unroll
-    for (int q = 1; q < RC_MAX_PROB; ++q)
-        if (q < L.n && (int)blockIdx.x >= L.p[q].wg_base) pi = q;
-    const GemmProblem& P = L.p[pi];
-    const int local = blockIdx.x - P.wg_base;
-    int m_tile, n_tile;
-    if ((P.n_tiles & 7) == 0) {   // XCD-aware: the row tiles of one weight slice share block-id % 8
-        const int xcd = local & 7, s = local >> 3;
-        m_tile = s % P.m_tiles;
-        n_tile = (s / P.m_tiles) * 8 + xcd;
-    } else {
-        m_tile = local % P.m_tiles;
-        n_tile = local / P.m_tiles;
-    }
-    if (n_tile >= P.n_tiles) return;
 
     // ---- active rows of this tile -------------------------------------------------------------------------
-    const int B = L.B, lo = m_tile * RC_MT;
+    const int lo = m_tile * RC_MT;
     int nrows;
     if (P.flag_bit == 0) {
         nrows = min(RC_MT, B - lo);
@@ -132,35 +137,29 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
     }
     const int Q = P.Kp >> 3, Qw = Q / RC_NW, ng = Qw / RC_G;
     const int K0 = P.seg[0].K;
-    const float* pb0 = P.W + ((long long)(n_tile * 2) * Q + (long long)wave * Qw) * 256 + lane * 4;
-    const float* pb1 = pb0 + (long long)Q * 256;
+    const long long bstride = (long long)Q * 256;                   // floats between consecutive 32-column blocks
+    const float* pb = P.W + ((long long)(n_tile * NB) * Q + (long long)wave * Qw) * 256 + lane * 4;
     const int kbase = wave * Qw * 8;
 
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     auto a_ptr = [&](int g) -> const float* {
         const int k = kbase + g * (8 * RC_G);
         return k < K0 ? pa_seg[0] + k * 32 : pa_seg[1] + (k - K0) * 32;      // chunk k/8 -> 256 floats
     };
-    // Software pipeline: the loads of group g+1 are issued BEFORE the 32 MFMAs of group g and stay in flight
-    // behind them (12 dwordx4 = 12 KiB per wave; the wait in front of an MFMA block is a counted vmcnt(12)).
-    // Two things are needed for hipcc (ROCm 7.2) to keep it that way: no conditional inside the steady-state
-    // loop (else it waits vmcnt(0) and round-trips the accumulators through VGPRs), and sched_barrier(0)
-    // between the phases (else it hoists both load groups to the loop top and drains them inside the iteration).
-#define LOADG(F, G) load_group(F, a_ptr(G), pb0 + (G) * (256 * RC_G), pb1 + (G) * (256 * RC_G))
-#ifndef RC_PIPE
-#define RC_PIPE 0
-#endif
-#if RC_PIPE
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SB() ((void)0)
-#endif
-    Frag fa = {}, fb = {};
+#define LOADG(F, G) load_group<NB>(F, a_ptr(G), pb + (G) * (256 * RC_G), bstride)
+#define SB() do { if (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
+    // The steady-state loop has NO conditionals: with a conditional prefetch hipcc (ROCm 7.2) waits vmcnt(0) in
+    // front of the MFMAs and round-trips the accumulators through VGPRs every iteration.
+    Frag<NB> fa = {}, fb = {};
     int g = 0;
     LOADG(fa, 0);
     if (ng & 1) {                       // odd group count (only K' = 128): peel one group
         SB();
-        mma_group(fa, acc0, acc1);
+        mma_group<NB>(fa, acc);
         g = 1;
         if (ng > 1) LOADG(fa, 1);
     }
@@ -168,73 +167,101 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
         for (; g + 2 < ng; g += 2) {
             LOADG(fb, g + 1);
             SB();
-            mma_group(fa, acc0, acc1);
+            mma_group<NB>(fa, acc);
             SB();
             LOADG(fa, g + 2);
             SB();
-            mma_group(fb, acc0, acc1);
+            mma_group<NB>(fb, acc);
             SB();
         }
         LOADG(fb, g + 1);
         SB();
-        mma_group(fa, acc0, acc1);
+        mma_group<NB>(fa, acc);
         SB();
-        mma_group(fb, acc0, acc1);
+        mma_group<NB>(fb, acc);
     }
 #undef LOADG
 #undef SB
 
     // ---- split-K reduction through LDS (C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        s_part[wave][rr][i] = acc0[r];
-        s_part[wave][rr][32 + i] = acc1[r];
-    }
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            s_part[(wave * RC_MT + rr) * LD + 32 * j + i] = acc[j][r];
+        }
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
-        // thread -> (row rr, unit u); columns of a tile are [i(16) | f(16) | g(16) | o(16)]
-        const int u = tid & 15;
-        const int unit = n_tile * RC_UNITS + u;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int rr = (tid >> 4) + 16 * pass;
+        // item -> (row rr, unit u); columns of a tile are [i(UT) | f(UT) | g(UT) | o(UT)]
+        for (int item = tid; item < RC_MT * UT; item += RC_NW * 64) {
+            const int rr = item / UT, u = item - rr * UT;
+            if (rr >= nrows) continue;
+            const int unit = n_tile * UT + u;
             float gsum[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int col = gq * 16 + u;
-                float v = s_part[0][rr][col];
+                const int col = gq * UT + u;
+                float v = s_part[rr * LD + col];
 #pragma unroll
-                for (int w = 1; w < RC_NW; ++w) v += s_part[w][rr][col];
-                gsum[gq] = v + P.bias[n_tile * RC_NT + col];
+                for (int w = 1; w < RC_NW; ++w) v += s_part[(w * RC_MT + rr) * LD + col];
+                gsum[gq] = v + P.bias[n_tile * NT + col];
             }
-            if (rr < nrows) {
-                const int r2 = s_rows[rr];
-                const int dst = P.steps[r2] & 1;
-                const long long ci = (long long)r2 * P.H + unit;
-                const float ig = sigmoidf_(gsum[0]), fg = sigmoidf_(gsum[1]);
-                const float gg = tanhf(gsum[2]), og = sigmoidf_(gsum[3]);
-                const float cn = fg * P.cstate[ci] + ig * gg;
-                P.cstate[ci] = cn;
-                P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf(cn);
-            }
+            const int r2 = s_rows[rr];
+            const int dst = P.steps[r2] & 1;
+            const long long ci = (long long)r2 * P.H + unit;
+            const float ig = sigmoidf_(gsum[0]), fg = sigmoidf_(gsum[1]);
+            const float gg = tanhf(gsum[2]), og = sigmoidf_(gsum[3]);
+            const float cn = fg * P.cstate[ci] + ig * gg;
+            P.cstate[ci] = cn;
+            P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf(cn);
         }
     } else {
-        const int col = tid & 63;
-        const int n = n_tile * RC_NT + col;
-        const float bv = P.bias[n];
-        for (int rr = tid >> 6; rr < nrows; rr += RC_NW) {
-            float v = s_part[0][rr][col];
+        for (int item = tid; item < RC_MT * NT; item += RC_NW * 64) {
+            const int rr = item / NT, col = item - rr * NT;
+            if (rr >= nrows) continue;
+            const int n = n_tile * NT + col;
+            float v = s_part[rr * LD + col];
 #pragma unroll
-            for (int w = 1; w < RC_NW; ++w) v += s_part[w][rr][col];
-            v += bv;
+            for (int w = 1; w < RC_NW; ++w) v += s_part[(w * RC_MT + rr) * LD + col];
+            v += P.bias[n];
             if (P.epi == RC_EPI_RELU) v = fmaxf(v, 0.0f);
             if (n < P.N) {
                 const int r2 = s_rows[rr];
                 P.out[P.out_packed ? rc_pk(r2, P.out_col0 + n, P.ldo) : (long long)r2 * P.ldo + P.out_col0 + n] = v;
             }
         }
+    }
+}
+
+#define RC_LDS_FLOATS (64 + RC_NW * RC_MT * (32 * 5 + LDS_PAD))
+
+__global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < RC_MAX_PROB; ++q)
+        if (q < L.n && (int)blockIdx.x >= L.p[q].wg_base) pi = q;
+    const GemmProblem& P = L.p[pi];
+    const int local = blockIdx.x - P.wg_base;
+    int m_tile, n_tile;
+    if ((P.n_tiles & 7) == 0) {   // XCD-aware: the row tiles of one weight slice share block-id % 8
+        const int xcd = local & 7, s = local >> 3;
+        m_tile = s % P.m_tiles;
+        n_tile = (s / P.m_tiles) * 8 + xcd;
+    } else {
+        m_tile = local % P.m_tiles;
+        n_tile = local / P.m_tiles;
+    }
+    if (n_tile >= P.n_tiles) return;
+    switch (P.nb) {
+        case 5: gemm_tile<5, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4: gemm_tile<4, true>(P, L.B, m_tile, n_tile, s_mem); break;
+#ifndef RC_PIPE2
+#define RC_PIPE2 true
+#endif
+        default: gemm_tile<2, RC_PIPE2>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
 

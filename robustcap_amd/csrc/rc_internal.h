@@ -8,11 +8,12 @@
 // (in-workgroup split-K) and reduced through LDS. Each wave runs v_mfma_f32_32x32x2_f32 on two 32-column
 // blocks that share the A operand.
 #define RC_MT 32          // rows per workgroup tile
-#define RC_NT 64          // columns per workgroup tile (LSTM: 16 hidden units x 4 gates)
+#define RC_NT 64          // columns per workgroup tile of dense layers (NB = 2 blocks of 32)
 #define RC_NW 4           // waves per workgroup (K split)
-#define RC_G 4            // 8-wide k-chunks fetched per prefetch group
-#define RC_KALIGN (8 * RC_G * RC_NW)   // padded K granularity = 128
-#define RC_UNITS 16       // hidden units per LSTM tile
+#ifndef RC_G
+#define RC_G 2            // 8-wide k-chunks fetched per prefetch group (2: best of 1/2/4 on MI355X, profiles/r01_gemm_probe.txt)
+#endif
+#define RC_KALIGN 128      // padded K granularity (>= 8 * RC_G * RC_NW)
 #define RC_MAX_PROB 6     // problems fused in one launch
 
 // Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
@@ -58,6 +59,8 @@ struct GemmProblem {
     int epi;                // RC_EPI_*
     int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
     int n_tiles, m_tiles, wg_base, Kp;
+    int nb;                 // 32-column blocks per tile: 2 (dense, H = 512), 4 (H = 1024), 5 (H = 1280)
+    int pad_;
 };
 
 struct GemmLaunch {
