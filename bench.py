@@ -44,6 +44,7 @@ def make_inputs(body, B, T, conf, seed, unique=32):
         for b in range(u, B):
             c = synth.conf_schedule(seed * 7919 + b, 7, T, conf)
             out["j2dc"][b, :, :, 2] = np.clip(out["j2dc"][b, :, :, 2] - out["conf"][b][:, None] + c[:, None], 0, 1)
+        out["conf"] = out["j2dc"][..., 2].mean(-1)
     return out
 
 

@@ -1,0 +1,58 @@
+"""Host-side logic that needs no GPU: state_dict layout, seeded generators, sharding arithmetic."""
+import numpy as np
+import pytest
+
+from robustcap_amd import config as C
+from robustcap_amd import dist as rdist
+from robustcap_amd import synth
+
+
+def test_state_dict_layout_matches_reference_counts():
+    spec = C.state_dict_spec()
+    assert len(spec) == len(dict(spec)) == 6 * 12 + 6
+    assert sum(int(np.prod(s)) for _, s in spec) == 63_424_546
+    macs = 0
+    for _, nin, h, nout in C.NETS:
+        macs += nin * h + 2 * 8 * h * h + h * nout
+    assert 2 * macs == C.FLOPS_PER_BODY_FRAME == 121_379_840
+
+
+def test_generators_are_deterministic_and_seed_sensitive():
+    a = synth.uniform01(3, 5, 1000)
+    assert np.array_equal(a, synth.uniform01(3, 5, 1000)) and not np.array_equal(a, synth.uniform01(4, 5, 1000))
+    assert a.dtype == np.float32 and 0 <= a.min() and a.max() < 1 and abs(float(a.mean()) - 0.5) < 0.05
+    b1, b2 = synth.make_body(1), synth.make_body(1)
+    assert all(np.array_equal(b1[k], b2[k]) for k in b1)
+    assert np.allclose(b1["weights"].sum(1), 1, atol=1e-6) and (b1["weights"] >= 0).all()
+    assert list(b1["parent"][1:]) == list(C.smpl_parent[1:])
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 64])
+def test_motion_shapes_and_physics(T):
+    body = synth.make_body(1)
+    m = synth.make_motion(9, 2, T, body, conf="mixed")
+    assert m["j2dc"].shape == (2, T, 33, 3) and m["accc"].shape == (2, T, 6, 3) and m["oric"].shape == (2, T, 6, 3, 3)
+    R = m["oric"].reshape(-1, 3, 3).astype(np.float64)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-5)           # IMU orientations are rotations
+    assert np.allclose(np.linalg.norm(m["gravityc"], axis=1), 1, atol=1e-5)
+    c = m["j2dc"][..., 2].mean(-1)
+    assert ((np.abs(c - 0.7) > 0.005) & (np.abs(c - 0.8) > 0.005)).all()           # schedules stay off the thresholds
+    assert (m["tran"][..., 2] > 2).all()                                           # bodies in front of the camera
+
+
+def test_conf_schedule_regimes():
+    c = synth.conf_schedule(5, 7, 4000, "mixed")
+    hi, mid, lo = (c >= 0.8).mean(), ((c > 0.7) & (c < 0.8)).mean(), (c <= 0.7).mean()
+    assert 0.3 < hi < 0.7 and 0.05 < mid < 0.4 and 0.1 < lo < 0.5
+    assert (synth.conf_schedule(5, 7, 500, "high") >= 0.8).all()
+
+
+@pytest.mark.parametrize("n,world", [(256, 8), (257, 8), (5, 8), (0, 2), (9, 1), (1024, 3)])
+def test_shard_range_partitions_rows(n, world):
+    blocks = [rdist.shard_range(n, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    sizes = [b - a for a, b in blocks]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        rdist.shard_range(4, 2, 2)
