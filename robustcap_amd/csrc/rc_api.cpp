@@ -43,7 +43,7 @@ struct NetDev {
     int* steps = nullptr;                // [B]
     float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
     int in = 0, H = 0, out = 0;
-    int nb = 2;                          // 32-column blocks per LSTM tile (8*nb hidden units x 4 gates)
+    int nc = 4;                          // 16-column blocks per LSTM tile (4*nc hidden units x 4 gates)
 };
 
 }  // namespace
@@ -93,19 +93,19 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
     return RC_OK;
 }
 
-// MFMA-B fragment order: for 32-column block nb and 8-wide k-chunk q, lane l = kh*32 + j holds the float4
-// W'[nb*32 + j][8q + 4kh + 0..3]; blocks are laid out [nb][q][lane][4] so that a wave's K slice is one
-// contiguous stream of 1 KiB pieces. getW(n, k) returns the (padded) logical weight W'[n][k].
+// MFMA-B fragment order (v_mfma_f32_16x16x4_f32): for 16-column block cb and 16-wide k-chunk q, lane l = kq*16 + j
+// holds the float4 W'[cb*16 + j][16q + 4kq + 0..3]; blocks are laid out [cb][q][lane][4] so that a wave's K slice of
+// a column block is one contiguous stream of 1 KiB pieces. getW(n, k) returns the (padded) logical weight W'[n][k].
 template <typename F>
 std::vector<float> pack_weights(int Np, int Kp, F getW) {
     std::vector<float> out((size_t)Np * Kp);
-    const int Q = Kp / 8;
-    for (int nb = 0; nb < Np / 32; ++nb)
+    const int Q = Kp / RC_KC;
+    for (int cb = 0; cb < Np / 16; ++cb)
         for (int q = 0; q < Q; ++q)
             for (int l = 0; l < 64; ++l) {
-                const int kh = l >> 5, j = l & 31;
-                float* d = &out[(((size_t)nb * Q + q) * 64 + l) * 4];
-                for (int s = 0; s < 4; ++s) d[s] = getW(nb * 32 + j, 8 * q + 4 * kh + s);
+                const int kq = l >> 4, j = l & 15;
+                float* d = &out[(((size_t)cb * Q + q) * 64 + l) * 4];
+                for (int s = 0; s < 4; ++s) d[s] = getW(cb * 16 + j, RC_KC * q + 4 * kq + s);
             }
     return out;
 }
@@ -155,7 +155,7 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nb = 2;
+    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nc = 4;
     return p;
 }
 
@@ -178,7 +178,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
-    p.n_tiles = n.H / (8 * n.nb); p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H; p.nb = n.nb;
+    p.n_tiles = n.H / (4 * n.nc); p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H; p.nc = n.nc;
     return p;
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
@@ -324,7 +324,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     for (int i = 0; i < 6 && !rc; ++i) {
         NetDev& n = ctx->net[i];
         n.in = kNets[i].in; n.H = kNets[i].H; n.out = kNets[i].out;
-        n.nb = n.H == 1280 ? 5 : (n.H == 1024 ? 4 : 2);      // 256 tiles per layer at batch 256 for every net
+        n.nc = n.H == 1280 ? 10 : (n.H == 1024 ? 8 : 4);     // 256 tiles per layer at batch 256 for every net
         A(n.h, 4 * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
     }
     A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);
@@ -422,7 +422,7 @@ int rc_finalize_weights(rc_ctx* ctx) {
             const auto *bi = need("rnn.bias_ih_l" + sl, 4 * H), *bh = need("rnn.bias_hh_l" + sl, 4 * H);
             if (!wi || !wh || !bi || !bh) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing LSTM weights of " + p);
             // column n' of tile t = [i | f | g | o] x UT units  <->  torch row g*H + t*UT + u (gate order i,f,g,o)
-            const int UT = 8 * n.nb, NT = 4 * UT;
+            const int UT = 4 * n.nc, NT = 4 * UT;
             auto orig = [&](int np) { const int t = np / NT, g = (np % NT) / UT, u = np % UT; return (size_t)g * H + t * UT + u; };
             auto get = [&](int np, int k) -> float {
                 const size_t r = orig(np);

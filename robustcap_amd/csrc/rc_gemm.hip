@@ -8,7 +8,7 @@
 // 32-row x 64-column tiles; a tile's K range is split over the 4 waves of its workgroup so that a 512-unit
 // layer already yields 256 workgroups (one per CU). Each wave streams ITS slice of the weights straight from
 // L2/HBM into VGPRs as 1 KiB coalesced dwordx4 loads (weights are pre-packed in MFMA-B fragment order, nothing
-// is shared between waves so LDS staging would be pure overhead) and feeds v_mfma_f32_32x32x2_f32 -- bitwise an
+// is shared between waves so LDS staging would be pure overhead) and feeds v_mfma_f32_16x16x4_f32 -- bitwise an
 // fp32 fma chain, which is what keeps the 1e-4 parity budget. Partial sums meet in LDS; the epilogue applies the
 // bias and, for LSTM layers, the gate non-linearities and the (c, h) update, so gates never touch HBM.
 // The 8 row tiles that share a weight slice are mapped to the same XCD (block id % 8) to share it through L2.
@@ -28,62 +28,53 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int NB>
-struct Frag {                 // one prefetch group: RC_G chunks of 8 k for A and for NB 32-column blocks of W
-    f32x4 a[RC_G];
-    f32x4 b[NB][RC_G];
+template <int NC>
+struct Frag {                 // one chunk (16 k): a float4 per lane for each of the 2 row blocks and NC column blocks
+    f32x4 a[2];
+    f32x4 b[NC];
 };
 
-template <int NB>
-__device__ __forceinline__ void load_group(Frag<NB>& f, const float* pa, const float* pb, long long bstride) {
+template <int NC>
+__device__ __forceinline__ void load_chunk(Frag<NC>& f, const float* pa, long long astride, const float* pb, long long bstride) {
 #pragma unroll
-    for (int c = 0; c < RC_G; ++c) {
-        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[c] = *reinterpret_cast<const f32x4*>(pa + 256 * c);
+    for (int r = 0; r < 2; ++r)
+        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[r] = *reinterpret_cast<const f32x4*>(pa + r * astride);
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (!(RC_ABLATE & 2) || RC_ABLATE == 4) f.b[j][c] = *reinterpret_cast<const f32x4*>(pb + j * bstride + 256 * c);
-    }
+    for (int j = 0; j < NC; ++j)
+        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) f.b[j] = *reinterpret_cast<const f32x4*>(pb + j * bstride);
 }
 
-template <int NB>
-__device__ __forceinline__ void mma_group(const Frag<NB>& f, f32x16 (&acc)[NB]) {
+template <int NC>
+__device__ __forceinline__ void mma_chunk(const Frag<NC>& f, f32x4 (&acc)[2][NC]) {
 #pragma unroll
-    for (int c = 0; c < RC_G; ++c) {
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int j = 0; j < NC; ++j) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
+            for (int r = 0; r < 2; ++r) {
 #if RC_ABLATE == 4
-                acc[j][s] += f.a[c][s] + f.b[j][c][s];
-#elif RC_ABLATE == 5   // timing probe only (wrong numerics): same FLOPs as two 16x16x4 MFMAs, 1/2 the accumulator traffic
-                {
-                    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-                    f32x4_ lo = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]}, hi = {acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
-                    lo = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[c][s], f.b[j][c][s], lo, 0, 0, 0);
-                    hi = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[c][s], f.b[j][c][s], hi, 0, 0, 0);
-                    acc[j][0] = lo[0]; acc[j][1] = lo[1]; acc[j][2] = lo[2]; acc[j][3] = lo[3];
-                    acc[j][4] = hi[0]; acc[j][5] = hi[1]; acc[j][6] = hi[2]; acc[j][7] = hi[3];
-                }
+                acc[r][j][s] += f.a[r][s] + f.b[j][s];
 #else
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[c][s], f.b[j][c][s], acc[j], 0, 0, 0);
+                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r][s], f.b[j][s], acc[r][j], 0, 0, 0);
 #endif
             }
         }
     }
 }
 
-// One workgroup = one 32-row x (32*NB)-column tile, K split over the RC_NW waves.
-//   NB = 2: 16 hidden units x 4 gates (H = 512 nets, dense layers)      384 B loaded per MFMA
-//   NB = 4: 32 units (rnn6, H = 1024)                                   320 B
-//   NB = 5: 40 units (rnn4, H = 1280)                                   307 B
+// One workgroup = one 32-row x (16*NC)-column tile, K split over the RC_NW waves.
+//   NC = 4 : 16 hidden units x 4 gates (H = 512 nets, dense layers)     384 B of operands per 4096 MFMA-FLOP
+//   NC = 8 : 32 units (rnn6, H = 1024)                                  320 B
+//   NC = 10: 40 units (rnn4, H = 1280)                                  307 B
 // so that every LSTM layer of every net is exactly 256 workgroups at batch 256 (one per CU) and the big nets
-// load fewer bytes per MFMA: measured on MI355X, a CU delivers ~256 B of operands per 64-cycle MFMA slot while
-// the matrix pipe is busy, which caps a 32x64 tile at 67 % MFMA utilisation (profiles/r01_gemm_probe.txt).
-// PIPE pins a software pipeline (loads of group g+1 issued before the MFMAs of group g) with sched_barrier;
-// without it hipcc issues both groups' loads at the top of an iteration and drains them inside it.
-template <int NB, bool PIPE>
+// load fewer bytes per FLOP: measured on MI355X, a CU delivers ~256 B of operands per 64 MFMA cycles while the
+// matrix pipe is busy, which caps a 32x64 tile at 67 % MFMA utilisation (profiles/r01_gemm_probe.txt).
+// v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
+// PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
+// without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
+template <int NC, bool PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile, const int n_tile, float* s_mem) {
-    constexpr int NT = 32 * NB, UT = 8 * NB, LD = NT + LDS_PAD;
+    constexpr int NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
     int* s_rows = reinterpret_cast<int*>(s_mem);                   // [RC_MT]
     int* s_cnt = s_rows + RC_MT;                                    // [RC_NW] (+ padding to 64 ints)
     float* s_part = s_mem + 64;                                     // [RC_NW][RC_MT][LD]
@@ -125,72 +116,72 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     if (P.open_step && n_tile == 0 && tid < nrows) P.steps[s_rows[tid]] += 1;
 
     // ---- K loop: wave `wave` owns chunks [wave*Qw, (wave+1)*Qw) -------------------------------------------
-    const int i = lane & 31, kh = lane >> 5;
-    const int row = s_rows[i];
-    const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] : 0;
-    const float* pa_seg[2];
+    const int i = lane & 15, kq = lane >> 4;
+    // per-lane A pointers of the two 16-row blocks (rows may come from anywhere in the batch after compaction)
+    const float* pa_seg[2][2];
 #pragma unroll
-    for (int sgi = 0; sgi < 2; ++sgi) {
-        const GemmSeg& sg = P.seg[sgi];
-        const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
-        pa_seg[sgi] = sg.base + (long long)par * sg.par_stride + rc_pk(row, 4 * kh, sg.ld);
+    for (int r = 0; r < 2; ++r) {
+        const int row = s_rows[16 * r + i];
+        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] : 0;
+#pragma unroll
+        for (int sgi = 0; sgi < 2; ++sgi) {
+            const GemmSeg& sg = P.seg[sgi];
+            const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
+            pa_seg[sgi][r] = sg.base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
+        }
     }
-    const int Q = P.Kp >> 3, Qw = Q / RC_NW, ng = Qw / RC_G;
+    const int Q = P.Kp / RC_KC, Qw = Q / RC_NW;                     // chunks per wave: even (K' % 128 == 0)
     const int K0 = P.seg[0].K;
-    const long long bstride = (long long)Q * 256;                   // floats between consecutive 32-column blocks
-    const float* pb = P.W + ((long long)(n_tile * NB) * Q + (long long)wave * Qw) * 256 + lane * 4;
-    const int kbase = wave * Qw * 8;
+    const long long bstride = (long long)Q * 256;                   // floats between consecutive 16-column blocks
+    const float* pb = P.W + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
+    const int kbase = wave * Qw * RC_KC;
+    // block 1's pointer as an offset from block 0's (same segment, same k): one base pointer per chunk
+    const long long ad0 = pa_seg[0][1] - pa_seg[0][0], ad1 = pa_seg[1][1] - pa_seg[1][0];
 
-    f32x16 acc[NB];
+    f32x4 acc[2][NC];
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    auto a_ptr = [&](int g) -> const float* {
-        const int k = kbase + g * (8 * RC_G);
-        return k < K0 ? pa_seg[0] + k * 32 : pa_seg[1] + (k - K0) * 32;      // chunk k/8 -> 256 floats
-    };
-#define LOADG(F, G) load_group<NB>(F, a_ptr(G), pb + (G) * (256 * RC_G), bstride)
+        for (int j = 0; j < NC; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define LOADC(F, QI)                                                                                      \
+    do {                                                                                                  \
+        const int k_ = kbase + (QI) * RC_KC;                                                              \
+        const bool s0_ = k_ < K0;                                                                         \
+        load_chunk<NC>(F, s0_ ? pa_seg[0][0] + k_ * 16 : pa_seg[1][0] + (k_ - K0) * 16, s0_ ? ad0 : ad1,  \
+                       pb + (long long)(QI) * 256, bstride);                                              \
+    } while (0)
 #define SB() do { if (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
     // The steady-state loop has NO conditionals: with a conditional prefetch hipcc (ROCm 7.2) waits vmcnt(0) in
     // front of the MFMAs and round-trips the accumulators through VGPRs every iteration.
-    Frag<NB> fa = {}, fb = {};
-    int g = 0;
-    LOADG(fa, 0);
-    if (ng & 1) {                       // odd group count (only K' = 128): peel one group
+    Frag<NC> fa = {}, fb = {};
+    int q = 0;
+    LOADC(fa, 0);
+    for (; q + 2 < Qw; q += 2) {
+        LOADC(fb, q + 1);
         SB();
-        mma_group<NB>(fa, acc);
-        g = 1;
-        if (ng > 1) LOADG(fa, 1);
+        mma_chunk<NC>(fa, acc);
+        SB();
+        LOADC(fa, q + 2);
+        SB();
+        mma_chunk<NC>(fb, acc);
+        SB();
     }
-    if (g < ng) {
-        for (; g + 2 < ng; g += 2) {
-            LOADG(fb, g + 1);
-            SB();
-            mma_group<NB>(fa, acc);
-            SB();
-            LOADG(fa, g + 2);
-            SB();
-            mma_group<NB>(fb, acc);
-            SB();
-        }
-        LOADG(fb, g + 1);
-        SB();
-        mma_group<NB>(fa, acc);
-        SB();
-        mma_group<NB>(fb, acc);
-    }
-#undef LOADG
+    LOADC(fb, q + 1);
+    SB();
+    mma_chunk<NC>(fa, acc);
+    SB();
+    mma_chunk<NC>(fb, acc);
+#undef LOADC
 #undef SB
 
-    // ---- split-K reduction through LDS (C layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) ----
+    // ---- split-K reduction through LDS (C layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg) --------
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            s_part[(wave * RC_MT + rr) * LD + 32 * j + i] = acc[j][r];
-        }
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s_part[(wave * RC_MT + 16 * r + 4 * kq + e) * LD + 16 * j + i] = acc[r][j][e];
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
@@ -235,9 +226,15 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     }
 }
 
-#define RC_LDS_FLOATS (64 + RC_NW * RC_MT * (32 * 5 + LDS_PAD))
+// LDS is sized > 80 KB on purpose: ONE workgroup per CU. Two co-resident workgroups contend for the CU's operand
+// delivery path and run slower than back to back (probe: 512 tiles of H=512 take 33.9 us co-resident vs 28.2 us
+// serial; bench 373k vs 511k body-frames/s), profiles/r01_gemm_probe.txt.
+#define RC_LDS_FLOATS (64 + RC_NW * RC_MT * (16 * 10 + LDS_PAD))   // 90 KB
 
-__global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L) {
+#ifndef RC_WPS
+#define RC_WPS 1   // waves per SIMD the register allocation must allow
+#endif
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
     int pi = 0;
 #pragma unroll
@@ -255,13 +252,10 @@ __global__ __launch_bounds__(RC_NW * 64) void rc_gemm_kernel(const GemmLaunch L)
         n_tile = local / P.m_tiles;
     }
     if (n_tile >= P.n_tiles) return;
-    switch (P.nb) {
-        case 5: gemm_tile<5, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 4: gemm_tile<4, true>(P, L.B, m_tile, n_tile, s_mem); break;
-#ifndef RC_PIPE2
-#define RC_PIPE2 true
-#endif
-        default: gemm_tile<2, RC_PIPE2>(P, L.B, m_tile, n_tile, s_mem); break;
+    switch (P.nc) {
+        case 10: gemm_tile<10, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 8: gemm_tile<8, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        default: gemm_tile<4, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
 

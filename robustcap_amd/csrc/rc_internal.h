@@ -4,24 +4,22 @@
 #include <stdint.h>
 
 // ---- GEMM tiling -------------------------------------------------------------------------------------------
-// One workgroup = RC_NW waves = one 32-row x 64-column output tile; the K range is split across the waves
-// (in-workgroup split-K) and reduced through LDS. Each wave runs v_mfma_f32_32x32x2_f32 on two 32-column
-// blocks that share the A operand.
-#define RC_MT 32          // rows per workgroup tile
-#define RC_NT 64          // columns per workgroup tile of dense layers (NB = 2 blocks of 32)
+// One workgroup = RC_NW waves = one 32-row x (16*NC)-column output tile; the K range is split across the waves
+// (in-workgroup split-K) and reduced through LDS. Each wave runs v_mfma_f32_16x16x4_f32 on 2 row blocks x NC
+// column blocks (A: lane l = row l&15, k-quarter l>>4; B: k-quarter l>>4, column l&15).
+#define RC_MT 32          // rows per workgroup tile (2 MFMA row blocks)
+#define RC_NT 64          // columns per workgroup tile of dense layers (NC = 4 blocks of 16)
 #define RC_NW 4           // waves per workgroup (K split)
-#ifndef RC_G
-#define RC_G 2            // 8-wide k-chunks fetched per prefetch group (2: best of 1/2/4 on MI355X, profiles/r01_gemm_probe.txt)
-#endif
-#define RC_KALIGN 128      // padded K granularity (>= 8 * RC_G * RC_NW)
+#define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
+#define RC_KALIGN 128     // padded K granularity (>= 2 * RC_KC * RC_NW: an even number of chunks per wave)
 #define RC_MAX_PROB 6     // problems fused in one launch
 
 // Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
-// wave's A load is one contiguous 1 KiB piece, exactly like the packed weights: for 32-row tile t = row / 32 and
-// 8-wide k chunk q = k / 8 the 256 floats [k-half (k/4)&1][row & 31][k & 3] are contiguous. (Row-major rows would
-// make each dwordx4 load touch 32 cache lines; the vector-memory front end, not HBM, was the bound -- profiles/.)
+// wave's A load is one contiguous 1 KiB piece, exactly like the packed weights: for 16-row block row / 16 and
+// 16-wide k chunk k / 16 the 256 floats [k-quarter (k/4)&3][row & 15][k & 3] are contiguous. (Row-major rows would
+// make each dwordx4 load touch many cache lines; the vector-memory front end, not HBM, was the bound -- profiles/.)
 __host__ __device__ inline long long rc_pk(long long row, int k, int ld) {
-    return (row >> 5) * (32ll * ld) + (long long)(k >> 3) * 256 + ((k >> 2) & 1) * 128 + (row & 31) * 4 + (k & 3);
+    return (row >> 4) * (16ll * ld) + (long long)(k >> 4) * 256 + ((k >> 2) & 3) * 64 + (row & 15) * 4 + (k & 3);
 }
 
 enum { RC_EPI_DENSE = 0, RC_EPI_RELU = 1, RC_EPI_LSTM = 2 };
@@ -59,7 +57,7 @@ struct GemmProblem {
     int epi;                // RC_EPI_*
     int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
     int n_tiles, m_tiles, wg_base, Kp;
-    int nb;                 // 32-column blocks per tile: 2 (dense, H = 512), 4 (H = 1024), 5 (H = 1280)
+    int nc;                 // 16-column blocks per tile: 4 (dense, H = 512), 8 (H = 1024), 10 (H = 1280)
     int pad_;
 };
 
