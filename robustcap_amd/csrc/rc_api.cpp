@@ -161,11 +161,18 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
 
 struct Stage {                 // which rows of which net, reading which (rc_pk) input buffer, writing where
     int net; int flag_bit; const float* x; int ldx; Out y;
+    const unsigned char* flags = nullptr;      // row-selection byte array (default: fb.flags)
+    const float* x_alt = nullptr;              // input of rows lacking sel_bit in fb.flags (deferred updater step)
+    int sel_bit = 0;
+    int out_bit = 0;                           // linear2 writes only rows with this bit in fb.flags
 };
 
 GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
-    return dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit, c->fb.flags, n.steps, true);
+    GemmProblem p = dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit,
+                                  s.flags ? s.flags : c->fb.flags, n.steps, true);
+    p.alt_base = s.x_alt; p.sel_flags = c->fb.flags; p.sel_bit = s.x_alt ? s.sel_bit : 0;
+    return p;
 }
 GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     const NetDev& n = c->net[s.net];
@@ -176,7 +183,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.seg[1] = seg(n.h + layer * 2 * BH, n.H, n.H, RC_PAR_SRC, BH);         // own h, previous step
     p.W = n.Wl[layer]; p.bias = n.bl[layer];
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
-    p.steps = n.steps; p.flags = c->fb.flags; p.flag_bit = s.flag_bit;
+    p.steps = n.steps; p.flags = s.flags ? s.flags : c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
     p.n_tiles = n.H / (4 * n.nc); p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H; p.nc = n.nc;
     return p;
@@ -184,8 +191,10 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
     const long long BH = (long long)c->Bp * n.H;
-    return dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit, c->fb.flags,
-                         n.steps, false);
+    GemmProblem p = dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit,
+                                  s.flags ? s.flags : c->fb.flags, n.steps, false);
+    p.out_flags = c->fb.flags; p.out_bit = s.out_bit;
+    return p;
 }
 
 int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st) {
@@ -254,11 +263,20 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
     const int first = (flags & RC_FLAG_FIRST_FRAME) ? 1 : 0;
 
     rc_launch_prep(fb, io, prm, B, first, st);
-    // inertial pose branch + visual pose branch (L144, L153)
-    if (int rc = run_stage(ctx, {{N2, 0, fb.x2, 128, Out{fb.x3, 256, 72, true}},
-                                 {N4, (int)RC_ROW_VIS, fb.x4, 256, Out{fb.x6, 256, 171, true}}}, true, nullptr, st)) return rc;
+    // deferred vision updater of the previous frame (L264-271) for rows that step again now: rnn6 then rnn4 in the
+    // reference, independent nets here. State-only, linear2 skipped; usually no row qualifies and the tiles exit.
+    if (ctx->prm.use_vision_updater) {
+        if (int rc = run_stage(ctx, {Stage{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2},
+                                     Stage{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}},
+                               false, nullptr, st)) return rc;
+    }
+    // inertial pose branch (L144) + visual pose branch (L153); rnn4 also takes the rows whose deferred updater
+    // step is still pending and that do not step on camera keypoints this frame (they read x4l)
+    if (int rc = run_stage(ctx, {Stage{N2, 0, fb.x2, 128, Out{fb.x3, 256, 72, true}},
+                                 Stage{N4, (int)RC_ROW2_M4, fb.x4, 256, Out{fb.x6, 256, 171, true}, fb.flags2, fb.x4l,
+                                       (int)RC_ROW_VIS, (int)RC_ROW_VIS}}, true, nullptr, st)) return rc;
     if (first) {                                                           // L155-156: rnn6 on every row
-        if (int rc = run_stage(ctx, {{N6, 0, fb.x6, 256, Out{fb.pc, 4, 0, false}}}, true, nullptr, st)) return rc;
+        if (int rc = run_stage(ctx, {Stage{N6, 0, fb.x6, 256, Out{fb.pc, 4, 0, false}}}, true, nullptr, st)) return rc;
     }
     rc_launch_fuse(fb, io, prm, B, st);
     // velocity, visual translation, pose, contact (L145, L161/165, L169-170) + rnn2.init_net (L181-182)
@@ -268,17 +286,25 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
         init.push_back(dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), Out{ctx->hid2, 1024, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false));
         init.push_back(dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), Out{fb.init_out, 2048, 0, false}, false, RC_ROW_REACH, fb.flags, nullptr, false));
     }
-    if (int rc = run_stage(ctx, {{N3, 0, fb.x3, 256, Out{fb.vr, 4, 0, false}}, {N6, (int)RC_ROW_PC, fb.x6, 256, Out{fb.pc, 4, 0, false}},
-                                 {N7, 0, fb.x78, 256, Out{fb.r6d, 144, 0, false}}, {N8, 0, fb.x78, 256, Out{fb.contact, 2, 0, false}}},
+    if (int rc = run_stage(ctx, {Stage{N3, 0, fb.x3, 256, Out{fb.vr, 4, 0, false}},
+                                 Stage{N6, (int)RC_ROW2_M6, fb.x6, 256, Out{fb.pc, 4, 0, false}, fb.flags2, fb.x6l,
+                                       (int)RC_ROW_PC, (int)RC_ROW_PC},
+                                 Stage{N7, 0, fb.x78, 256, Out{fb.r6d, 144, 0, false}}, Stage{N8, 0, fb.x78, 256, Out{fb.contact, 2, 0, false}}},
                            true, &init, st)) return rc;
+    // tail: fusion logic + landmarks; rows in the occluded regime get their updater inputs (x6l, x4l) and a
+    // pending mark -- the two sub-net steps themselves run at the start of the next frame (or in rc_get_state)
     rc_launch_tail(fb, io, prm, ctx->body, B, first, st);
-    // vision updater (L264-271): state-only steps, linear2 skipped
-    if (ctx->prm.use_vision_updater) {
-        if (int rc = run_stage(ctx, {{N6, (int)RC_ROW_UPD, fb.x6l, 256, Out{nullptr, 0, 0, false}},
-                                     {N4, (int)RC_ROW_UPD, fb.x4l, 256, Out{nullptr, 0, 0, false}}}, false, nullptr, st)) return rc;
-    }
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
+}
+
+// run every pending (deferred) updater step now: state then equals the reference's at the end of its frame
+int flush_pending(rc_ctx* ctx, hipStream_t st) {
+    if (!ctx->have_weights || !ctx->prm.use_vision_updater) return RC_OK;
+    const FrameBuffers& fb = ctx->fb;
+    rc_launch_flush_flags(fb, ctx->B, st);
+    return run_stage(ctx, {Stage{N6, (int)RC_ROW2_FLUSH, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2},
+                           Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st);
 }
 
 int check_ready(rc_ctx* ctx) {
@@ -331,7 +357,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     A(fb.x2, Bp * 128); A(fb.x3, Bp * 256); A(fb.x4, Bp * 256); A(fb.x6, Bp * 256); A(fb.x78, Bp * 256);
     A(fb.x4l, Bp * 256); A(fb.x6l, Bp * 256); A(fb.xi, Bp * 128);
     A(fb.vr, B * 4); A(fb.pc, B * 4); A(fb.r6d, B * 144); A(fb.contact, B * 2); A(fb.init_out, B * 2048);
-    A(fb.flags, B); A(fb.regime, B); A(fb.kconf, B); A(fb.gravity, B * 3);
+    A(fb.flags, B); A(fb.flags2, B); A(fb.pend, B); A(fb.regime, B); A(fb.kconf, B); A(fb.gravity, B * 3);
     A(fb.last_pfoot, B * 6); A(fb.last_tran, B * 3); A(fb.floor, B * 33); A(fb.j_temp, B * 99);
     A(fb.has_last, B); A(fb.n_floor, B); A(fb.first_reach, B); A(fb.uv_count, B); A(fb.trace, B * 8);
     A(ctx->body, 1);
@@ -550,6 +576,7 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
     if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_lstm_step: unknown net ") + net);
     hipStream_t st = (hipStream_t)stream;
     const NetDev& n = ctx->net[ni];
+    if (int rc = flush_pending(ctx, st)) return rc;
     // stage x into the zero-padded rc_pk-ordered [B, 256] buffer the GEMM reads
     rc_launch_pack_rows(x, n.in, n.in, ctx->xtmp, 256, ctx->B, st);
     Stage s{ni, row_mask ? 255 : 0, ctx->xtmp, 256, Out{y, n.out, 0, false}};
@@ -564,6 +591,7 @@ int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, voi
     if (!ctx || !net || !h_host || !c_host) return RC_ERR_INVALID;
     const int ni = net_index(net);
     if (ni < 0) return fail(ctx, RC_ERR_INVALID, std::string("rc_get_state: unknown net ") + net);
+    if (int rc = flush_pending(ctx, (hipStream_t)stream)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     const NetDev& n = ctx->net[ni];
     const size_t B = ctx->B, Bp = ctx->Bp, H = n.H;

@@ -191,10 +191,18 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
     for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];                     // L139
     if (lane == 0) {
         unsigned f = 0;
-        if (gt_lo || first_frame) f |= RC_ROW_VIS;                        // L149
+        const bool vis = gt_lo || first_frame;
+        if (vis) f |= RC_ROW_VIS;                                         // L149
         if (gt_lo) f |= RC_ROW_PC;                                        // L161 / L165
         if (!gt_lo && refresh && prm.use_vision_updater) f |= RC_ROW_UPD; // L264
         fb.flags[row] = (unsigned char)f;
+        // deferred updater steps of the previous frame (see RC_ROW2_*)
+        const bool pend = fb.pend[row] != 0;
+        unsigned f2 = 0;
+        if (pend && vis) f2 |= RC_ROW2_TR;
+        if (vis || pend) f2 |= RC_ROW2_M4;
+        if (gt_lo || (pend && !vis)) f2 |= RC_ROW2_M6;
+        fb.flags2[row] = (unsigned char)f2;
         fb.regime[row] = is_hi ? 2 : (gt_lo ? 1 : 0);
         fb.kconf[row] = (c64 - prm.conf_lo) / (prm.conf_hi - prm.conf_lo);   // L163
         int* tr = fb.trace + row * 8;
@@ -210,8 +218,6 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
         const float a = acc[lane];
         fb.x4[rc_pk(row, lane, LD_X4)] = a;
         fb.x6[rc_pk(row, lane, LD_X6)] = a;
-        fb.x4l[rc_pk(row, lane, LD_X4)] = a;
-        fb.x6l[rc_pk(row, lane, LD_X6)] = a;
     }
     if (lane < 54) {                                                      // orir = Rcr^T . oric, L143
         const int i = lane / 9, r = (lane % 9) / 3, cc = lane % 3;
@@ -223,8 +229,6 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
         const float a = ori[lane];
         fb.x4[rc_pk(row, 18 + lane, LD_X4)] = a;
         fb.x6[rc_pk(row, 18 + lane, LD_X6)] = a;
-        fb.x4l[rc_pk(row, 18 + lane, LD_X4)] = a;
-        fb.x6l[rc_pk(row, 18 + lane, LD_X6)] = a;
     }
     if (lane < 33) {
         const int k = 72 + 3 * lane;
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             for (int c = 0; c < 3; ++c) fb.floor[row * 33 + 3 * appended + c] = pick[c];
         }
         if (live) fb.uv_count[row] = refresh ? prm.update_vision_freq : uvc - 1;   // L234-242
+        fb.pend[row] = (flags & RC_ROW_UPD) ? 1 : 0;                     // L264-271 run at the start of the next frame
         int* tr = fb.trace + row * 8;
         tr[1] = ((flags & RC_ROW_VIS) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
         tr[2] = (first_frame ? 1 : 0) + ((flags & RC_ROW_PC) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
@@ -446,6 +451,10 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 
     // L264-271: inputs of the vision updater (rnn6 on raw re-projection, rnn4 on the normalised one)
     if (flags & RC_ROW_UPD) {
+        // the updater's sub-net steps run at the start of the NEXT frame: this frame's IMU data goes with them
+        const float* acc = io.acc + row * io.s_acc;
+        if (lane < 18) { fb.x4l[rc_pk(row, lane, LD_X4)] = acc[lane]; fb.x6l[rc_pk(row, lane, LD_X6)] = acc[lane]; }
+        if (lane < 54) { fb.x4l[rc_pk(row, 18 + lane, LD_X4)] = ori[lane]; fb.x6l[rc_pk(row, 18 + lane, LD_X6)] = ori[lane]; }
         float x = 0.f, y = 0.f, z1 = 0.f;
         if (lane < 33) {
             const float z = s.J33[lane][2];
@@ -502,6 +511,7 @@ __global__ __launch_bounds__(256) void rc_reset_kernel(FrameBuffers fb, ResetArg
         fb.has_last[row] = 0;
         fb.n_floor[row] = 0;
         fb.first_reach[row] = 1;
+        fb.pend[row] = 0;
     }
 }
 
@@ -603,7 +613,18 @@ __global__ void rc_pack_rows_kernel(const float* src, int src_ld, int cols, floa
     dst[rc_pk(row, k, ld)] = src[row * src_ld + k];
 }
 
+// rc_get_state: turn every pending updater step into a transition step to be run right now
+__global__ void rc_flush_flags_kernel(FrameBuffers fb, int B) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B) return;
+    fb.flags2[row] = fb.pend[row] ? RC_ROW2_FLUSH : 0;
+    fb.pend[row] = 0;
+}
+
 // ================================================================================================ launchers
+void rc_launch_flush_flags(const FrameBuffers& fb, int B, hipStream_t st) {
+    hipLaunchKernelGGL(rc_flush_flags_kernel, dim3((B + 255) / 256), dim3(256), 0, st, fb, B);
+}
 void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t st) {
     const long long n = (long long)B * cols;
     hipLaunchKernelGGL(rc_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, src_ld, cols, dst, ld, B);

@@ -127,7 +127,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         for (int sgi = 0; sgi < 2; ++sgi) {
             const GemmSeg& sg = P.seg[sgi];
             const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
-            pa_seg[sgi][r] = sg.base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
+            const float* base = sg.base;
+            if (sgi == 0 && P.sel_bit && !(P.sel_flags[row] & P.sel_bit)) base = P.alt_base;
+            pa_seg[sgi][r] = base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
         }
     }
     const int Q = P.Kp / RC_KC, Qw = Q / RC_NW;                     // chunks per wave: even (K' % 128 == 0)
@@ -218,8 +220,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             for (int w = 1; w < RC_NW; ++w) v += s_part[(w * RC_MT + rr) * LD + col];
             v += P.bias[n];
             if (P.epi == RC_EPI_RELU) v = fmaxf(v, 0.0f);
-            if (n < P.N) {
-                const int r2 = s_rows[rr];
+            const int r2 = s_rows[rr];
+            if (n < P.N && (P.out_bit == 0 || (P.out_flags[r2] & P.out_bit))) {
                 P.out[P.out_packed ? rc_pk(r2, P.out_col0 + n, P.ldo) : (long long)r2 * P.ldo + P.out_col0 + n] = v;
             }
         }

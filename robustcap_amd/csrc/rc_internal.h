@@ -31,6 +31,14 @@ enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
 #define RC_ROW_UPD 4u     // vision updater: rnn6/rnn4 step on re-projected landmarks (c <= lo)
 #define RC_ROW_REACH 8u   // rnn2 state re-initialised by init_net this frame
 #define RC_ROW_MASK 16u   // caller-supplied mask (rc_lstm_step)
+// second flag byte (flags2): scheduling of the DEFERRED vision-updater steps. The updater's rnn6/rnn4 steps of
+// frame t only change state that frame t+1 reads, so they are executed at the start of frame t+1: merged into that
+// frame's own rnn4 / rnn6 launch when the row does not step there anyway (the row just reads its "late" input
+// buffer), or in a small transition launch first when it does (regime change low -> high).
+#define RC_ROW2_TR 1u     // pending updater step AND the row steps again this frame: transition launch
+#define RC_ROW2_M4 2u     // rows of the merged rnn4 launch  (VIS | pending)
+#define RC_ROW2_M6 4u     // rows of the merged rnn6 launch  (PC  | pending)
+#define RC_ROW2_FLUSH 8u  // rc_get_state: run every pending step now
 
 struct GemmSeg {
     const float* base;      // activation matrix [rows, ld] in rc_pk order
@@ -50,9 +58,13 @@ struct GemmProblem {
     float* cstate;          // lstm: c[row][H]
     int* steps;             // per-row step counter of this net (parity = steps & 1)
     const unsigned char* flags;
+    const float* alt_base;  // seg[0] of rows WITHOUT sel_bit in sel_flags reads here (deferred updater input)
+    const unsigned char* sel_flags;
+    const unsigned char* out_flags;   // dense: only rows with out_bit set are written (0 = all active rows)
     long long h_par_stride;
     int ldo, N, H;
     int out_col0, out_packed;
+    int sel_bit, out_bit;
     int flag_bit;           // 0 = all rows
     int epi;                // RC_EPI_*
     int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
@@ -83,6 +95,8 @@ struct FrameBuffers {       // device pointers owned by the context (all [B, ld]
     float *vr, *pc, *r6d, *contact;                     // sub-net outputs consumed by the fusion logic
     float *init_out;                                    // rnn2.init_net output [B, 2048]
     unsigned char* flags;                               // RC_ROW_* per row
+    unsigned char* flags2;                              // RC_ROW2_* per row
+    unsigned char* pend;                                // 1 = updater step of the previous frame still to run
     unsigned char* regime;                              // 0 low / 1 mid / 2 high
     double* kconf;                                      // (c - lo) / (hi - lo) per row
     float* gravity;                                     // [B,3]
@@ -116,6 +130,7 @@ void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
 
+void rc_launch_flush_flags(const FrameBuffers& fb, int B, hipStream_t s);
 void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t s);
 
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
