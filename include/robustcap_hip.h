@@ -48,6 +48,8 @@ typedef struct {
     int32_t use_imu_updater;       /* 1                                                                  */
     int32_t live;                  /* Net.live: landmark refresh every update_vision_freq+1 frames       */
     int32_t update_vision_freq;    /* 30                                                                 */
+    int32_t use_reproj_opt;        /* 0; Net.use_reproj_opt: closed-form translation refinement L245-261  */
+    float smooth;                  /* Net.smooth = 1 (regulariser of that refinement)                    */
     int32_t reserved;
 } rc_params;
 
@@ -103,6 +105,11 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
 /* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
 /* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264): r6d[n,6] -> R[n,3,3]. */
 int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream);
+/* art.math.axis_angle_to_rotation_matrix (articulate/math/angular.py:221-233): aa[n,3] -> R[n,3,3]. */
+int rc_axis_angle_to_rotmat(const float* aa, float* R, int64_t n, void* stream);
+/* art.math.rotation_matrix_to_axis_angle (articulate/math/angular.py:236-246; the reference loops cv2.Rodrigues on
+ * the host): R[n,3,3] -> aa[n,3], angle in [0, pi]. Computed in float64 (atan2 form). */
+int rc_rotmat_to_axis_angle(const float* R, float* aa, int64_t n, void* stream);
 /* ParametricModel.inverse_kinematics_R (articulate/math/spatial.py:197-221): Rg[n,24,3,3] -> Rl[n,24,3,3]. */
 int rc_ik_r(rc_ctx* ctx, const float* Rglobal, float* Rlocal, int64_t n, void* stream);
 /* fk() of forward_online (net/sig_mp.py:131-135): joints[n,24,3] from GLOBAL rotations + rest bone vectors. */

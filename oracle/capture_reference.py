@@ -182,6 +182,7 @@ SCENARIOS = {
     "noflat_mid": dict(T=96, conf="midheavy", first_tran=True, use_flat_floor=False),
     "live_post": dict(T=96, conf="mixed", first_frame=True, live="post"),
     "live_pre": dict(T=96, conf="livepre", first_frame=True, live="pre"),
+    "reproj_opt": dict(T=96, conf="mixed_hi0", first_tran=True, use_reproj_opt=True),
 }
 
 
@@ -214,7 +215,10 @@ def capture_sequences(art, sig_mp, body):
             "weight_checksum": {k: synth.checksum(v.numpy()) for k, v in list(sd.items())[::7]},
             "body_checksum": {k: synth.checksum(v) for k, v in body.items()},
             "torch": torch.__version__, "threads": torch.get_num_threads()}
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for si, (name, sc) in enumerate(SCENARIOS.items()):
+        if only and name not in only:
+            continue
         T = sc["T"]
         mseed = 100 + si
         conf = _conf(sc["conf"], T, mseed * 7919)
@@ -229,6 +233,7 @@ def capture_sequences(art, sig_mp, body):
         if live == "post":
             net.live = True
         net.use_flat_floor = sc.get("use_flat_floor", True)
+        net.use_reproj_opt = sc.get("use_reproj_opt", False)
         net.gravityc = torch.from_numpy(m["gravityc"][0].copy())
         ft = sc.get("first_tran")
         if ft is True:
@@ -276,6 +281,7 @@ def capture_sequences(art, sig_mp, body):
             j2dc=m["j2dc"][0], accc=m["accc"][0], oric=m["oric"][0], gravityc=m["gravityc"][0],
             first_tran=np.zeros(0, np.float32) if ft is None else ft.numpy(), first_frame=np.int32(ff),
             live=np.str_(live or ""), use_flat_floor=np.int32(sc.get("use_flat_floor", True)),
+            use_reproj_opt=np.int32(sc.get("use_reproj_opt", False)),
             pose=np.stack(poses), tran=np.stack(trans), trace=np.asarray(trace, np.float64),
             net_out=np.stack(outs), last_pfoot=net.last_pfoot.numpy(), **hid)
         tr = np.asarray(trace)
@@ -284,6 +290,8 @@ def capture_sequences(art, sig_mp, body):
               f"|tran| {np.abs(np.stack(trans)).max():.2f}")
         Net.live = False
     import json
+    if only:
+        return
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
@@ -293,5 +301,6 @@ if __name__ == "__main__":
     art, sig_mp, body = import_reference()
     torch.manual_seed(0)
     with torch.no_grad():
-        capture_ops(art, sig_mp, body)
+        if not [a for a in sys.argv[1:] if not a.startswith("-")]:
+            capture_ops(art, sig_mp, body)
         capture_sequences(art, sig_mp, body)

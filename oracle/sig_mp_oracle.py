@@ -245,6 +245,8 @@ class OracleNet(torch.nn.Module):
         self.use_flat_floor = True
         self.use_vision_updater = True
         self.use_imu_updater = True
+        self.use_reproj_opt = False
+        self.smooth = 1
         self.update_vision_freq = 30
         self.gravityc = torch.tensor([-0.0029, 0.9980, -0.0273]).repeat(batch, 1)   # sig_mp.py:36
         self.update_vision_count = torch.zeros(batch, dtype=torch.long)      # class attrs: survive reset_states
@@ -401,6 +403,22 @@ class OracleNet(torch.nn.Module):
             self.j_temp = j33.clone()
             self.update_vision_count = torch.where(refresh, torch.full_like(self.update_vision_count, self.update_vision_freq),
                                                    self.update_vision_count - 1)
+
+        if self.use_reproj_opt:                                               # L245-261: closed-form tran refinement
+            m = (c64 > lo).unsqueeze(1)
+            p, u2, v2 = j2dc[:, :, 2], j2dc[:, :, 0], j2dc[:, :, 1]
+            jx, jy, jz = j33[..., 0], j33[..., 1], j33[..., 2]
+            ax = (p / jz.pow(2)).sum(dim=1) + self.smooth
+            bx = (p * (-jx / jz.pow(2) + u2 / jz)).sum(dim=1)
+            by = (p * (-jy / jz.pow(2) + v2 / jz)).sum(dim=1)
+            d1 = torch.stack((bx / ax, by / ax, torch.zeros(B)), dim=1)
+            j1 = j33 + d1.unsqueeze(1)
+            jx, jy, jz = j1[..., 0], j1[..., 1], j1[..., 2]
+            az = (p * (jx.pow(2) + jy.pow(2)) / jz.pow(4)).sum(dim=1) + self.smooth
+            bz = (p * ((jx / jz - u2) * jx / jz.pow(2) + (jy / jz - v2) * jy / jz.pow(2))).sum(dim=1)
+            d2 = torch.stack((torch.zeros(B), torch.zeros(B), bz / az), dim=1)
+            tran = torch.where(m, (tran + d1) + d2, tran)
+            j33 = torch.where(m.unsqueeze(2), j1 + d2.unsqueeze(1), j33)
 
         upd = (c64 <= lo) & refresh & self.use_vision_updater                 # L264-271
         rows_u = upd.nonzero().flatten()

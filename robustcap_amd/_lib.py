@@ -19,7 +19,8 @@ class RcParams(C.Structure):
                 ("height_threshold", C.c_float), ("tran_filter_num", C.c_double),
                 ("use_flat_floor", C.c_int32), ("use_vision_updater", C.c_int32),
                 ("use_imu_updater", C.c_int32), ("live", C.c_int32),
-                ("update_vision_freq", C.c_int32), ("reserved", C.c_int32)]
+                ("update_vision_freq", C.c_int32), ("use_reproj_opt", C.c_int32), ("smooth", C.c_float),
+                ("reserved", C.c_int32)]
 
 
 class RobustcapLibraryError(RuntimeError):
@@ -42,6 +43,8 @@ SIGNATURES = {
     "rc_step": (_I32, [_P, _P, _P, _P, _P, _U32, _P, _P, _P]),
     "rc_sequence": (_I32, [_P, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _U32, _P, _I64, _P, _I64, _P]),
     "rc_r6d_to_rotmat": (_I32, [_P, _P, _I64, _P]),
+    "rc_axis_angle_to_rotmat": (_I32, [_P, _P, _I64, _P]),
+    "rc_rotmat_to_axis_angle": (_I32, [_P, _P, _I64, _P]),
     "rc_ik_r": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_fk_bone": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_body_fk": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -113,3 +113,21 @@ def r6d_to_rotation_matrix(r6d, device="cuda"):
     lib = _lib.load()
     _lib.check(None, lib.rc_r6d_to_rotmat(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_r6d_to_rotmat")
     return out
+
+
+def axis_angle_to_rotation_matrix(a, device="cuda"):
+    """art.math.axis_angle_to_rotation_matrix (articulate/math/angular.py:221-233) on the GPU: [n,3] -> [n,3,3]."""
+    x = _f32c(a, torch.device(device)).view(-1, 3)
+    out = torch.empty(x.shape[0], 3, 3, device=x.device)
+    lib = _lib.load()
+    _lib.check(None, lib.rc_axis_angle_to_rotmat(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_axis_angle_to_rotmat")
+    return out
+
+
+def rotation_matrix_to_axis_angle(r, device="cuda"):
+    """art.math.rotation_matrix_to_axis_angle (angular.py:236-246, cv2.Rodrigues loop in the reference): [n,3,3] -> [n,3]."""
+    x = _f32c(r, torch.device(device)).view(-1, 3, 3)
+    out = torch.empty(x.shape[0], 3, device=x.device)
+    lib = _lib.load()
+    _lib.check(None, lib.rc_rotmat_to_axis_angle(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_rotmat_to_axis_angle")
+    return out

@@ -253,6 +253,7 @@ rc_params_dev dev_params(const rc_params& p) {
     d.height_threshold = p.height_threshold;
     d.use_flat_floor = p.use_flat_floor; d.use_vision_updater = p.use_vision_updater;
     d.use_imu_updater = p.use_imu_updater; d.live = p.live; d.update_vision_freq = p.update_vision_freq;
+    d.use_reproj_opt = p.use_reproj_opt; d.smooth = p.smooth;
     return d;
 }
 
@@ -331,6 +332,8 @@ int rc_default_params(int32_t live, rc_params* out) {
     out->use_flat_floor = 1; out->use_vision_updater = 1; out->use_imu_updater = 1;
     out->live = live ? 1 : 0;
     out->update_vision_freq = 30;
+    out->use_reproj_opt = 0;                    // net/sig_mp.py:32
+    out->smooth = 1.0f;                         // net/sig_mp.py:30
     return RC_OK;
 }
 
@@ -539,6 +542,18 @@ int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream) {
     if (n == 0) return RC_OK;
     if (!r6d || !R || n < 0) return RC_ERR_INVALID;
     rc_launch_r6d(r6d, R, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_axis_angle_to_rotmat(const float* aa, float* R, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!aa || !R || n < 0) return RC_ERR_INVALID;
+    rc_launch_aa2R(aa, R, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_rotmat_to_axis_angle(const float* R, float* aa, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!aa || !R || n < 0) return RC_ERR_INVALID;
+    rc_launch_R2aa(R, aa, n, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
 }
 int rc_ik_r(rc_ctx* ctx, const float* Rg, float* Rl, int64_t n, void* stream) {

@@ -416,8 +416,6 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         for (int c = 0; c < 3; ++c) {
             fb.last_pfoot[row * 6 + c] = pf[0][c];
             fb.last_pfoot[row * 6 + 3 + c] = pf[1][c];
-            fb.last_tran[row * 3 + c] = tran[c];
-            io.tran_out[row * io.s_tran + c] = tran[c];
         }
         fb.has_last[row] = 1;
         fb.n_floor[row] = n_floor;
@@ -447,6 +445,33 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             }
         }
         __syncthreads();
+    }
+
+    // L245-261 (use_reproj_opt, default off): closed-form refinement of the translation from the 2D residual
+    if (prm.use_reproj_opt && regime >= 1) {
+        const float* kp = io.j2d + row * io.s_j2d;
+        float p = 0.f, u = 0.f, v = 0.f, jx = 0.f, jy = 0.f, jz = 1.f;
+        if (lane < 33) { u = kp[3 * lane]; v = kp[3 * lane + 1]; p = kp[3 * lane + 2]; jx = s.J33[lane][0]; jy = s.J33[lane][1]; jz = s.J33[lane][2]; }
+        const bool on = lane < 33;
+        const float ax = wave_sum(on ? p / (jz * jz) : 0.f) + prm.smooth;
+        const float bx = wave_sum(on ? p * (-jx / (jz * jz) + u / jz) : 0.f);
+        const float by = wave_sum(on ? p * (-jy / (jz * jz) + v / jz) : 0.f);
+        const float dx = bx / ax, dy = by / ax;
+        jx += dx; jy += dy;
+        const float z2 = jz * jz;
+        const float az = wave_sum(on ? p * (jx * jx + jy * jy) / (z2 * z2) : 0.f) + prm.smooth;
+        const float bz = wave_sum(on ? p * ((jx / jz - u) * jx / z2 + (jy / jz - v) * jy / z2) : 0.f);
+        const float dz = bz / az;
+        tran[0] = (tran[0] + dx) + 0.0f; tran[1] = (tran[1] + dy) + 0.0f; tran[2] = (tran[2] + 0.0f) + dz;
+        if (on) { s.J33[lane][0] = jx; s.J33[lane][1] = jy; s.J33[lane][2] = (jz + 0.0f) + dz; }
+        __syncthreads();
+    }
+    if (lane == 0) {                                                       // L273 (after the optional refinement)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fb.last_tran[row * 3 + c] = tran[c];
+            io.tran_out[row * io.s_tran + c] = tran[c];
+        }
     }
 
     // L264-271: inputs of the vision updater (rnn6 on raw re-projection, rnn4 on the normalised one)
@@ -578,6 +603,55 @@ __global__ __launch_bounds__(64) void rc_body_fk_kernel(const BodyConst* __restr
     }
 }
 
+// art.math.axis_angle_to_rotation_matrix (articulate/math/angular.py:221-233): c I + (1-c) a a^T + s [a]x, zero -> I
+__global__ void rc_aa2R_kernel(const float* aa, float* R, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a[3] = {aa[3 * i], aa[3 * i + 1], aa[3 * i + 2]};
+    const float th = norm3(a);
+    float k[3] = {a[0] / th, a[1] / th, a[2] / th};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if (!(fabsf(k[q]) <= 3.0e38f)) k[q] = 0.0f;          // NaN / inf -> 0
+    const float c = cosf(th), sn = sinf(th), t = 1.0f - c;
+    const float K[9] = {0.f, -k[2], k[1], k[2], 0.f, -k[0], -k[1], k[0], 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            R[9 * i + 3 * r + q] = ((r == q ? c : 0.0f) + t * (k[r] * k[q])) + sn * K[3 * r + q];
+}
+
+// art.math.rotation_matrix_to_axis_angle (angular.py:236-246 loops cv2.Rodrigues on the host). Restated from the
+// Rodrigues formula in float64: theta = atan2(|v|, (tr - 1) / 2), v = vee(R - R^T) / 2; near pi the axis comes
+// from the symmetric part. PARITY UNPINNED against OpenCV (absent); validated by round trip.
+__global__ void rc_R2aa_kernel(const float* Rm, float* aa, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double R[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) R[q] = (double)Rm[9 * i + q];
+    const double v[3] = {(R[7] - R[5]) * 0.5, (R[2] - R[6]) * 0.5, (R[3] - R[1]) * 0.5};
+    const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    const double th = atan2(sn, c);
+    double o[3];
+    if (sn > 1e-9) {
+        const double kf = th / sn;
+        o[0] = v[0] * kf; o[1] = v[1] * kf; o[2] = v[2] * kf;
+    } else if (c > 0.0) {
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    } else {                                     // theta = pi: R + I = 2 a a^T
+        const double d[3] = {sqrt(fmax((R[0] + 1.0) * 0.5, 0.0)), sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)), sqrt(fmax((R[8] + 1.0) * 0.5, 0.0))};
+        int m = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+        double ax[3] = {d[0], d[1], d[2]};
+        for (int q = 0; q < 3; ++q)
+            if (q != m && (R[3 * m + q] + R[3 * q + m]) < 0.0) ax[q] = -ax[q];
+        const double pi = 3.14159265358979323846;
+        o[0] = ax[0] * pi; o[1] = ax[1] * pi; o[2] = ax[2] * pi;
+    }
+    aa[3 * i] = (float)o[0]; aa[3 * i + 1] = (float)o[1]; aa[3 * i + 2] = (float)o[2];
+}
+
 // smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
 // (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
 __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
@@ -652,6 +726,12 @@ void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, c
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(rc_r6d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r6d, R, n);
+}
+void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_aa2R_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, R, n);
+}
+void rc_launch_R2aa(const float* R, float* aa, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_R2aa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R, aa, n);
 }
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t st) {
     if (n <= 0) return;

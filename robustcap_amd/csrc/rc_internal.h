@@ -119,7 +119,8 @@ struct FrameIO {
 struct rc_params_dev {
     double conf_lo, conf_hi, tran_filter_num;
     float contact_threshold, distance_threshold, height_threshold;
-    int use_flat_floor, use_vision_updater, use_imu_updater, live, update_vision_freq;
+    int use_flat_floor, use_vision_updater, use_imu_updater, live, update_vision_freq, use_reproj_opt;
+    float smooth;
 };
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
@@ -134,6 +135,8 @@ void rc_launch_flush_flags(const FrameBuffers& fb, int B, hipStream_t s);
 void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t s);
 
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
+void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t s);
+void rc_launch_R2aa(const float* R, float* aa, long long n, hipStream_t s);
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);
 void rc_launch_fk_bone(const BodyConst* body, const float* Rg, float* joints, long long n, hipStream_t s);
 void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tran, float* grot, float* joint,

@@ -27,7 +27,8 @@ from .. import body as _body
 from .. import config as cfg
 
 _PARAM_ATTRS = {"use_flat_floor", "use_vision_updater", "use_imu_updater", "live", "conf_range", "tran_filter_num",
-                "contact_threshold", "distrance_threshold", "height_threhold", "update_vision_freq"}
+                "contact_threshold", "distrance_threshold", "height_threhold", "update_vision_freq", "use_reproj_opt",
+                "smooth"}
 
 
 class Net:
@@ -70,8 +71,6 @@ class Net:
         if live_ctor:
             self.__dict__["conf_range"] = (0.85, 0.9)
             self.__dict__["tran_filter_num"] = 0.01
-        if self.use_reproj_opt:
-            raise NotImplementedError("use_reproj_opt (sig_mp.py:245-261) is off by default and not built yet")
         self._sd_cpu = {}
         self._loaded = False
         self._gravity_key = None
@@ -97,6 +96,8 @@ class Net:
         p.use_imu_updater = int(bool(self.use_imu_updater))
         p.live = int(bool(self.live))
         p.update_vision_freq = int(self.update_vision_freq)
+        p.use_reproj_opt = int(bool(self.use_reproj_opt))
+        p.smooth = float(self.smooth)
         _lib.check(self._ctx, self._lib.rc_set_params(self._ctx, C.byref(p)), "rc_set_params")
 
     def _sync_gravity(self):

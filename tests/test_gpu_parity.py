@@ -73,6 +73,21 @@ def test_r6d(ops):
     assert r6d_to_rotation_matrix(torch.zeros(0, 6)).shape == (0, 3, 3)            # empty input
 
 
+def test_axis_angle_both_ways(ops):
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd.body import axis_angle_to_rotation_matrix, rotation_matrix_to_axis_angle
+    R = axis_angle_to_rotation_matrix(t(ops["aa_in"]))
+    assert maxdiff(R, ops["aa_out"]) <= 2e-6                                       # vs the reference (pure torch there)
+    aa = rotation_matrix_to_axis_angle(t(ops["aa_out"]))                           # unpinned vs cv2: round trip + oracle
+    assert maxdiff(axis_angle_to_rotation_matrix(aa), ops["aa_out"]) <= 5e-6
+    assert maxdiff(aa, O.rotation_matrix_to_axis_angle(t(ops["aa_out"]))) <= 5e-6
+    assert float(aa.norm(dim=1).max()) <= 3.1416 and float(aa[0].abs().max()) == 0.0   # identity -> zero vector
+    half = torch.tensor([[[1.0, 0, 0], [0, -1, 0], [0, 0, -1]], [[-1.0, 0, 0], [0, -1, 0], [0, 0, 1]]])   # theta = pi
+    out = rotation_matrix_to_axis_angle(half).cpu()
+    assert maxdiff(out.abs(), torch.tensor([[3.14159265, 0, 0], [0, 0, 3.14159265]])) <= 1e-6
+    assert rotation_matrix_to_axis_angle(torch.zeros(0, 3, 3)).shape == (0, 3)
+
+
 def test_ik_and_bone_fk(ops, pm):
     assert maxdiff(pm.inverse_kinematics_R(t(ops["ik_in"])), ops["ik_out"]) <= 2e-6
     from oracle import sig_mp_oracle as O
@@ -144,6 +159,7 @@ def test_sequence_vs_reference_capture(path, synth_assets):
     if live == "post":
         net.live = True
     net.use_flat_floor = bool(s["use_flat_floor"])
+    net.use_reproj_opt = bool(s["use_reproj_opt"]) if "use_reproj_opt" in s else False
     net.gravityc = t(s["gravityc"])
     ft = t(s["first_tran"]) if s["first_tran"].size else None
     T = s["pose"].shape[0]

@@ -103,6 +103,7 @@ def test_sequence_vs_reference(path, synth_assets):
     if live == "post":
         net.live = True                                    # live_server.py:64-65 sets it after construction
     net.use_flat_floor = bool(s["use_flat_floor"])
+    net.use_reproj_opt = bool(s["use_reproj_opt"]) if "use_reproj_opt" in s else False
     net.gravityc = t(s["gravityc"]).view(1, 3)
     ft = t(s["first_tran"]) if s["first_tran"].size else None
     T = s["pose"].shape[0]
