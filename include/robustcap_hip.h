@@ -102,6 +102,18 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                 const float* oric, int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out,
                 int64_t rs_pose, float* tran_out, int64_t rs_tran, void* stream);
 
+/* ---- live / streaming mode (BASELINE config 5) ------------------------------------------------------------- */
+/* The live_server.py loop (live_server.py:40-48): one frame per call, HOST tensors in and out exactly like
+ * forward_online's CPU tensors. rc_live_begin captures the steady-state frame (H2D of the 171 input floats per row,
+ * the 17 kernels, D2H of the 219 output floats) into ONE hipGraph on a private stream; rc_live_step replays it
+ * (frames with first_tran / RC_FLAG_FIRST_FRAME take the ordinary enqueue path) and returns when the outputs are in
+ * host memory. j2dc[batch,33,3], accc[batch,6,3], oric[batch,6,3,3], first_tran[batch,3]|NULL -> pose[batch,24,3,3],
+ * tran[batch,3]. */
+int rc_live_begin(rc_ctx* ctx);
+int rc_live_step(rc_ctx* ctx, const float* j2dc_host, const float* accc_host, const float* oric_host,
+                 const float* first_tran_host, uint32_t flags, float* pose_host, float* tran_host);
+int rc_live_end(rc_ctx* ctx);
+
 /* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
 /* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264): r6d[n,6] -> R[n,3,3]. */
 int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream);

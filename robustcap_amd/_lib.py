@@ -42,6 +42,9 @@ SIGNATURES = {
     "rc_reset": (_I32, [_P, _P, _P]),
     "rc_step": (_I32, [_P, _P, _P, _P, _P, _U32, _P, _P, _P]),
     "rc_sequence": (_I32, [_P, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _U32, _P, _I64, _P, _I64, _P]),
+    "rc_live_begin": (_I32, [_P]),
+    "rc_live_step": (_I32, [_P, _P, _P, _P, _P, _U32, _P, _P]),
+    "rc_live_end": (_I32, [_P]),
     "rc_r6d_to_rotmat": (_I32, [_P, _P, _I64, _P]),
     "rc_axis_angle_to_rotmat": (_I32, [_P, _P, _I64, _P]),
     "rc_rotmat_to_axis_angle": (_I32, [_P, _P, _I64, _P]),

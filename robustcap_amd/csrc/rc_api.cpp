@@ -62,6 +62,12 @@ struct rc_ctx {
     std::map<std::string, std::vector<float>> staged;
     std::vector<void*> allocs;
     std::string err;
+    // live mode: one captured frame on a private stream, pinned host staging
+    hipStream_t live_stream = nullptr;
+    hipGraph_t live_graph = nullptr;
+    hipGraphExec_t live_exec = nullptr;
+    float *live_in_h = nullptr, *live_out_h = nullptr;      // pinned: [B,171] and [B,219]
+    float *live_in_d = nullptr, *live_out_d = nullptr, *live_ft_d = nullptr;
     // timing of the gate GEMM launches
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -381,6 +387,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
 
 int rc_destroy(rc_ctx* ctx) {
     if (!ctx) return RC_OK;
+    rc_live_end(ctx);
     for (void* p : ctx->allocs) hipFree(p);
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete ctx;
@@ -535,6 +542,72 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                    pose_out + (int64_t)t * 216, tran_out + (int64_t)t * 3, rs_j2d, rs_acc, rs_ori, rs_pose, rs_tran};
         if (int rc = step_impl(ctx, io, t == 0 ? flags : 0u, (hipStream_t)stream)) return rc;
     }
+    return RC_OK;
+}
+
+int rc_live_end(rc_ctx* ctx) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (ctx->live_exec) { hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
+    if (ctx->live_graph) { hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
+    if (ctx->live_stream) { hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
+    if (ctx->live_in_h) { hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
+    if (ctx->live_out_h) { hipHostFree(ctx->live_out_h); ctx->live_out_h = nullptr; }
+    if (ctx->live_in_d) { hipFree(ctx->live_in_d); ctx->live_in_d = nullptr; }
+    if (ctx->live_out_d) { hipFree(ctx->live_out_d); ctx->live_out_d = nullptr; }
+    if (ctx->live_ft_d) { hipFree(ctx->live_ft_d); ctx->live_ft_d = nullptr; }
+    return RC_OK;
+}
+
+int rc_live_begin(rc_ctx* ctx) {
+    if (int rc = check_ready(ctx)) return rc;
+    rc_live_end(ctx);
+    const size_t B = ctx->B;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->live_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_in_h, B * 171 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_out_h, B * 219 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->live_in_d, B * 171 * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->live_out_d, B * 219 * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->live_ft_d, B * 3 * sizeof(float)));
+    // capture: H2D -> frame -> D2H. Inputs are laid out [j2dc B*99 | accc B*18 | oric B*54], outputs [pose B*216 | tran B*3].
+    hipStream_t st = ctx->live_stream;
+    const bool timing = ctx->timing;
+    ctx->timing = false;
+    HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+    FrameIO io{ctx->live_in_d, ctx->live_in_d + B * 99, ctx->live_in_d + B * 117, nullptr,
+               ctx->live_out_d, ctx->live_out_d + B * 216, 99, 18, 54, 216, 3};
+    const int rc = step_impl(ctx, io, 0u, st);
+    hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipStreamEndCapture(st, &ctx->live_graph);
+    ctx->timing = timing;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    HIP_TRY(ctx, hipGraphInstantiate(&ctx->live_exec, ctx->live_graph, nullptr, nullptr, 0));
+    return RC_OK;
+}
+
+int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran, uint32_t flags,
+                 float* pose, float* tran) {
+    if (!ctx || !ctx->live_exec) return ctx ? fail(ctx, RC_ERR_STATE, "rc_live_step: call rc_live_begin first") : RC_ERR_INVALID;
+    if (!j2dc || !accc || !oric || !pose || !tran) return fail(ctx, RC_ERR_INVALID, "rc_live_step: null buffer");
+    const size_t B = ctx->B;
+    hipStream_t st = ctx->live_stream;
+    std::memcpy(ctx->live_in_h, j2dc, B * 99 * sizeof(float));
+    std::memcpy(ctx->live_in_h + B * 99, accc, B * 18 * sizeof(float));
+    std::memcpy(ctx->live_in_h + B * 117, oric, B * 54 * sizeof(float));
+    if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
+        if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
+        FrameIO io{ctx->live_in_d, ctx->live_in_d + B * 99, ctx->live_in_d + B * 117, first_tran ? ctx->live_ft_d : nullptr,
+                   ctx->live_out_d, ctx->live_out_d + B * 216, 99, 18, 54, 216, 3};
+        if (int rc = step_impl(ctx, io, flags, st)) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));
+    std::memcpy(tran, ctx->live_out_h + B * 216, B * 3 * sizeof(float));
     return RC_OK;
 }
 

@@ -99,6 +99,9 @@ class Net:
         p.use_reproj_opt = int(bool(self.use_reproj_opt))
         p.smooth = float(self.smooth)
         _lib.check(self._ctx, self._lib.rc_set_params(self._ctx, C.byref(p)), "rc_set_params")
+        if self.__dict__.get("_live_on"):               # kernel arguments are baked into the captured frame
+            _lib.check(self._ctx, self._lib.rc_live_end(self._ctx), "rc_live_end")
+            self.__dict__["_live_on"] = False
 
     def _sync_gravity(self):
         g = self.gravityc                                                   # instance attr, else the class attr
@@ -172,11 +175,34 @@ class Net:
 
     @torch.no_grad()
     def forward_online(self, j2dc, accc, oric, first_tran=None, first_frame=False):
-        """net/sig_mp.py:113-274: one body, one frame; returns CPU tensors like the reference (L274)."""
+        """net/sig_mp.py:113-274: one body, one frame; returns CPU tensors like the reference (L274).
+        With ``net.use_graph = True`` (live loops) the frame is one hipGraph replay incl. the host copies."""
         if self.batch != 1:
             raise ValueError("forward_online is the batch-1 call; use forward_batch")
+        if self.__dict__.get("use_graph"):
+            p, t = self.forward_live(j2dc, accc, oric, first_tran, first_frame)
+            return p[0], t[0]
         pose, tran = self.forward_batch(j2dc, accc, oric, first_tran, first_frame)
         return pose[0].cpu(), tran[0].cpu()
+
+    @torch.no_grad()
+    def forward_live(self, j2dc, accc, oric, first_tran=None, first_frame=False):
+        """Streaming step for all rows with HOST tensors in and out (live_server.py:40-48): one captured hipGraph
+        per frame (H2D + 17 kernels + D2H). Returns CPU tensors pose [B,24,3,3], tran [B,3]."""
+        B = self.batch
+        self._sync_gravity()
+        if not self.__dict__.get("_live_on"):
+            torch.cuda.synchronize()
+            _lib.check(self._ctx, self._lib.rc_live_begin(self._ctx), "rc_live_begin")
+            self.__dict__["_live_on"] = True
+        host = lambda t, shape: torch.as_tensor(t, dtype=torch.float32).cpu().reshape(shape).contiguous()
+        j2dc, accc, oric = host(j2dc, (B, 33, 3)), host(accc, (B, 6, 3)), host(oric, (B, 6, 3, 3))
+        ft = None if first_tran is None else host(first_tran, (B, 3))
+        pose, tran = torch.empty(B, 24, 3, 3), torch.empty(B, 3)
+        rc = self._lib.rc_live_step(self._ctx, _lib.ptr(j2dc), _lib.ptr(accc), _lib.ptr(oric), _lib.ptr(ft),
+                                    _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, _lib.ptr(pose), _lib.ptr(tran))
+        _lib.check(self._ctx, rc, "rc_live_step")
+        return pose, tran
 
     @torch.no_grad()
     def forward_sequence(self, j2dc, accc, oric, first_tran=None, first_frame=False):

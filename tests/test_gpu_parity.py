@@ -249,3 +249,26 @@ def test_error_behaviour(synth_assets):
         net.load_state_dict(bad)
     with pytest.raises(_lib.RobustcapLibraryError):
         Net(body=synth_assets["body"], batch=1, device="cpu")
+
+
+def test_live_graph_step_equals_eager(synth_assets):
+    """config 5: the hipGraph-captured frame (host tensors in/out) == the ordinary enqueue path, bitwise."""
+    from robustcap_amd import synth
+    T = 40
+    m = synth.make_motion(95, 1, T, synth_assets["body"], conf="mixed")
+    m["j2dc"][0, 10:25, :, 2] = 0.4                              # an occluded stretch: exercises the deferred updater
+    a, b = make_net(synth_assets, 1), make_net(synth_assets, 1)
+    a.gravityc = b.gravityc = t(m["gravityc"])
+    b.use_graph = True
+    for i in range(T):
+        args = (t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+        pa, ta = a.forward_online(*args, first_frame=(i == 0))
+        pb, tb = b.forward_online(*args, first_frame=(i == 0))
+        assert torch.equal(pa, pb) and torch.equal(ta, tb), i
+    b.use_flat_floor = False                                     # attribute poke re-captures the graph
+    a.use_flat_floor = False
+    for i in range(T - 5, T):
+        args = (t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+        pa, ta = a.forward_online(*args)
+        pb, tb = b.forward_online(*args)
+        assert torch.equal(pa, pb) and torch.equal(ta, tb)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: batch 1, 60 fps streaming, per-frame latency p50/p99 of forward_online (host tensors in,
+host tensors out): hipGraph-captured frame vs the ordinary enqueue path. Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from robustcap_amd import synth  # noqa: E402
+from robustcap_amd.net.sig_mp import Net  # noqa: E402
+
+
+def run(net, m, n):
+    t = torch.from_numpy
+    T = m["j2dc"].shape[1]
+    lat = np.empty(n)
+    for i in range(n):
+        k = i % T
+        args = (t(m["j2dc"][0, k]), t(m["accc"][0, k]), t(m["oric"][0, k]))
+        t0 = time.perf_counter()
+        net.forward_online(*args, first_frame=(i == 0))
+        lat[i] = time.perf_counter() - t0
+    return lat[50:] * 1e6
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    sd, body = synth.make_state_dict(0), synth.make_body(1)
+    m = synth.make_motion(7, 1, 600, body, conf="mixed")
+    out = {}
+    for mode in ("graph", "eager"):
+        net = Net(body=body, batch=1)
+        net.load_state_dict(sd)
+        net.gravityc = torch.from_numpy(m["gravityc"])
+        net.use_graph = mode == "graph"
+        lat = run(net, m, n)
+        out[mode] = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+                     "mean_us": round(float(lat.mean()), 1), "fps": round(1e6 / float(lat.mean()), 1)}
+    print(json.dumps({"metric": "forward_online latency, batch 1, host->host", "frames": n, "weights_MB": 243.06,
+                      "weight_stream_floor_us_at_6.3TBps": 38.6, **out}))
+
+
+if __name__ == "__main__":
+    main()
