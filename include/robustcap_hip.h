@@ -140,6 +140,14 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
 int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K,
                        float sigma, float* loss, int64_t T, void* stream);
 
+/* Harness input preparation of evaluate.py:38-51,70-73 for ONE (sequence, camera) of n frames:
+ *   j2dc = K^-1 [u, v, 1] with the confidence copied into the last channel, accc = R_cw acc_w, oric = R_cw ori_w,
+ *   gravity_out (HOST float[3]) = R_cw [0, -1, 0].
+ * kp_pix[n,33,3] = (u, v, conf) in pixels, imu_acc_w[n,6,3], imu_ori_w[n,6,3,3] DEVICE; K[3,3], Tcw[4,4] HOST. */
+int rc_camera_inputs(const float* kp_pix, const float* imu_acc_w, const float* imu_ori_w, const float* K_host,
+                     const float* Tcw_host, float* j2dc, float* accc, float* oric, float* gravity_out_host, int64_t n,
+                     void* stream);
+
 /* ---- state access (tests / checkpointing of a running sequence) ------------------------------------------ */
 /* Copy the (h, c) state of sub-net `net` to HOST buffers h[2,batch,H], c[2,batch,H]. Synchronises `stream`. */
 int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, void* stream);

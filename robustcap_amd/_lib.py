@@ -53,6 +53,7 @@ SIGNATURES = {
     "rc_body_fk": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),
     "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
+    "rc_camera_inputs": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "rc_get_state": (_I32, [_P, C.c_char_p, _P, _P, _P]),
     "rc_get_trace": (_I32, [_P, _P, _P]),
     "rc_gemm_timing": (_I32, [_P, _I32]),

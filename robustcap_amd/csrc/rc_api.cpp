@@ -675,6 +675,27 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
     return RC_OK;
 }
 
+int rc_camera_inputs(const float* kp, const float* acc, const float* ori, const float* K, const float* Tcw, float* j2dc,
+                     float* accc, float* oric, float* g_out, int64_t n, void* stream) {
+    if (!K || !Tcw || !g_out || n < 0) return RC_ERR_INVALID;
+    CamConst cam;
+    // K^-1 by the adjugate in double (the reference uses torch's float32 LU inverse, evaluate.py:34,70)
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (det == 0.0) return RC_ERR_INVALID;
+    const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                           (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                           (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    for (int q = 0; q < 9; ++q) cam.Kinv[q] = (float)inv[q];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) cam.R[3 * r + q] = Tcw[4 * r + q];
+    for (int r = 0; r < 3; ++r) g_out[r] = -cam.R[3 * r + 1];            // R_cw [0, -1, 0], evaluate.py:73
+    if (n == 0) return RC_OK;
+    if (!kp || !acc || !ori || !j2dc || !accc || !oric) return RC_ERR_INVALID;
+    rc_launch_camera_inputs(kp, acc, ori, cam, j2dc, accc, oric, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+
 int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, void* stream) {
     if (!ctx || !net || !h_host || !c_host) return RC_ERR_INVALID;
     const int ni = net_index(net);

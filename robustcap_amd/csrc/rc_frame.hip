@@ -652,6 +652,28 @@ __global__ void rc_R2aa_kernel(const float* Rm, float* aa, long long n) {
     aa[3 * i] = (float)o[0]; aa[3 * i + 1] = (float)o[1]; aa[3 * i + 2] = (float)o[2];
 }
 
+// evaluate.py:38-51,70-72: per-frame camera-frame inputs from pixel keypoints and world-frame IMU readings
+__global__ void rc_camera_inputs_kernel(const float* kp, const float* acc, const float* ori, CamConst cam, float* j2dc,
+                                        float* accc, float* oric, long long n) {
+    const long long f = blockIdx.x;
+    const int t = threadIdx.x;
+    if (t < 33) {
+        const float u = kp[(f * 33 + t) * 3], v = kp[(f * 33 + t) * 3 + 1], cf = kp[(f * 33 + t) * 3 + 2];
+        float* o = j2dc + (f * 33 + t) * 3;
+        o[0] = (cam.Kinv[0] * u + cam.Kinv[1] * v) + cam.Kinv[2];
+        o[1] = (cam.Kinv[3] * u + cam.Kinv[4] * v) + cam.Kinv[5];
+        o[2] = cf;
+    } else if (t < 33 + 18) {
+        const int e = t - 33, i = e / 3, r = e % 3;
+        const float* a = acc + (f * 6 + i) * 3;
+        accc[f * 18 + e] = (cam.R[3 * r] * a[0] + cam.R[3 * r + 1] * a[1]) + cam.R[3 * r + 2] * a[2];
+    } else if (t < 33 + 18 + 54) {
+        const int e = t - 51, i = e / 9, r = (e % 9) / 3, c = e % 3;
+        const float* o = ori + (f * 6 + i) * 9;
+        oric[f * 54 + e] = (cam.R[3 * r] * o[c] + cam.R[3 * r + 1] * o[3 + c]) + cam.R[3 * r + 2] * o[6 + c];
+    }
+}
+
 // smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
 // (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
 __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
@@ -726,6 +748,10 @@ void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, c
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(rc_r6d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r6d, R, n);
+}
+void rc_launch_camera_inputs(const float* kp, const float* acc, const float* ori, const CamConst& cam, float* j2dc, float* accc,
+                             float* oric, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_camera_inputs_kernel, dim3((unsigned)n), dim3(128), 0, st, kp, acc, ori, cam, j2dc, accc, oric, n);
 }
 void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t st) {
     hipLaunchKernelGGL(rc_aa2R_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, R, n);

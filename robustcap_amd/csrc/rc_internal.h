@@ -135,6 +135,9 @@ void rc_launch_flush_flags(const FrameBuffers& fb, int B, hipStream_t s);
 void rc_launch_pack_rows(const float* src, int src_ld, int cols, float* dst, int ld, int B, hipStream_t s);
 
 void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
+struct CamConst { float Kinv[9]; float R[9]; };
+void rc_launch_camera_inputs(const float* kp, const float* acc, const float* ori, const CamConst& cam, float* j2dc, float* accc,
+                             float* oric, long long n, hipStream_t s);
 void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t s);
 void rc_launch_R2aa(const float* R, float* aa, long long n, hipStream_t s);
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);

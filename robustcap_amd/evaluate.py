@@ -1,0 +1,133 @@
+"""Evaluation harness for the sig_mp path: the counterpart of the reference's ``evaluate_aist_ours`` loop
+(evaluate.py:20-117) with every (sequence, camera) a row of one batched, GPU-sharded run.
+
+  dataset layout  : the reference's preprocessed ``test.pt`` dict (preprocess.py:229-237) -- per sequence ``pose``
+                    [T,72], ``tran`` [T,3], ``imu_ori`` [T,6,3,3], ``imu_acc`` [T,6,3] in the world frame, per camera
+                    ``cam_K``, ``cam_T`` (T_cw), ``joint2d_mp`` [n_cam,T,33,3] normalised by the image size.
+                    ``robustcap_amd.synth.make_dataset`` generates the same layout (the real data is external).
+  input prep      : rc_camera_inputs kernel = evaluate.py:38-51,70-73 (K^-1 [u,v,1], R_cw IMU, gravity).
+  per-frame loop  : ``Net.forward_sequence`` -- all rows, all frames, one call (evaluate.py:75-83 is a Python loop).
+  sharding        : contiguous (sequence, camera) blocks per rank, one final all-gather (robustcap_amd.dist).
+  metrics         : root-position error (articulate/evaluator.py:100-129 semantics), root-aligned MPJPE over the 24
+                    SMPL joints and global joint-angle error. The reference's H36M-14 MPJPE / PVE / PA-MPJPE need
+                    the full 6890-vertex mesh and ``J_regressor_h36m.npy`` (absent): SURVEY.md section 8(f) rank 2.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import body as _body
+from . import dist as rdist
+from .net.sig_mp import Net
+
+
+def camera_inputs(kp_norm, imu_acc_w, imu_ori_w, K, Tcw, image_size=(1920, 1080), device="cuda"):
+    """evaluate.py:38-51 + 70-73 for one (sequence, camera). Returns device tensors j2dc [T,33,3], accc [T,6,3],
+    oric [T,6,3,3] and the host gravity vector [3]."""
+    dev = torch.device(device)
+    kp = torch.as_tensor(kp_norm, dtype=torch.float32).clone()
+    kp[..., 0] *= image_size[0]                                    # evaluate.py:43-44
+    kp[..., 1] *= image_size[1]
+    kp = kp.to(dev).contiguous()
+    T = kp.shape[0]
+    acc = torch.as_tensor(imu_acc_w, dtype=torch.float32).to(dev).contiguous()
+    ori = torch.as_tensor(imu_ori_w, dtype=torch.float32).to(dev).contiguous()
+    K = np.ascontiguousarray(np.asarray(K, np.float32).reshape(3, 3))
+    Tcw = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(4, 4))
+    j2dc = torch.empty(T, 33, 3, device=dev)
+    accc = torch.empty(T, 6, 3, device=dev)
+    oric = torch.empty(T, 6, 3, 3, device=dev)
+    g = np.zeros(3, np.float32)
+    lib = _lib.load()
+    rc = lib.rc_camera_inputs(_lib.ptr(kp), _lib.ptr(acc), _lib.ptr(ori), K.ctypes.data_as(C.c_void_p), Tcw.ctypes.data_as(C.c_void_p),
+                              _lib.ptr(j2dc), _lib.ptr(accc), _lib.ptr(oric), g.ctypes.data_as(C.c_void_p), T, _lib.stream_ptr())
+    _lib.check(None, rc, "rc_camera_inputs")
+    torch.cuda.current_stream().synchronize()
+    return j2dc, accc, oric, torch.from_numpy(g)
+
+
+def rows_of(dataset):
+    """[(sequence index, camera index)] in the reference's order (sequence-major, evaluate.py:32-33)."""
+    return [(i, j) for i in range(len(dataset["pose"])) for j in range(len(dataset["cam_K"][i]))]
+
+
+def labels(dataset, i, j, device="cuda"):
+    """camera-frame ground truth of row (i, j): pose [T,24,3,3] with the root rotated by R_cw, tran = T_cw [tran;1]
+    (evaluate.py:46-49)."""
+    Tcw = torch.as_tensor(dataset["cam_T"][i][j], dtype=torch.float32)
+    pose = _body.axis_angle_to_rotation_matrix(torch.as_tensor(dataset["pose"][i]).reshape(-1, 3), device).view(-1, 24, 3, 3).cpu()
+    pose[:, 0] = Tcw[:3, :3] @ pose[:, 0]
+    tran = torch.as_tensor(dataset["tran"][i], dtype=torch.float32) @ Tcw[:3, :3].T + Tcw[:3, 3]
+    return pose, tran
+
+
+def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda"):
+    """Run every (sequence, camera) row of ``dataset`` (or the given subset) through the net; rows are sharded over
+    the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU."""
+    all_rows = rows_of(dataset) if rows is None else list(rows)
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    a, b = rdist.shard_range(len(all_rows), rank, world)
+    mine = all_rows[a:b]
+    Tmax = max(len(dataset["pose"][i]) for i, _ in all_rows)
+    n = len(mine)
+    pose_all = torch.zeros(len(all_rows) if world > 1 else n, Tmax, 216)
+    out_p = torch.zeros(max(n, 1), Tmax, 24, 3, 3, device=device)
+    out_t = torch.zeros(max(n, 1), Tmax, 3, device=device)
+    if n:
+        j2d = torch.zeros(n, Tmax, 33, 3, device=device)
+        acc = torch.zeros(n, Tmax, 6, 3, device=device)
+        ori = torch.eye(3, device=device).repeat(n, Tmax, 6, 1, 1)      # padding frames: identity orientations
+        grav, ft = torch.zeros(n, 3), torch.zeros(n, 3)
+        for r, (i, j) in enumerate(mine):
+            T = len(dataset["pose"][i])
+            k, ac, orc, g = camera_inputs(dataset["joint2d_mp"][i][j], dataset["imu_acc"][i], dataset["imu_ori"][i],
+                                          dataset["cam_K"][i][j], dataset["cam_T"][i][j], device=device)
+            j2d[r, :T], acc[r, :T], ori[r, :T], grav[r] = k, ac, orc, g
+            ft[r] = labels(dataset, i, j, device)[1][0]                    # first_tran = label translation of frame 0
+        net = Net(body=body, batch=n, device=device)
+        net.load_state_dict(state_dict)
+        net.use_flat_floor = use_flat_floor
+        net.gravityc = grav
+        out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)
+    del pose_all
+    if world > 1:                                                       # the path's only collective
+        cap_p = rdist.gather_rows(out_p[:n].reshape(n, -1), len(all_rows))
+        cap_t = rdist.gather_rows(out_t[:n].reshape(n, -1), len(all_rows))
+        out_p, out_t, rows_out = cap_p.view(-1, Tmax, 24, 3, 3), cap_t.view(-1, Tmax, 3), all_rows
+    else:
+        rows_out = mine
+    res = {}
+    for r, (i, j) in enumerate(rows_out):
+        T = len(dataset["pose"][i])
+        res[(i, j)] = (out_p[r, :T].cpu(), out_t[r, :T].cpu())
+    return res
+
+
+def joint_errors(model, pose_p, tran_p, pose_t, tran_t):
+    """dict of per-sequence means: root-aligned MPJPE over the 24 SMPL joints (m), absolute root position error (m)
+    and global joint rotation error (degrees, float64 atan2 form). ``model`` = robustcap_amd.body.ParametricModel."""
+    gp, jp = model.forward_kinematics(pose_p, tran=tran_p)
+    gt, jt = model.forward_kinematics(pose_t, tran=tran_t)
+    rel_p, rel_t = jp - jp[:, :1], jt - jt[:, :1]
+    mpjpe = (rel_p - rel_t).norm(dim=2).mean()
+    root = (jp[:, 0] - jt[:, 0]).norm(dim=1).mean()
+    D = (gp.double().transpose(-1, -2) @ gt.double()).reshape(-1, 3, 3)
+    v = torch.stack((D[:, 2, 1] - D[:, 1, 2], D[:, 0, 2] - D[:, 2, 0], D[:, 1, 0] - D[:, 0, 1]), dim=1) * 0.5
+    ang = torch.rad2deg(torch.atan2(v.norm(dim=1), (D[:, 0, 0] + D[:, 1, 1] + D[:, 2, 2] - 1) * 0.5)).mean()
+    return {"mpjpe_smpl24_m": float(mpjpe), "root_error_m": float(root), "global_angle_deg": float(ang)}
+
+
+def evaluate(dataset, state_dict, body, device="cuda", **kw):
+    """Full loop: run all rows, return per-row metrics and their mean (rank-local when not distributed)."""
+    res = run_dataset(dataset, state_dict, body, device=device, **kw)
+    model = _body.ParametricModel(body=body, device=device)
+    per_row = {}
+    for (i, j), (pose, tran) in res.items():
+        pt, tt = labels(dataset, i, j, device)
+        per_row[(i, j)] = joint_errors(model, pose, tran, pt, tt)
+    keys = next(iter(per_row.values())).keys() if per_row else []
+    mean = {k: float(np.mean([m[k] for m in per_row.values()])) for k in keys}
+    return per_row, mean

@@ -253,3 +253,58 @@ def make_motion(seed, B, T, body, conf="mixed", noise=0.003):
         out["tran"].append(tr)
         out["conf"].append(ck.mean(1))
     return {k: np.stack(v).astype(np.float32) for k, v in out.items()}
+
+
+# ----------------------------------------------------------------------------------------------------- dataset
+def _log_map(R):
+    """[...,3,3] rotation matrices -> axis-angle [...,3] (float64, angle < pi)."""
+    v = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1) * 0.5
+    s = np.linalg.norm(v, axis=-1)
+    c = (np.trace(R, axis1=-2, axis2=-1) - 1) * 0.5
+    th = np.arctan2(s, c)
+    k = np.where(s > 1e-12, th / np.where(s > 1e-12, s, 1.0), 1.0)
+    return v * k[..., None]
+
+
+def make_dataset(seed, n_seq, T, body, n_cam=3, conf="mixed", image_size=(1920, 1080)):
+    """Synthetic multi-camera dataset in the layout of the reference's preprocessed ``test.pt``
+    (preprocess.py:229-237, read by evaluate.py:24-52): per sequence world-frame ``pose`` [T,72] axis-angle,
+    ``tran`` [T,3], ``imu_ori`` [T,6,3,3], ``imu_acc`` [T,6,3]; per camera ``cam_K`` [n_cam,3,3], ``cam_T`` [n_cam,4,4]
+    (T_cw) and ``joint2d_mp`` [n_cam,T,33,3] = (u / width, v / height, confidence)."""
+    W, H = image_size
+    ds = {k: [] for k in ("name", "pose", "tran", "imu_ori", "imu_acc", "cam_K", "cam_T", "joint2d_mp")}
+    ids = list(C.mp_mask)
+    for i in range(n_seq):
+        m = make_motion(seed * 131 + i, 1, T, body, conf=conf)          # camera-0 frame == world frame here
+        R = m["pose"][0].astype(np.float64)
+        tr = m["tran"][0].astype(np.float64)
+        G, joint, vert = body_fk_numpy(body, R, tr, ids)
+        v33 = vert.copy()
+        for row, j in C.mp_joint_override.items():
+            v33[:, row] = joint[:, j]
+        Ks, Ts, kps = [], [], []
+        for c in range(n_cam):
+            u = uniform01(seed * 977 + i, 50 + c, 8).astype(np.float64)
+            yaw = 0.0 if c == 0 else 0.5 * (u[0] - 0.5)
+            Rcw = np.eye(3) if c == 0 else _rodrigues(np.array([0.05 * (u[1] - 0.5), yaw, 0.03 * (u[2] - 0.5)]))
+            centre = tr.mean(0)
+            t = np.zeros(3) if c == 0 else centre - Rcw @ centre + np.array([0.4 * (u[3] - 0.5), 0.2 * (u[4] - 0.5), 0.6 * u[5]])
+            Tcw = np.eye(4)
+            Tcw[:3, :3], Tcw[:3, 3] = Rcw, t
+            f = 1400.0 + 200.0 * u[6]
+            K = np.array([[f, 0.0, W / 2 + 20 * (u[7] - 0.5)], [0.0, f * 1.002, H / 2], [0.0, 0.0, 1.0]])
+            Xc = v33 @ Rcw.T + t
+            uv = (Xc / Xc[..., 2:]) @ K.T
+            conf_c = m["j2dc"][0][..., 2].astype(np.float64)
+            noise = 2.0 * (1 - conf_c)[..., None] * normal(seed * 31 + i, 80 + c, T * 66).reshape(T, 33, 2)
+            kp = np.concatenate([(uv[..., :2] + noise) / np.array([W, H]), conf_c[..., None]], -1)
+            Ks.append(K), Ts.append(Tcw), kps.append(kp)
+        ds["name"].append(f"synth_seq{i:03d}_cAll")
+        ds["pose"].append(_log_map(R).reshape(T, 72).astype(np.float32))
+        ds["tran"].append(tr.astype(np.float32))
+        ds["imu_ori"].append(m["oric"][0])
+        ds["imu_acc"].append(m["accc"][0])
+        ds["cam_K"].append(np.stack(Ks).astype(np.float32))
+        ds["cam_T"].append(np.stack(Ts).astype(np.float32))
+        ds["joint2d_mp"].append(np.stack(kps).astype(np.float32))
+    return ds

@@ -1,0 +1,55 @@
+"""Harness (evaluate.py counterpart): camera input prep kernel, row batching of (sequence, camera), metrics."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+t = torch.from_numpy
+
+
+def test_camera_inputs_match_reference_formulas(synth_assets):
+    from robustcap_amd import synth
+    from robustcap_amd.evaluate import camera_inputs
+    ds = synth.make_dataset(5, 1, 16, synth_assets["body"], n_cam=2)
+    K, Tcw = t(ds["cam_K"][0][1]), t(ds["cam_T"][0][1])
+    j2dc, accc, oric, g = camera_inputs(ds["joint2d_mp"][0][1], ds["imu_acc"][0], ds["imu_ori"][0], K, Tcw)
+    kp = t(ds["joint2d_mp"][0][1]).clone()
+    kp[..., 0] *= 1920
+    kp[..., 1] *= 1080
+    ones = torch.cat((kp[..., :2], torch.ones_like(kp[..., :1])), -1)
+    ref = (K.inverse() @ ones.unsqueeze(-1)).squeeze(-1)                           # evaluate.py:70-71
+    ref[..., -1] = kp[..., -1]                                                      # evaluate.py:72
+    assert float((j2dc.cpu() - ref).abs().max()) <= 2e-6
+    assert float((oric.cpu() - Tcw[:3, :3] @ t(ds["imu_ori"][0])).abs().max()) <= 1e-6        # evaluate.py:38
+    assert float((accc.cpu() - t(ds["imu_acc"][0]) @ Tcw[:3, :3].T).abs().max()) <= 1e-5      # evaluate.py:39
+    assert float((g - Tcw[:3, :3] @ torch.tensor([0.0, -1.0, 0.0])).abs().max()) <= 1e-7      # evaluate.py:73
+
+
+def test_run_dataset_rows_equal_direct_runs_and_metrics(synth_assets):
+    from robustcap_amd import synth
+    from robustcap_amd import evaluate as ev
+    from robustcap_amd.body import ParametricModel
+    from robustcap_amd.net.sig_mp import Net
+    body, sd = synth_assets["body"], synth_assets["state_dict"]
+    ds = synth.make_dataset(6, 2, 40, body, n_cam=2)
+    ds["pose"][1], ds["tran"][1] = ds["pose"][1][:30], ds["tran"][1][:30]          # ragged: sequence 1 is shorter
+    ds["imu_ori"][1], ds["imu_acc"][1] = ds["imu_ori"][1][:30], ds["imu_acc"][1][:30]
+    ds["joint2d_mp"][1] = ds["joint2d_mp"][1][:, :30]
+    res = ev.run_dataset(ds, sd, body)
+    assert sorted(res) == [(0, 0), (0, 1), (1, 0), (1, 1)] and res[(1, 1)][0].shape == (30, 24, 3, 3)
+    for (i, j) in ((0, 1), (1, 0)):                                                # one row run alone, like evaluate.py's loop
+        k, a, o, g = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])
+        net = Net(body=body, batch=1)
+        net.load_state_dict(sd)
+        net.gravityc = g
+        ft = ev.labels(ds, i, j)[1][0]
+        p, tr = net.forward_sequence(k[None], a[None], o[None], first_tran=ft[None])
+        assert torch.equal(p[0].cpu(), res[(i, j)][0]) and torch.equal(tr[0].cpu(), res[(i, j)][1])
+    model = ParametricModel(body=body)
+    pt, tt = ev.labels(ds, 0, 0)
+    z = ev.joint_errors(model, pt, tt, pt, tt)
+    assert z["mpjpe_smpl24_m"] == 0.0 and z["root_error_m"] == 0.0 and z["global_angle_deg"] < 1e-3
+    shifted = ev.joint_errors(model, pt, tt + torch.tensor([0.1, 0.0, 0.0]), pt, tt)
+    assert abs(shifted["root_error_m"] - 0.1) < 1e-5 and shifted["mpjpe_smpl24_m"] < 1e-5
+    per_row, mean = ev.evaluate(ds, sd, body)
+    assert len(per_row) == 4 and np.isfinite(list(mean.values())).all()

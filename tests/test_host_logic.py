@@ -56,3 +56,17 @@ def test_shard_range_partitions_rows(n, world):
     assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     with pytest.raises(ValueError):
         rdist.shard_range(4, 2, 2)
+
+
+def test_dataset_layout_matches_reference_test_pt():
+    body = synth.make_body(1)
+    ds = synth.make_dataset(3, 2, 24, body, n_cam=3)
+    assert set(ds) >= {"name", "pose", "tran", "imu_ori", "imu_acc", "cam_K", "cam_T", "joint2d_mp"}   # preprocess.py:229-237
+    assert ds["pose"][0].shape == (24, 72) and ds["tran"][0].shape == (24, 3)
+    assert ds["imu_ori"][0].shape == (24, 6, 3, 3) and ds["imu_acc"][0].shape == (24, 6, 3)
+    assert ds["cam_K"][0].shape == (3, 3, 3) and ds["cam_T"][0].shape == (3, 4, 4) and ds["joint2d_mp"][0].shape == (3, 24, 33, 3)
+    uv = ds["joint2d_mp"][0][..., :2]
+    assert 0.0 < np.median(uv) < 1.0                                              # normalised image coordinates
+    assert np.allclose(ds["cam_T"][0][0], np.eye(4))                               # camera 0 frame == world frame
+    R = synth._rodrigues(ds["pose"][0].reshape(-1, 3).astype(np.float64))
+    assert np.allclose(synth._log_map(R), ds["pose"][0].reshape(-1, 3), atol=1e-5)
