@@ -44,6 +44,7 @@ struct NetDev {
     float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
     int in = 0, H = 0, out = 0;
     int nc = 4;                          // 16-column blocks per LSTM tile (4*nc hidden units x 4 gates)
+    int mr = 2;                          // 16-row blocks per LSTM tile
 };
 
 }  // namespace
@@ -161,7 +162,7 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nc = 4;
+    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nc = 4; p.mr = 2;
     return p;
 }
 
@@ -191,7 +192,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = s.flags ? s.flags : c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
-    p.n_tiles = n.H / (4 * n.nc); p.m_tiles = (c->B + RC_MT - 1) / RC_MT; p.Kp = 2 * n.H; p.nc = n.nc;
+    p.n_tiles = n.H / (4 * n.nc); p.m_tiles = (c->B + 16 * n.mr - 1) / (16 * n.mr); p.Kp = 2 * n.H; p.nc = n.nc; p.mr = n.mr;
     return p;
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
@@ -359,7 +360,11 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     for (int i = 0; i < 6 && !rc; ++i) {
         NetDev& n = ctx->net[i];
         n.in = kNets[i].in; n.H = kNets[i].H; n.out = kNets[i].out;
-        n.nc = n.H == 1280 ? 10 : (n.H == 1024 ? 8 : 4);     // 256 tiles per layer at batch 256 for every net
+        // tile shape per net (see rc_gemm.hip): 32 rows x 16/32/40 units = 256 tiles per layer at batch 256. The
+        // 64-row shapes (4 x 5, 4 x 4) load 20-25 % fewer operand bytes but measured no faster (63.2 vs 64.8 us for an
+        // rnn4 layer) and coarsen the row compaction of masked stages (bench 535k vs 573k body-frames/s): not used.
+        n.mr = 2;
+        n.nc = n.H == 1280 ? 10 : (n.H == 1024 ? 8 : 4);
         A(n.h, 4 * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
     }
     A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);

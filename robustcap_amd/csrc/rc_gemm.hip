@@ -28,30 +28,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int NC>
-struct Frag {                 // one chunk (16 k): a float4 per lane for each of the 2 row blocks and NC column blocks
-    f32x4 a[2];
+template <int MR, int NC>
+struct Frag {                 // one chunk (16 k): a float4 per lane for each of the MR row blocks and NC column blocks
+    f32x4 a[MR];
     f32x4 b[NC];
 };
 
-template <int NC>
-__device__ __forceinline__ void load_chunk(Frag<NC>& f, const float* pa, long long astride, const float* pb, long long bstride) {
+template <int MR, int NC>
+__device__ __forceinline__ void load_chunk(Frag<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const float* pb,
+                                           long long bstride) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[r] = *reinterpret_cast<const f32x4*>(pa + r * astride);
+    for (int r = 0; r < MR; ++r)
+        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
 #pragma unroll
     for (int j = 0; j < NC; ++j)
         if (!(RC_ABLATE & 2) || RC_ABLATE == 4) f.b[j] = *reinterpret_cast<const f32x4*>(pb + j * bstride);
 }
 
-template <int NC>
-__device__ __forceinline__ void mma_chunk(const Frag<NC>& f, f32x4 (&acc)[2][NC]) {
+template <int MR, int NC>
+__device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR][NC]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < MR; ++r) {
 #if RC_ABLATE == 4
                 acc[r][j][s] += f.a[r][s] + f.b[j][s];
 #else
@@ -62,35 +63,36 @@ __device__ __forceinline__ void mma_chunk(const Frag<NC>& f, f32x4 (&acc)[2][NC]
     }
 }
 
-// One workgroup = one 32-row x (16*NC)-column tile, K split over the RC_NW waves.
-//   NC = 4 : 16 hidden units x 4 gates (H = 512 nets, dense layers)     384 B of operands per 4096 MFMA-FLOP
-//   NC = 8 : 32 units (rnn6, H = 1024)                                  320 B
-//   NC = 10: 40 units (rnn4, H = 1280)                                  307 B
-// so that every LSTM layer of every net is exactly 256 workgroups at batch 256 (one per CU) and the big nets
-// load fewer bytes per FLOP: measured on MI355X, a CU delivers ~256 B of operands per 64 MFMA cycles while the
-// matrix pipe is busy, which caps a 32x64 tile at 67 % MFMA utilisation (profiles/r01_gemm_probe.txt).
+// One workgroup = one (16*MR)-row x (16*NC)-column tile, K split over the RC_NW waves. Tile shapes are chosen so that
+// every LSTM layer of every net is exactly 256 workgroups at batch 256 (one per CU), with as few operand bytes per
+// MFMA as the register file allows -- measured on MI355X, a CU delivers only ~256 B of operands per 64 MFMA cycles
+// while the matrix pipe is busy (profiles/r01_gemm_probe.txt):
+//   MR x NC = 4 x 5 : 64 rows x 20 units (rnn4, H = 1280)    (4 + 5) KiB per 80 MFMAs  = 230 B per 64 cycles
+//             4 x 4 : 64 rows x 16 units (rnn6, H = 1024)    (4 + 4) KiB per 64 MFMAs  = 256 B
+//             2 x 4 : 32 rows x 16 units (H = 512, dense)    (2 + 4) KiB per 32 MFMAs  = 384 B
+//             2 x 8 / 2 x 10: 32-row variants of the big nets for small batches (more row tiles than 64-row ones)
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int NC, bool PIPE>
+template <int MR, int NC, bool PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile, const int n_tile, float* s_mem) {
-    constexpr int NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
-    int* s_rows = reinterpret_cast<int*>(s_mem);                   // [RC_MT]
-    int* s_cnt = s_rows + RC_MT;                                    // [RC_NW] (+ padding to 64 ints)
-    float* s_part = s_mem + 64;                                     // [RC_NW][RC_MT][LD]
+    constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
+    int* s_rows = reinterpret_cast<int*>(s_mem);                   // [MT <= 64]
+    int* s_cnt = s_rows + 64;                                       // [RC_NW] (+ padding to 128 ints)
+    float* s_part = s_mem + 128;                                    // [RC_NW][MT][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- active rows of this tile -------------------------------------------------------------------------
-    const int lo = m_tile * RC_MT;
+    const int lo = m_tile * MT;
     int nrows;
     if (P.flag_bit == 0) {
-        nrows = min(RC_MT, B - lo);
+        nrows = min(MT, B - lo);
         if (nrows <= 0) return;
-        if (tid < RC_MT) s_rows[tid] = lo + min(tid, nrows - 1);
+        if (tid < MT) s_rows[tid] = lo + min(tid, nrows - 1);
         __syncthreads();
     } else {
         int total = 0;
-        for (int base = 0; base < B && total < lo + RC_MT; base += RC_NW * 64) {
+        for (int base = 0; base < B && total < lo + MT; base += RC_NW * 64) {
             const int r = base + tid;
             const bool f = r < B && (P.flags[r] & P.flag_bit);
             const unsigned long long bal = __ballot(f);
@@ -104,91 +106,92 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
                 sum += cw;
             }
             const int idx = total + woff + __popcll(bal & ((1ull << lane) - 1ull));
-            if (f && idx >= lo && idx < lo + RC_MT) s_rows[idx - lo] = r;
+            if (f && idx >= lo && idx < lo + MT) s_rows[idx - lo] = r;
             total += sum;
             __syncthreads();
         }
-        nrows = min(RC_MT, total - lo);
+        nrows = min(MT, total - lo);
         if (nrows <= 0) return;
-        if (tid < RC_MT && tid >= nrows) s_rows[tid] = s_rows[0];
+        if (tid < MT && tid >= nrows) s_rows[tid] = s_rows[0];
         __syncthreads();
     }
     if (P.open_step && n_tile == 0 && tid < nrows) P.steps[s_rows[tid]] += 1;
 
     // ---- K loop: wave `wave` owns chunks [wave*Qw, (wave+1)*Qw) -------------------------------------------
     const int i = lane & 15, kq = lane >> 4;
-    // per-lane A pointers of the two 16-row blocks (rows may come from anywhere in the batch after compaction)
-    const float* pa_seg[2][2];
+    // per-lane A pointers of the MR 16-row blocks (rows may come from anywhere in the batch after compaction)
+    const float* pa0[MR];
+    const float* pa1[MR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MR; ++r) {
         const int row = s_rows[16 * r + i];
         const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] : 0;
+        const float* pp[2];
 #pragma unroll
         for (int sgi = 0; sgi < 2; ++sgi) {
             const GemmSeg& sg = P.seg[sgi];
             const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
             const float* base = sg.base;
             if (sgi == 0 && P.sel_bit && !(P.sel_flags[row] & P.sel_bit)) base = P.alt_base;
-            pa_seg[sgi][r] = base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
+            pp[sgi] = base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
         }
+        pa0[r] = pp[0];
+        pa1[r] = pp[1];
     }
     const int Q = P.Kp / RC_KC, Qw = Q / RC_NW;                     // chunks per wave: even (K' % 128 == 0)
     const int K0 = P.seg[0].K;
     const long long bstride = (long long)Q * 256;                   // floats between consecutive 16-column blocks
     const float* pb = P.W + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
     const int kbase = wave * Qw * RC_KC;
-    // block 1's pointer as an offset from block 0's (same segment, same k): one base pointer per chunk
-    const long long ad0 = pa_seg[0][1] - pa_seg[0][0], ad1 = pa_seg[1][1] - pa_seg[1][0];
 
-    f32x4 acc[2][NC];
+    f32x4 acc[MR][NC];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MR; ++r)
 #pragma unroll
         for (int j = 0; j < NC; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define LOADC(F, QI)                                                                                      \
     do {                                                                                                  \
         const int k_ = kbase + (QI) * RC_KC;                                                              \
-        const bool s0_ = k_ < K0;                                                                         \
-        load_chunk<NC>(F, s0_ ? pa_seg[0][0] + k_ * 16 : pa_seg[1][0] + (k_ - K0) * 16, s0_ ? ad0 : ad1,  \
-                       pb + (long long)(QI) * 256, bstride);                                              \
+        if (k_ < K0) load_chunk<MR, NC>(F, pa0, (long long)k_ * 16, pb + (long long)(QI) * 256, bstride);  \
+        else load_chunk<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pb + (long long)(QI) * 256, bstride);   \
     } while (0)
 #define SB() do { if (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
-    // The steady-state loop has NO conditionals: with a conditional prefetch hipcc (ROCm 7.2) waits vmcnt(0) in
-    // front of the MFMAs and round-trips the accumulators through VGPRs every iteration.
-    Frag<NC> fa = {}, fb = {};
+    // The steady-state loop has NO conditionals on the load path other than the wave-uniform segment select: with a
+    // conditional prefetch hipcc (ROCm 7.2) waits vmcnt(0) in front of the MFMAs.
+    Frag<MR, NC> fa = {}, fb = {};
     int q = 0;
     LOADC(fa, 0);
     for (; q + 2 < Qw; q += 2) {
         LOADC(fb, q + 1);
         SB();
-        mma_chunk<NC>(fa, acc);
+        mma_chunk<MR, NC>(fa, acc);
         SB();
         LOADC(fa, q + 2);
         SB();
-        mma_chunk<NC>(fb, acc);
+        mma_chunk<MR, NC>(fb, acc);
         SB();
     }
     LOADC(fb, q + 1);
     SB();
-    mma_chunk<NC>(fa, acc);
+    mma_chunk<MR, NC>(fa, acc);
     SB();
-    mma_chunk<NC>(fb, acc);
+    mma_chunk<MR, NC>(fb, acc);
 #undef LOADC
 #undef SB
 
     // ---- split-K reduction through LDS (C layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg) --------
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MR; ++r)
 #pragma unroll
         for (int j = 0; j < NC; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                s_part[(wave * RC_MT + 16 * r + 4 * kq + e) * LD + 16 * j + i] = acc[r][j][e];
+                s_part[(wave * MT + 16 * r + 4 * kq + e) * LD + 16 * j + i] = acc[r][j][e];
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
         // item -> (row rr, unit u); columns of a tile are [i(UT) | f(UT) | g(UT) | o(UT)]
-        for (int item = tid; item < RC_MT * UT; item += RC_NW * 64) {
+        for (int item = tid; item < MT * UT; item += RC_NW * 64) {
             const int rr = item / UT, u = item - rr * UT;
             if (rr >= nrows) continue;
             const int unit = n_tile * UT + u;
@@ -198,7 +201,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
                 const int col = gq * UT + u;
                 float v = s_part[rr * LD + col];
 #pragma unroll
-                for (int w = 1; w < RC_NW; ++w) v += s_part[(w * RC_MT + rr) * LD + col];
+                for (int w = 1; w < RC_NW; ++w) v += s_part[(w * MT + rr) * LD + col];
                 gsum[gq] = v + P.bias[n_tile * NT + col];
             }
             const int r2 = s_rows[rr];
@@ -211,13 +214,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf(cn);
         }
     } else {
-        for (int item = tid; item < RC_MT * NT; item += RC_NW * 64) {
+        for (int item = tid; item < MT * NT; item += RC_NW * 64) {
             const int rr = item / NT, col = item - rr * NT;
             if (rr >= nrows) continue;
             const int n = n_tile * NT + col;
             float v = s_part[rr * LD + col];
 #pragma unroll
-            for (int w = 1; w < RC_NW; ++w) v += s_part[(w * RC_MT + rr) * LD + col];
+            for (int w = 1; w < RC_NW; ++w) v += s_part[(w * MT + rr) * LD + col];
             v += P.bias[n];
             if (P.epi == RC_EPI_RELU) v = fmaxf(v, 0.0f);
             const int r2 = s_rows[rr];
@@ -228,10 +231,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     }
 }
 
-// LDS is sized > 80 KB on purpose: ONE workgroup per CU. Two co-resident workgroups contend for the CU's operand
-// delivery path and run slower than back to back (probe: 512 tiles of H=512 take 33.9 us co-resident vs 28.2 us
-// serial; bench 373k vs 511k body-frames/s), profiles/r01_gemm_probe.txt.
-#define RC_LDS_FLOATS (64 + RC_NW * RC_MT * (16 * 10 + LDS_PAD))   // 90 KB
+#define RC_LDS_FLOATS (128 + RC_NW * 64 * (16 * 5 + LDS_PAD))   // 98 KB = the 4 x 5 tile; 2 x 10 needs 90 KB
 
 #ifndef RC_WPS
 #define RC_WPS 1   // waves per SIMD the register allocation must allow
@@ -254,10 +254,12 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
         n_tile = local / P.m_tiles;
     }
     if (n_tile >= P.n_tiles) return;
-    switch (P.nc) {
-        case 10: gemm_tile<10, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 8: gemm_tile<8, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        default: gemm_tile<4, true>(P, L.B, m_tile, n_tile, s_mem); break;
+    switch (P.mr * 16 + P.nc) {
+        case 4 * 16 + 5: gemm_tile<4, 5, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 4: gemm_tile<4, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 10: gemm_tile<2, 10, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 8: gemm_tile<2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        default: gemm_tile<2, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
 

@@ -7,7 +7,7 @@
 // One workgroup = RC_NW waves = one 32-row x (16*NC)-column output tile; the K range is split across the waves
 // (in-workgroup split-K) and reduced through LDS. Each wave runs v_mfma_f32_16x16x4_f32 on 2 row blocks x NC
 // column blocks (A: lane l = row l&15, k-quarter l>>4; B: k-quarter l>>4, column l&15).
-#define RC_MT 32          // rows per workgroup tile (2 MFMA row blocks)
+#define RC_MT 32          // rows per workgroup tile of dense layers (2 MFMA row blocks); LSTM tiles: 16 * mr
 #define RC_NT 64          // columns per workgroup tile of dense layers (NC = 4 blocks of 16)
 #define RC_NW 4           // waves per workgroup (K split)
 #define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
@@ -69,8 +69,8 @@ struct GemmProblem {
     int epi;                // RC_EPI_*
     int open_step;          // linear1 opens a step: the n_tile 0 workgroup increments steps[row]
     int n_tiles, m_tiles, wg_base, Kp;
-    int nc;                 // 16-column blocks per tile: 4 (dense, H = 512), 8 (H = 1024), 10 (H = 1280)
-    int pad_;
+    int nc;                 // 16-column blocks per tile
+    int mr;                 // 16-row blocks per tile (2 or 4); (mr, nc) must be one of the instantiated shapes
 };
 
 struct GemmLaunch {

@@ -8,7 +8,8 @@
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 1280, iters = 20;
-    const int NBv = argc > 3 ? atoi(argv[3]) : (H == 1280 ? 10 : (H == 1024 ? 8 : 4));
+    const int NBv = argc > 3 ? atoi(argv[3]) : (H == 1280 ? 5 : 4);
+    const int MRv = argc > 4 ? atoi(argv[4]) : (H >= 1024 ? 4 : 2);
     const long long BH = (long long)B * H;
     float *x1, *h, *c, *W, *bias; int* steps;
     hipMalloc(&x1, BH * 4); hipMalloc(&h, 2 * BH * 4); hipMalloc(&c, BH * 4);
@@ -29,7 +30,7 @@ int main(int argc, char** argv) {
     p.seg[0] = {x1, 0, H, H, RC_PAR_NONE, 0};
     p.seg[1] = {h, BH, H, H, RC_PAR_SRC, 0};
     p.W = W; p.bias = bias; p.hstate = h; p.cstate = c; p.h_par_stride = BH; p.H = H; p.steps = steps;
-    p.flag_bit = 0; p.epi = RC_EPI_LSTM; p.n_tiles = H / (4 * NBv); p.nc = NBv; p.m_tiles = (B + RC_MT - 1) / RC_MT; p.Kp = 2 * H; p.wg_base = 0;
+    p.flag_bit = 0; p.epi = RC_EPI_LSTM; p.n_tiles = H / (4 * NBv); p.nc = NBv; p.mr = MRv; p.m_tiles = (B + 16 * MRv - 1) / (16 * MRv); p.Kp = 2 * H; p.wg_base = 0;
     const int wgs = p.n_tiles * p.m_tiles;
     int occ = -1; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rc_gemm_kernel, RC_NW * 64, 0);
     hipFuncAttributes fa_; hipFuncGetAttributes(&fa_, (const void*)rc_gemm_kernel);
@@ -42,7 +43,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, flop = 2.0 * B * (2.0 * H) * (4.0 * H);
-    printf("ablate=%d nc=%d B=%d H=%d wgs=%d  %.1f us/launch  %.1f TFLOP/s  weights %.1f MB -> %.2f TB/s\n", RC_ABLATE, NBv, B, H, wgs, us,
+    printf("ablate=%d mr=%d nc=%d B=%d H=%d wgs=%d  %.1f us/launch  %.1f TFLOP/s  weights %.1f MB -> %.2f TB/s\n", RC_ABLATE, MRv, NBv, B, H, wgs, us,
            flop / us * 1e-6, 4.0 * H * 2 * H * 4e-6, 4.0 * H * 2 * H * 4 / us * 1e-6);
     return 0;
 }
