@@ -33,6 +33,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct Dense {       // packed dense layer
     float* W = nullptr; float* b = nullptr;
     int K = 0, N = 0, Kp = 0, Np = 0;
+    int mr = 2, nc = 4;                  // tile shape: 16*mr rows x 16*nc columns
 };
 struct NetDev {
     Dense lin1, lin2;
@@ -124,7 +125,9 @@ int upload(rc_ctx* ctx, float** dst, const std::vector<float>& v) {
 }
 
 int make_dense(rc_ctx* ctx, Dense& d, const std::vector<float>& W, const std::vector<float>& b, int N, int K) {
-    d.N = N; d.K = K; d.Kp = round_up(K, RC_KALIGN); d.Np = round_up(N, RC_NT);
+    // narrow outputs (linear2: N = 2..144) use 16 x 32 tiles, wide ones (linear1, init_net) 32 x 64
+    d.mr = N <= 160 ? 1 : 2; d.nc = N <= 160 ? 2 : 4;
+    d.N = N; d.K = K; d.Kp = round_up(K, RC_KALIGN); d.Np = round_up(N, 16 * d.nc);
     auto get = [&](int n, int k) -> float { return (n < N && k < K) ? W[(size_t)n * K + k] : 0.0f; };
     std::vector<float> bp(d.Np, 0.0f);
     for (int n = 0; n < N; ++n) bp[n] = b[n];
@@ -162,7 +165,7 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    p.n_tiles = d.Np / RC_NT; p.m_tiles = (ctx->B + RC_MT - 1) / RC_MT; p.Kp = d.Kp; p.nc = 4; p.mr = 2;
+    p.n_tiles = d.Np / (16 * d.nc); p.m_tiles = (ctx->B + 16 * d.mr - 1) / (16 * d.mr); p.Kp = d.Kp; p.nc = d.nc; p.mr = d.mr;
     return p;
 }
 

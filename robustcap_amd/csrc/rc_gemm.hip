@@ -70,7 +70,9 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 //   MR x NC = 4 x 5 : 64 rows x 20 units (rnn4, H = 1280)    (4 + 5) KiB per 80 MFMAs  = 230 B per 64 cycles
 //             4 x 4 : 64 rows x 16 units (rnn6, H = 1024)    (4 + 4) KiB per 64 MFMAs  = 256 B
 //             2 x 4 : 32 rows x 16 units (H = 512, dense)    (2 + 4) KiB per 32 MFMAs  = 384 B
-//             2 x 8 / 2 x 10: 32-row variants of the big nets for small batches (more row tiles than 64-row ones)
+//             2 x 8 / 2 x 10: 32-row variants of the big nets (the ones in use: see rc_api.cpp)
+//             1 x 2 : 16 rows x 32 columns for linear2 (N = 2..144): 3x the workgroups of a 32 x 64 tile -- these
+//                     launches are parallelism-starved (16-48 workgroups), not bandwidth- or latency-bound
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
         case 4 * 16 + 4: gemm_tile<4, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
         case 2 * 16 + 10: gemm_tile<2, 10, true>(P, L.B, m_tile, n_tile, s_mem); break;
         case 2 * 16 + 8: gemm_tile<2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 2: gemm_tile<1, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
         default: gemm_tile<2, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
