@@ -175,12 +175,22 @@ struct Stage {                 // which rows of which net, reading which (rc_pk)
     const float* x_alt = nullptr;              // input of rows lacking sel_bit in fb.flags (deferred updater step)
     int sel_bit = 0;
     int out_bit = 0;                           // linear2 writes only rows with this bit in fb.flags
+    int rows_hint = -1;                        // expected active rows (-1 = the whole batch): picks the LSTM tile shape
 };
+
+// LSTM tile shape (16*mr rows x 4*nc units) for a stage expected to touch `rows` rows: wide tiles when the row tiles
+// alone fill the chip, narrow ones (more column tiles, each streaming a slice of the weights) when few rows are active.
+void pick_tile(int H, int rows, int* mr, int* nc) {
+    if (rows >= 128) { *mr = 2; *nc = H == 1280 ? 10 : (H == 1024 ? 8 : 4); return; }
+    if (rows > 16) { *mr = 2; *nc = rows >= 64 ? 4 : 2; if (*nc == 2) { *mr = 1; } return; }
+    *mr = 1; *nc = 1;
+}
 
 GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
     GemmProblem p = dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit,
                                   s.flags ? s.flags : c->fb.flags, n.steps, true);
+    if (s.rows_hint >= 0 && s.rows_hint < c->B) p.m_tiles = (s.rows_hint + 16 * p.mr - 1) / (16 * p.mr);
     p.alt_base = s.x_alt; p.sel_flags = c->fb.flags; p.sel_bit = s.x_alt ? s.sel_bit : 0;
     return p;
 }
@@ -195,7 +205,10 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = s.flags ? s.flags : c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
-    p.n_tiles = n.H / (4 * n.nc); p.m_tiles = (c->B + 16 * n.mr - 1) / (16 * n.mr); p.Kp = 2 * n.H; p.nc = n.nc; p.mr = n.mr;
+    int mr, nc;
+    pick_tile(n.H, s.rows_hint < 0 ? c->B : s.rows_hint, &mr, &nc);
+    const int rows = s.rows_hint < 0 ? c->B : (s.rows_hint < c->B ? s.rows_hint : c->B);
+    p.n_tiles = n.H / (4 * nc); p.m_tiles = (rows + 16 * mr - 1) / (16 * mr); p.Kp = 2 * n.H; p.nc = nc; p.mr = mr;
     return p;
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
@@ -277,9 +290,10 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
     // deferred vision updater of the previous frame (L264-271) for rows that step again now: rnn6 then rnn4 in the
     // reference, independent nets here. State-only, linear2 skipped; usually no row qualifies and the tiles exit.
     if (ctx->prm.use_vision_updater) {
-        if (int rc = run_stage(ctx, {Stage{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2},
-                                     Stage{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}},
-                               false, nullptr, st)) return rc;
+        Stage t6{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
+        Stage t4{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
+        t6.rows_hint = t4.rows_hint = 8;              // regime changes: a handful of rows per frame -> narrow tiles
+        if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st)) return rc;
     }
     // inertial pose branch (L144) + visual pose branch (L153); rnn4 also takes the rows whose deferred updater
     // step is still pending and that do not step on camera keypoints this frame (they read x4l)
@@ -465,9 +479,9 @@ int rc_finalize_weights(rc_ctx* ctx) {
             const auto *wi = need("rnn.weight_ih_l" + sl, 4 * H * H), *wh = need("rnn.weight_hh_l" + sl, 4 * H * H);
             const auto *bi = need("rnn.bias_ih_l" + sl, 4 * H), *bh = need("rnn.bias_hh_l" + sl, 4 * H);
             if (!wi || !wh || !bi || !bh) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing LSTM weights of " + p);
-            // column n' of tile t = [i | f | g | o] x UT units  <->  torch row g*H + t*UT + u (gate order i,f,g,o)
-            const int UT = 4 * n.nc, NT = 4 * UT;
-            auto orig = [&](int np) { const int t = np / NT, g = (np % NT) / UT, u = np % UT; return (size_t)g * H + t * UT + u; };
+            // 16-column block cb = 4 hidden units x [i | f | g | o]: column n' <-> torch row g*H + 4*cb + u (gate order
+            // i,f,g,o). Independent of the tile width, so few-row stages can run narrow tiles on the same weights.
+            auto orig = [&](int np) { const int cb = np / 16, g = (np % 16) / 4, u = np % 4; return (size_t)g * H + 4 * cb + u; };
             auto get = [&](int np, int k) -> float {
                 const size_t r = orig(np);
                 return k < (int)H ? (*wi)[r * H + k] : (*wh)[r * H + (k - H)];

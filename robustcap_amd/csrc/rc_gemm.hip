@@ -71,14 +71,20 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 //             4 x 4 : 64 rows x 16 units (rnn6, H = 1024)    (4 + 4) KiB per 64 MFMAs  = 256 B
 //             2 x 4 : 32 rows x 16 units (H = 512, dense)    (2 + 4) KiB per 32 MFMAs  = 384 B
 //             2 x 8 / 2 x 10: 32-row variants of the big nets (the ones in use: see rc_api.cpp)
+//             1 x 1 : 16 rows x 4 units: few-row stages (regime transitions, batch 1): 320/256/128 tiles per layer so
+//                     that every CU streams a slice of the weights (a 32 x 160 tile would leave 224 CUs idle)
 //             1 x 2 : 16 rows x 32 columns for linear2 (N = 2..144): 3x the workgroups of a 32 x 64 tile -- these
 //                     launches are parallelism-starved (16-48 workgroups), not bandwidth- or latency-bound
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
 template <int MR, int NC, bool PIPE>
-__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile, const int n_tile, float* s_mem) {
+__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
+  // Row tiles m_tile0, m_tile0 + m_tiles, ... : stages that expect only a few active rows launch a single row tile per
+  // column tile and still cover any number of rows (a full grid of row tiles would mostly be workgroups that scan the
+  // flags and exit: 9,216 of them per launch at batch 256 with 16-row tiles).
+  for (int m_tile = m_tile0;; m_tile += P.m_tiles) {
     int* s_rows = reinterpret_cast<int*>(s_mem);                   // [MT <= 64]
     int* s_cnt = s_rows + 64;                                       // [RC_NW] (+ padding to 128 ints)
     float* s_part = s_mem + 128;                                    // [RC_NW][MT][LD]
@@ -90,10 +96,12 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     if (P.flag_bit == 0) {
         nrows = min(MT, B - lo);
         if (nrows <= 0) return;
+        __syncthreads();                                            // previous row tile done with s_rows / s_part
         if (tid < MT) s_rows[tid] = lo + min(tid, nrows - 1);
         __syncthreads();
     } else {
         int total = 0;
+        __syncthreads();                                            // previous row tile done with s_rows / s_part
         for (int base = 0; base < B && total < lo + MT; base += RC_NW * 64) {
             const int r = base + tid;
             const bool f = r < B && (P.flags[r] & P.flag_bit);
@@ -192,7 +200,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
-        // item -> (row rr, unit u); columns of a tile are [i(UT) | f(UT) | g(UT) | o(UT)]
+        // item -> (row rr, unit u); every 16-column block holds 4 hidden units x [i | f | g | o] (4 columns each), so
+        // the weight packing does not depend on the tile width and the host picks NC per launch
         for (int item = tid; item < MT * UT; item += RC_NW * 64) {
             const int rr = item / UT, u = item - rr * UT;
             if (rr >= nrows) continue;
@@ -200,7 +209,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             float gsum[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int col = gq * UT + u;
+                const int col = 16 * (u >> 2) + 4 * gq + (u & 3);
                 float v = s_part[rr * LD + col];
 #pragma unroll
                 for (int w = 1; w < RC_NW; ++w) v += s_part[(w * MT + rr) * LD + col];
@@ -231,6 +240,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             }
         }
     }
+  }   // row-tile loop
 }
 
 #define RC_LDS_FLOATS (128 + RC_NW * 64 * (16 * 5 + LDS_PAD))   // 98 KB = the 4 x 5 tile; 2 x 10 needs 90 KB
@@ -262,6 +272,7 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
         case 2 * 16 + 10: gemm_tile<2, 10, true>(P, L.B, m_tile, n_tile, s_mem); break;
         case 2 * 16 + 8: gemm_tile<2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
         case 1 * 16 + 2: gemm_tile<1, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 1: gemm_tile<1, 1, true>(P, L.B, m_tile, n_tile, s_mem); break;
         default: gemm_tile<2, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
