@@ -78,7 +78,7 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int MR, int NC, bool PIPE>
+template <int MR, int NC, int D, bool PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
   // Row tiles m_tile0, m_tile0 + m_tiles, ... : stages that expect only a few active rows launch a single row tile per
@@ -168,24 +168,51 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define SB() do { if (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
     // The steady-state loop has NO conditionals on the load path other than the wave-uniform segment select: with a
     // conditional prefetch hipcc (ROCm 7.2) waits vmcnt(0) in front of the MFMAs.
-    Frag<MR, NC> fa = {}, fb = {};
-    int q = 0;
-    LOADC(fa, 0);
-    for (; q + 2 < Qw; q += 2) {
+    // Software pipeline over D chunk buffers: D - 1 chunks are in flight behind every MFMA block. The steady-state
+    // loop has NO conditionals other than the wave-uniform segment select (with a conditional prefetch hipcc waits
+    // vmcnt(0) in front of the MFMAs); prefetch indices past the end are clamped (a redundant, valid load) and only
+    // the remainder (< D chunks, already loaded) is predicated. D = 2 for the wide tiles (their 64-80 MFMAs per chunk
+    // cover the latency), D = 8 for the 16-row tiles whose 4-8 MFMAs per chunk do not.
+    if constexpr (D == 2) {             // wide tiles: two named buffers (the array form below schedules worse here)
+        Frag<MR, NC> fa = {}, fb = {};
+        int q = 0;
+        LOADC(fa, 0);
+        for (; q + 2 < Qw; q += 2) {
+            LOADC(fb, q + 1);
+            SB();
+            mma_chunk<MR, NC>(fa, acc);
+            SB();
+            LOADC(fa, q + 2);
+            SB();
+            mma_chunk<MR, NC>(fb, acc);
+            SB();
+        }
         LOADC(fb, q + 1);
         SB();
         mma_chunk<MR, NC>(fa, acc);
         SB();
-        LOADC(fa, q + 2);
-        SB();
         mma_chunk<MR, NC>(fb, acc);
-        SB();
+    } else {
+        Frag<MR, NC> f[D];
+    #pragma unroll
+        for (int d = 0; d < D; ++d) f[d] = Frag<MR, NC>{};
+    #pragma unroll
+        for (int d = 0; d < D - 1; ++d) LOADC(f[d], min(d, Qw - 1));
+        int q = 0;
+        for (; q + D <= Qw; q += D) {
+    #pragma unroll
+            for (int d = 0; d < D; ++d) {
+                LOADC(f[(d + D - 1) % D], min(q + d + D - 1, Qw - 1));
+                SB();
+                mma_chunk<MR, NC>(f[d], acc);
+                SB();
+            }
+        }
+        const int rem = Qw - q;
+    #pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (d < rem) mma_chunk<MR, NC>(f[d], acc);
     }
-    LOADC(fb, q + 1);
-    SB();
-    mma_chunk<MR, NC>(fa, acc);
-    SB();
-    mma_chunk<MR, NC>(fb, acc);
 #undef LOADC
 #undef SB
 
@@ -267,13 +294,13 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
     }
     if (n_tile >= P.n_tiles) return;
     switch (P.mr * 16 + P.nc) {
-        case 4 * 16 + 5: gemm_tile<4, 5, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 4 * 16 + 4: gemm_tile<4, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 2 * 16 + 10: gemm_tile<2, 10, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 2 * 16 + 8: gemm_tile<2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 1 * 16 + 2: gemm_tile<1, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 1 * 16 + 1: gemm_tile<1, 1, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        default: gemm_tile<2, 4, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 5: gemm_tile<4, 5, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 4: gemm_tile<4, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 10: gemm_tile<2, 10, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 8: gemm_tile<2, 8, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 2: gemm_tile<1, 2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 1: gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        default: gemm_tile<2, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
 
