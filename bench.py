@@ -9,7 +9,7 @@ A step = one frame of the hot path (prep -> 6 LSTM sub-nets -> fusion/FK tail ->
 of 256 bodies per GPU, inputs resident in HBM. Workload = BASELINE.json configs[1]: synthetic 60 fps sequences,
 6 IMUs + 33 keypoints, batch 256 x 512 frames, mixed-confidence schedule (50 % high /
 20 % mid / 30 % occluded, which forces the frame-stepped path incl. the vision updater). Weak scaling: every rank
-runs its own 256 bodies; outputs are all-gathered (RCCL) inside the timed region for N > 1.
+runs its own 256 bodies; outputs are gathered to rank 0 (RCCL) inside the timed region for N > 1.
 
 Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
 """
@@ -125,9 +125,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     pose, tran = run(W, T, False)
-    if world > 1:      # the path's only collective: final gather of the outputs
-        pose = rdist.gather_rows(pose.reshape(B, -1), B * world)
-        tran = rdist.gather_rows(tran.reshape(B, -1), B * world)
+    if world > 1:      # the path's only collective: final gather of the outputs to rank 0 (RCCL over xGMI)
+        gp = rdist.gather_rows(pose.reshape(B, -1), B * world, dst=0)
+        gt = rdist.gather_rows(tran.reshape(B, -1), B * world, dst=0)
+        if rank == 0:
+            pose, tran = gp, gt
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -42,18 +42,28 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def gather_rows(local, n_rows_total):
-    """All-gather row blocks of unequal size along dim 0 -> the full [n_rows_total, ...] tensor on every rank.
+def gather_rows(local, n_rows_total, dst=None):
+    """Gather row blocks of unequal size along dim 0 into the full [n_rows_total, ...] tensor.
+
+    dst=None: all-gather, every rank gets the result. dst=r: gather to rank r only (the other ranks return None) --
+    over xGMI that is 7 point-to-point transfers into r instead of a ring pass of everybody's block.
     ``local`` is this rank's block as produced by shard_range (same trailing shape everywhere)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(n_rows_total, r, world) for r in range(world)]
     cap = max(b - a for a, b in sizes)
     pad = local.new_zeros((cap,) + tuple(local.shape[1:]))
     pad[:local.shape[0]] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous())
+    pad = pad.contiguous()
+    if dst is None:
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad)
+    else:
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, out, dst=dst)
+        if rank != dst:
+            return None
     return torch.cat([o[:b - a] for o, (a, b) in zip(out, sizes)], dim=0)
 
 

@@ -48,6 +48,9 @@ def _worker(rank, world, port, B, T, out_dir):
 
     pose, tran = rdist.run_sharded(step, [rows], B)
     assert pose.shape == (B, T, 24, 3, 3) and tran.shape == (B, T, 3)
+    a, b = rdist.shard_range(B, rank, world)                       # gather-to-root variant (bench.py uses it)
+    g = rdist.gather_rows(tran[a:b].contiguous(), B, dst=0)
+    assert (g is None) == (rank != 0) and (rank != 0 or torch.equal(g, tran))
     torch.save((pose, tran), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
