@@ -292,14 +292,15 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
     if (ctx->prm.use_vision_updater) {
         Stage t6{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         Stage t4{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
-        t6.rows_hint = t4.rows_hint = 8;              // regime changes: a handful of rows per frame -> narrow tiles
+        t6.rows_hint = t4.rows_hint = 8;  // regime changes: a handful of rows per frame -> narrow tiles
         if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st)) return rc;
     }
     // inertial pose branch (L144) + visual pose branch (L153); rnn4 also takes the rows whose deferred updater
     // step is still pending and that do not step on camera keypoints this frame (they read x4l)
-    if (int rc = run_stage(ctx, {Stage{N2, 0, fb.x2, 128, Out{fb.x3, 256, 72, true}},
-                                 Stage{N4, (int)RC_ROW2_M4, fb.x4, 256, Out{fb.x6, 256, 171, true}, fb.flags2, fb.x4l,
-                                       (int)RC_ROW_VIS, (int)RC_ROW_VIS}}, true, nullptr, st)) return rc;
+    // (longest tiles first: the short ones of the other nets then fill the gaps at the end of the launch)
+    if (int rc = run_stage(ctx, {Stage{N4, (int)RC_ROW2_M4, fb.x4, 256, Out{fb.x6, 256, 171, true}, fb.flags2, fb.x4l,
+                                       (int)RC_ROW_VIS, (int)RC_ROW_VIS},
+                                 Stage{N2, 0, fb.x2, 128, Out{fb.x3, 256, 72, true}}}, true, nullptr, st)) return rc;
     if (first) {                                                           // L155-156: rnn6 on every row
         if (int rc = run_stage(ctx, {Stage{N6, 0, fb.x6, 256, Out{fb.pc, 4, 0, false}}}, true, nullptr, st)) return rc;
     }
@@ -311,9 +312,9 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
         init.push_back(dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), Out{ctx->hid2, 1024, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false));
         init.push_back(dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), Out{fb.init_out, 2048, 0, false}, false, RC_ROW_REACH, fb.flags, nullptr, false));
     }
-    if (int rc = run_stage(ctx, {Stage{N3, 0, fb.x3, 256, Out{fb.vr, 4, 0, false}},
-                                 Stage{N6, (int)RC_ROW2_M6, fb.x6, 256, Out{fb.pc, 4, 0, false}, fb.flags2, fb.x6l,
+    if (int rc = run_stage(ctx, {Stage{N6, (int)RC_ROW2_M6, fb.x6, 256, Out{fb.pc, 4, 0, false}, fb.flags2, fb.x6l,
                                        (int)RC_ROW_PC, (int)RC_ROW_PC},
+                                 Stage{N3, 0, fb.x3, 256, Out{fb.vr, 4, 0, false}},
                                  Stage{N7, 0, fb.x78, 256, Out{fb.r6d, 144, 0, false}}, Stage{N8, 0, fb.x78, 256, Out{fb.contact, 2, 0, false}}},
                            true, &init, st)) return rc;
     // tail: fusion logic + landmarks; rows in the occluded regime get their updater inputs (x6l, x4l) and a
