@@ -172,6 +172,7 @@ def main():
                        "batch_per_gpu": B, "frames": K, "conf": args.conf, "parallelism": f"dp{world} (sequence sharding)"},
             "roofline": roof, "cpu_baseline": cpu}))
     if world > 1:
+        torch.distributed.barrier()          # rank 0 may still be in its instrumented pass
         torch.distributed.destroy_process_group()
 
 

@@ -369,7 +369,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     rc_ctx* ctx = new rc_ctx();
     ctx->B = batch;
     ctx->Bp = round_up(batch, RC_MT);
-    hipGetDevice(&ctx->dev);
+    (void)hipGetDevice(&ctx->dev);
     rc_default_params(live, &ctx->prm);
     const size_t B = (size_t)batch, Bp = (size_t)ctx->Bp;
     int rc = RC_OK;
@@ -411,8 +411,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
 int rc_destroy(rc_ctx* ctx) {
     if (!ctx) return RC_OK;
     rc_live_end(ctx);
-    for (void* p : ctx->allocs) hipFree(p);
-    for (auto& e : ctx->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
 }
@@ -570,14 +570,14 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
 
 int rc_live_end(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
-    if (ctx->live_exec) { hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
-    if (ctx->live_graph) { hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
-    if (ctx->live_stream) { hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
-    if (ctx->live_in_h) { hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
-    if (ctx->live_out_h) { hipHostFree(ctx->live_out_h); ctx->live_out_h = nullptr; }
-    if (ctx->live_in_d) { hipFree(ctx->live_in_d); ctx->live_in_d = nullptr; }
-    if (ctx->live_out_d) { hipFree(ctx->live_out_d); ctx->live_out_d = nullptr; }
-    if (ctx->live_ft_d) { hipFree(ctx->live_ft_d); ctx->live_ft_d = nullptr; }
+    if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
+    if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
+    if (ctx->live_stream) { (void)hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
+    if (ctx->live_in_h) { (void)hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
+    if (ctx->live_out_h) { (void)hipHostFree(ctx->live_out_h); ctx->live_out_h = nullptr; }
+    if (ctx->live_in_d) { (void)hipFree(ctx->live_in_d); ctx->live_in_d = nullptr; }
+    if (ctx->live_out_d) { (void)hipFree(ctx->live_out_d); ctx->live_out_d = nullptr; }
+    if (ctx->live_ft_d) { (void)hipFree(ctx->live_ft_d); ctx->live_ft_d = nullptr; }
     return RC_OK;
 }
 
@@ -596,11 +596,11 @@ int rc_live_begin(rc_ctx* ctx) {
     const bool timing = ctx->timing;
     ctx->timing = false;
     HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
     FrameIO io{ctx->live_in_d, ctx->live_in_d + B * 99, ctx->live_in_d + B * 117, nullptr,
                ctx->live_out_d, ctx->live_out_d + B * 216, 99, 18, 54, 216, 3};
     const int rc = step_impl(ctx, io, 0u, st);
-    hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
     hipError_t e = hipStreamEndCapture(st, &ctx->live_graph);
     ctx->timing = timing;
     if (rc) return rc;

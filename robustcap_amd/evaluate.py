@@ -106,9 +106,28 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     return res
 
 
+def procrustes_error(S1, S2):
+    """Mean per-joint error after the optimal similarity transform of each frame's S1 [T,J,3] onto S2 [T,J,3]
+    (what the reference's PA-MPJPE does with utils.py:138-203 ``reconstruction_error``; harness-side numpy SVD)."""
+    S1, S2 = np.asarray(S1, np.float64), np.asarray(S2, np.float64)
+    mu1, mu2 = S1.mean(1, keepdims=True), S2.mean(1, keepdims=True)
+    X1, X2 = S1 - mu1, S2 - mu2
+    var1 = (X1 ** 2).sum((1, 2))
+    K = np.einsum("tji,tjk->tik", X1, X2)
+    U, s, Vt = np.linalg.svd(K)
+    V = np.swapaxes(Vt, 1, 2)
+    Z = np.tile(np.eye(3), (S1.shape[0], 1, 1))
+    Z[:, 2, 2] = np.sign(np.linalg.det(U @ Vt))
+    R = V @ Z @ np.swapaxes(U, 1, 2)
+    scale = np.einsum("tii->t", R @ K) / np.maximum(var1, 1e-30)
+    S1h = scale[:, None, None] * (X1 @ np.swapaxes(R, 1, 2)) + mu2
+    return float(np.linalg.norm(S1h - S2, axis=2).mean())
+
+
 def joint_errors(model, pose_p, tran_p, pose_t, tran_t):
-    """dict of per-sequence means: root-aligned MPJPE over the 24 SMPL joints (m), absolute root position error (m)
-    and global joint rotation error (degrees, float64 atan2 form). ``model`` = robustcap_amd.body.ParametricModel."""
+    """dict of per-sequence means: root-aligned MPJPE and Procrustes-aligned MPJPE over the 24 SMPL joints (m), absolute
+    root position error (m) and global joint rotation error (degrees, float64 atan2 form).
+    ``model`` = robustcap_amd.body.ParametricModel."""
     gp, jp = model.forward_kinematics(pose_p, tran=tran_p)
     gt, jt = model.forward_kinematics(pose_t, tran=tran_t)
     rel_p, rel_t = jp - jp[:, :1], jt - jt[:, :1]
@@ -117,7 +136,8 @@ def joint_errors(model, pose_p, tran_p, pose_t, tran_t):
     D = (gp.double().transpose(-1, -2) @ gt.double()).reshape(-1, 3, 3)
     v = torch.stack((D[:, 2, 1] - D[:, 1, 2], D[:, 0, 2] - D[:, 2, 0], D[:, 1, 0] - D[:, 0, 1]), dim=1) * 0.5
     ang = torch.rad2deg(torch.atan2(v.norm(dim=1), (D[:, 0, 0] + D[:, 1, 1] + D[:, 2, 2] - 1) * 0.5)).mean()
-    return {"mpjpe_smpl24_m": float(mpjpe), "root_error_m": float(root), "global_angle_deg": float(ang)}
+    return {"mpjpe_smpl24_m": float(mpjpe), "pa_mpjpe_smpl24_m": procrustes_error(rel_p.cpu().numpy(), rel_t.cpu().numpy()),
+            "root_error_m": float(root), "global_angle_deg": float(ang)}
 
 
 def evaluate(dataset, state_dict, body, device="cuda", **kw):

@@ -51,5 +51,10 @@ def test_run_dataset_rows_equal_direct_runs_and_metrics(synth_assets):
     assert z["mpjpe_smpl24_m"] == 0.0 and z["root_error_m"] == 0.0 and z["global_angle_deg"] < 1e-3
     shifted = ev.joint_errors(model, pt, tt + torch.tensor([0.1, 0.0, 0.0]), pt, tt)
     assert abs(shifted["root_error_m"] - 0.1) < 1e-5 and shifted["mpjpe_smpl24_m"] < 1e-5
+    Rz = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    rot = pt.clone()
+    rot[:, 0] = Rz @ rot[:, 0]                                                    # rigidly rotated prediction
+    e = ev.joint_errors(model, rot, tt, pt, tt)
+    assert e["mpjpe_smpl24_m"] > 0.05 and e["pa_mpjpe_smpl24_m"] < 1e-5           # Procrustes removes it
     per_row, mean = ev.evaluate(ds, sd, body)
     assert len(per_row) == 4 and np.isfinite(list(mean.values())).all()

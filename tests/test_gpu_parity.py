@@ -272,3 +272,25 @@ def test_live_graph_step_equals_eager(synth_assets):
         pa, ta = a.forward_online(*args)
         pb, tb = b.forward_online(*args)
         assert torch.equal(pa, pb) and torch.equal(ta, tb)
+
+
+def test_mass_regime_transition_vs_oracle(synth_assets):
+    """Every row leaves the occluded regime in the same frame: the deferred updater steps of ALL rows become
+    transition steps at once (far more rows than the narrow transition launch is sized for) -- and back again."""
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd import synth
+    B, T = 70, 30
+    m = synth.make_motion(123, B, T, synth_assets["body"], conf="high")
+    m["j2dc"][:, 5:12, :, 2] = 0.5          # all rows occluded for frames 5..11, visible again from 12
+    m["j2dc"][:, 20:24, :, 2] = 0.55
+    net, ora = make_net(synth_assets, B), make_oracle(synth_assets, B)
+    net.gravityc = t(m["gravityc"])
+    ora.gravityc = t(m["gravityc"])
+    pose, tran = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    for i in range(T):
+        p, tr = ora.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]), None, i == 0)
+        assert maxdiff(tran[:, i], tr) <= 1e-4, i
+        assert float(O.rotation_angle_deg(pose[:, i].cpu(), p).max()) <= 0.1, i
+    for n in ("rnn4", "rnn6"):
+        h, c = net.get_state(n)
+        assert maxdiff(h, ora.h[n]) <= 1e-4 and maxdiff(c, ora.c[n]) <= 2e-4, n
