@@ -5,8 +5,9 @@
 // and rnn2.init_net (articulate/utils/torch/rnn.py:195-201).
 //
 // Shape regime: M = batch rows (256..1024, skinny), K = 2H (1024..2560), N = 4H. The grid is made of
-// 32-row x 64-column tiles; a tile's K range is split over the 4 waves of its workgroup so that a 512-unit
-// layer already yields 256 workgroups (one per CU). Each wave streams ITS slice of the weights straight from
+// (16*MR)-row x (16*NC)-column tiles (shapes: gemm_tile below); a tile's K range is split over the 4 waves of its
+// workgroup so that every LSTM layer yields 256 workgroups at batch 256 (one per CU; one workgroup per CU is also
+// all that is resident -- see RC_LDS_FLOATS). Each wave streams ITS slice of the weights straight from
 // L2/HBM into VGPRs as 1 KiB coalesced dwordx4 loads (weights are pre-packed in MFMA-B fragment order, nothing
 // is shared between waves so LDS staging would be pure overhead) and feeds v_mfma_f32_16x16x4_f32 -- bitwise an
 // fp32 fma chain, which is what keeps the 1e-4 parity budget. Partial sums meet in LDS; the epilogue applies the
@@ -18,7 +19,6 @@
 #include "rc_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LDS_PAD 16            // floats added to a partial-sum row: epilogue rows land on different banks
 
