@@ -134,6 +134,12 @@ int rc_body_fk(rc_ctx* ctx, const float* pose, const float* tran, float* grot, f
 /* One step of sub-net `net` ("rnn2".."rnn8") = f(i, x) of forward_online (net/sig_mp.py:126-129) on its
  * recurrent state: x[batch, in] -> y[batch, out]. row_mask DEVICE uint8[batch] or NULL (all rows). */
 int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* row_mask, float* y, void* stream);
+/* Full-mesh skinning for the metrics of evaluate.py:120-133 (cal_mpjpe: PVE and regressor joints need every vertex).
+ * rc_set_mesh uploads v_template[V,3] and weights[V,24] (HOST pointers, same J / parent as rc_set_body);
+ * rc_body_mesh = ParametricModel.forward_kinematics(pose, tran, calc_mesh=True)[2] (articulate/model.py:229-241):
+ * pose[n,24,3,3] local, tran[n,3] -> vert[n,V,3]. */
+int rc_set_mesh(rc_ctx* ctx, const float* v_template_host, const float* weights_host, int32_t V);
+int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert, int64_t n, void* stream);
 /* smplify forward residual (net/smplify/temporal_smplify.py:198-220 -> losses.py:36-37,43-46): pose[T,24,3,3],
  * tran[T,3], kp[T,33,3] in pixels, K[3,3] (DEVICE) -> loss[T,33]. The confidences of landmarks
  * {1..9,31,32} count as zero. */

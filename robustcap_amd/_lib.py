@@ -51,6 +51,8 @@ SIGNATURES = {
     "rc_ik_r": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_fk_bone": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_body_fk": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "rc_set_mesh": (_I32, [_P, _P, _P, _I32]),
+    "rc_body_mesh": (_I32, [_P, _P, _P, _P, _I64, _P]),
     "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),
     "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
     "rc_camera_inputs": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -95,6 +95,23 @@ class ParametricModel:
                                                    _lib.ptr(j33), n, _lib.stream_ptr()), "rc_body_fk")
         return (grot, joint, j33) if calc_mesh else (grot, joint)
 
+    def forward_mesh(self, pose, tran=None):
+        """All V vertices of ``forward_kinematics(pose, tran=tran, calc_mesh=True)[2]`` (articulate/model.py:235-241),
+        for the mesh metrics of evaluate.py:120-133. Returns a device tensor [n, V, 3]."""
+        if not self.__dict__.get("_mesh_set"):
+            vt = np.ascontiguousarray(self._body["v_template"], dtype=np.float32)
+            w = np.ascontiguousarray(self._body["weights"], dtype=np.float32)
+            _lib.check(self._ctx, self._lib.rc_set_mesh(self._ctx, vt.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                                        vt.shape[0]), "rc_set_mesh")
+            self._mesh_set, self._V = True, vt.shape[0]
+        pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
+        n = pose.shape[0]
+        tran = torch.zeros(n, 3, device=self.device) if tran is None else _f32c(tran, self.device).view(n, 3)
+        vert = torch.empty(n, self._V, 3, device=self.device)
+        _lib.check(self._ctx, self._lib.rc_body_mesh(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(vert), n, _lib.stream_ptr()),
+                   "rc_body_mesh")
+        return vert
+
     def reprojection_residual(self, pose, tran, keypoints_2d, cam_k, sigma=100.0):
         """``TemporalSMPLify.get_fitting_loss`` (temporal_smplify.py:198-220): [T,33] robust reprojection loss."""
         pose = _f32c(pose, self.device).view(-1, 24, 3, 3)

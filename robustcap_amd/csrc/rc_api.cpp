@@ -60,6 +60,8 @@ struct rc_ctx {
     float *hid1 = nullptr, *hid2 = nullptr, *xtmp = nullptr;
     FrameBuffers fb{};
     BodyConst* body = nullptr;
+    float *mesh_vt = nullptr, *mesh_w = nullptr;      // full mesh (metrics only): v_template [V,3], weights [V,24]
+    int mesh_V = 0;
     bool have_body = false, have_weights = false;
     std::map<std::string, std::vector<float>> staged;
     std::vector<void*> allocs;
@@ -516,6 +518,7 @@ int rc_set_body(rc_ctx* ctx, const int32_t* parent, const float* J, const float*
     }
     for (int i = 0; i < 24; ++i)
         for (int c = 0; c < 3; ++c) {
+            b.jroot[c] = J[c];
             b.jrest[i][c] = J[3 * i + c] - J[c];                                   // model.py:87
             b.bone[i][c] = i == 0 ? b.jrest[0][c] : (J[3 * i + c] - J[c]) - (J[3 * parent[i] + c] - J[c]);   // spatial.py:148-167
         }
@@ -668,6 +671,23 @@ int rc_body_fk(rc_ctx* ctx, const float* pose, const float* tran, float* grot, f
     if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_body_fk: body not set") : RC_ERR_INVALID;
     if (!pose || !tran || !joint || !j33) return fail(ctx, RC_ERR_INVALID, "rc_body_fk: null buffer");
     rc_launch_body_fk(ctx->body, pose, tran, grot, joint, j33, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_set_mesh(rc_ctx* ctx, const float* vt, const float* w, int32_t V) {
+    if (!ctx || !vt || !w || V <= 0) return RC_ERR_INVALID;
+    if (int rc = dev_alloc(ctx, &ctx->mesh_vt, (size_t)V * 3, false)) return rc;
+    if (int rc = dev_alloc(ctx, &ctx->mesh_w, (size_t)V * 24, false)) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->mesh_vt, vt, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->mesh_w, w, (size_t)V * 24 * sizeof(float), hipMemcpyHostToDevice));
+    ctx->mesh_V = V;
+    return RC_OK;
+}
+int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body || ctx->mesh_V == 0) return ctx ? fail(ctx, RC_ERR_STATE, "rc_body_mesh: rc_set_body / rc_set_mesh first") : RC_ERR_INVALID;
+    if (n == 0) return RC_OK;
+    if (!pose || !tran || !vert || n < 0) return fail(ctx, RC_ERR_INVALID, "rc_body_mesh: bad argument");
+    rc_launch_body_mesh(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, pose, tran, vert, n, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
 }

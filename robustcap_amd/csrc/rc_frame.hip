@@ -674,6 +674,42 @@ __global__ void rc_camera_inputs_kernel(const float* kp, const float* acc, const
     }
 }
 
+// Full-mesh linear-blend skinning (articulate/model.py:235-241): one workgroup per frame; wave 0 chains the 24 joint
+// transforms into LDS, then all 256 threads sweep the V vertices (blend the 3x4 transforms, then apply). HBM-bound
+// sweep: 12 B out per vertex; v_template (83 KB) and the [V,24] weights (661 KB) stay in L2 across frames.
+__global__ __launch_bounds__(256) void rc_body_mesh_kernel(const BodyConst* __restrict__ body, const float* __restrict__ vt,
+                                                           const float* __restrict__ w, int V, const float* pose,
+                                                           const float* tran, float* vert) {
+    __shared__ WaveScratch s;
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 216; e += 256) s.Rl[e / 9][e % 9] = pose[b * 216 + e];
+    const float t[3] = {tran[b * 3], tran[b * 3 + 1], tran[b * 3 + 2]};
+    __syncthreads();
+    // wave_body_fk synchronises with __syncthreads: every wave runs it (lanes >= 64 do no joint work)
+    wave_body_fk(body, s, t, tid < 64 ? tid : 64);
+    for (int v = tid; v < V; v += 256) {
+        float A[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) A[k] = 0.0f;
+        const float* wv = w + (long long)v * 24;
+        for (int j = 0; j < 24; ++j) {
+            const float wj = wv[j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                A[4 * r + 0] += wj * s.G[j][3 * r + 0];
+                A[4 * r + 1] += wj * s.G[j][3 * r + 1];
+                A[4 * r + 2] += wj * s.G[j][3 * r + 2];
+                A[4 * r + 3] += wj * s.T[j][r];
+            }
+        }
+        const float x = vt[3 * v] - body->jroot[0], y = vt[3 * v + 1] - body->jroot[1], z = vt[3 * v + 2] - body->jroot[2];
+        float* o = vert + (b * V + v) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = (((A[4 * r] * x + A[4 * r + 1] * y) + A[4 * r + 2] * z) + A[4 * r + 3]) + t[r];
+    }
+}
+
 // smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
 // (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
 __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
@@ -771,6 +807,11 @@ void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tr
                        long long n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(rc_body_fk_kernel, dim3((unsigned)n), dim3(64), 0, st, body, pose, tran, grot, joint, j33);
+}
+void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w, int V, const float* pose, const float* tran,
+                         float* vert, long long n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rc_body_mesh_kernel, dim3((unsigned)n), dim3(256), 0, st, body, vt, w, V, pose, tran, vert);
 }
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K, float sigma,
                         float* loss, long long T, hipStream_t st) {

@@ -85,6 +85,7 @@ struct BodyConst {          // device copy of the body constants the path needs
     int level[24];          // depth in the kinematic tree
     float bone[24][3];      // rest bone vectors  (j_rest[i] - j_rest[parent[i]])
     float jrest[24][3];     // rest joints, root at the origin
+    float jroot[3];         // rest position of the root joint (subtracted from the template, model.py:87)
     float w33[33][24];
     float v33[33][3];       // landmark vertices, root-relative
     int override_joint[33]; // sync_mp3d: landmark row -> joint id, or -1
@@ -144,5 +145,7 @@ void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n
 void rc_launch_fk_bone(const BodyConst* body, const float* Rg, float* joints, long long n, hipStream_t s);
 void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tran, float* grot, float* joint,
                        float* j33, long long n, hipStream_t s);
+void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w, int V, const float* pose, const float* tran,
+                         float* vert, long long n, hipStream_t s);
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
                         float sigma, float* loss, long long T, hipStream_t s);

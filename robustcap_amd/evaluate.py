@@ -140,6 +140,24 @@ def joint_errors(model, pose_p, tran_p, pose_t, tran_t):
             "root_error_m": float(root), "global_angle_deg": float(ang)}
 
 
+def cal_mpjpe(model, pose, gt_pose, j_regressor=None, cal_pampjpe=False):
+    """evaluate.py:120-133 on the GPU mesh: [MPJPE over the first 14 regressor joints (pelvis-aligned), PVE, PA-MPJPE].
+    ``j_regressor`` [17, V] is the external ``J_regressor_h36m.npy``; without it the 24 SMPL joints stand in for the
+    regressor joints (documented deviation: the asset is not shipped). Translation is zero, as in the reference."""
+    v_t = model.forward_mesh(gt_pose)
+    v_p = model.forward_mesh(pose)
+    if j_regressor is not None:
+        Jr = torch.as_tensor(j_regressor, dtype=torch.float32, device=v_p.device)
+        kp_p, kp_t = (Jr @ v_p)[:, :14], (Jr @ v_t)[:, :14]                       # evaluate.py:122-125
+    else:
+        kp_p, kp_t = model.forward_kinematics(pose)[1], model.forward_kinematics(gt_pose)[1]
+    kp_p, kp_t = kp_p - kp_p[:, :1], kp_t - kp_t[:, :1]                            # evaluate.py:126-129
+    out = [float((kp_t - kp_p).norm(dim=2).mean()), float((v_t - v_p).norm(dim=2).mean())]
+    if cal_pampjpe:
+        out.append(procrustes_error(kp_p.cpu().numpy(), kp_t.cpu().numpy()))
+    return out
+
+
 def evaluate(dataset, state_dict, body, device="cuda", **kw):
     """Full loop: run all rows, return per-row metrics and their mean (rank-local when not distributed)."""
     res = run_dataset(dataset, state_dict, body, device=device, **kw)

@@ -58,3 +58,32 @@ def test_run_dataset_rows_equal_direct_runs_and_metrics(synth_assets):
     assert e["mpjpe_smpl24_m"] > 0.05 and e["pa_mpjpe_smpl24_m"] < 1e-5           # Procrustes removes it
     per_row, mean = ev.evaluate(ds, sd, body)
     assert len(per_row) == 4 and np.isfinite(list(mean.values())).all()
+
+
+def test_full_mesh_and_cal_mpjpe(synth_assets):
+    """rc_body_mesh == the oracle's skinning on every vertex (the oracle is pinned to the reference on sampled
+    vertices); cal_mpjpe semantics: zero for identical poses, PVE > 0 and PA-MPJPE ~ 0 for a rigid rotation."""
+    import os
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd import evaluate as ev
+    from robustcap_amd.body import ParametricModel
+    body = synth_assets["body"]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+    model = ParametricModel(body=body)
+    pose, tran = t(g["fk_pose"]), t(g["fk_tran"])
+    vert = model.forward_mesh(pose, tran)
+    assert vert.shape == (pose.shape[0], 6890, 3)
+    ids = [int(i) for i in g["fk_vert_extra_ids"]]
+    assert float((vert[:, ids].cpu() - t(g["fk_vert_extra"])).abs().max()) <= 2e-6           # reference capture
+    full = O.OracleBody(body, vertex_ids=range(6890)).forward_kinematics(pose, tran)[2]
+    assert float((vert.cpu() - full).abs().max()) <= 2e-6
+    z = ev.cal_mpjpe(model, pose, pose, cal_pampjpe=True)
+    assert z[0] == 0.0 and z[1] == 0.0 and z[2] < 1e-6
+    rot = pose.clone()
+    rot[:, 0] = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]) @ rot[:, 0]
+    e = ev.cal_mpjpe(model, rot, pose, cal_pampjpe=True)
+    assert e[0] > 0.05 and e[1] > 0.05 and e[2] < 1e-5
+    Jr = np.zeros((17, 6890), np.float32)
+    Jr[np.arange(17), np.arange(17) * 400] = 1.0                                              # a stand-in regressor
+    r = ev.cal_mpjpe(model, rot, pose, j_regressor=Jr)
+    assert len(r) == 2 and r[0] > 0.0
