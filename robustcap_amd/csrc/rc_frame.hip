@@ -84,6 +84,15 @@ struct WaveScratch {
     float J33[33][3];   // landmarks
 };
 
+// Body constants are read with data-dependent indices (parent chains): staging them in LDS once per workgroup turns
+// ~10 dependent global-load round trips of the tail kernel into LDS reads.
+__device__ __forceinline__ void stage_body(BodyConst* dst, const BodyConst* __restrict__ src, int tid, int nthreads) {
+    const int n = (int)(sizeof(BodyConst) / sizeof(int));
+    const int* s = reinterpret_cast<const int*>(src);
+    int* d = reinterpret_cast<int*>(dst);
+    for (int i = tid; i < n; i += nthreads) d[i] = s[i];
+}
+
 // joint `j` of fk(glb_pose) (net/sig_mp.py:131-135): sum of parent-rotated rest bone vectors, root -> leaf order.
 __device__ __forceinline__ void bone_chain(const BodyConst* body, const float (*Rg)[9], int j, float* out) {
     int path[12], n = 0;
@@ -283,9 +292,12 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
 
 // ============================================================================================ tail (L173-273)
 __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
-                                                     const BodyConst* __restrict__ body, int B, int first_frame) {
+                                                     const BodyConst* __restrict__ body_g, int B, int first_frame) {
     __shared__ WaveScratch s;
+    __shared__ BodyConst s_body;
     const int row = blockIdx.x, lane = threadIdx.x;
+    stage_body(&s_body, body_g, lane, 64);
+    const BodyConst* body = &s_body;
     const float* ori = io.ori + row * io.s_ori;
     float Rcr[9];
 #pragma unroll
