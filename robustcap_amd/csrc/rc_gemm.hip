@@ -270,7 +270,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
   }   // row-tile loop
 }
 
+#ifndef RC_LDS_FLOATS
 #define RC_LDS_FLOATS (128 + RC_NW * 64 * (16 * 5 + LDS_PAD))   // 98 KB = the 4 x 5 tile; 2 x 10 needs 90 KB
+#endif
 
 #ifndef RC_WPS
 #define RC_WPS 1   // waves per SIMD the register allocation must allow

@@ -9,7 +9,9 @@
 // column blocks (A: lane l = row l&15, k-quarter l>>4; B: k-quarter l>>4, column l&15).
 #define RC_MT 32          // rows per workgroup tile of dense layers (2 MFMA row blocks); LSTM tiles: 16 * mr
 #define RC_NT 64          // columns per workgroup tile of dense layers (NC = 4 blocks of 16)
+#ifndef RC_NW
 #define RC_NW 4           // waves per workgroup (K split)
+#endif
 #define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
 #define RC_KALIGN 128     // padded K granularity (>= 2 * RC_KC * RC_NW: an even number of chunks per wave)
 #define RC_MAX_PROB 6     // problems fused in one launch

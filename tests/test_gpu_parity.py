@@ -294,3 +294,33 @@ def test_mass_regime_transition_vs_oracle(synth_assets):
     for n in ("rnn4", "rnn6"):
         h, c = net.get_state(n)
         assert maxdiff(h, ora.h[n]) <= 1e-4 and maxdiff(c, ora.c[n]) <= 2e-4, n
+
+
+def test_live_session_over_the_wire_format(synth_assets):
+    """live_server.py loop on the GPU path: detector packets in, Unity packets out; poses equal a direct run."""
+    from robustcap_amd import live, synth
+    from robustcap_amd.body import rotation_matrix_to_axis_angle
+    T = 12
+    m = synth.make_motion(97, 1, T, synth_assets["body"], conf="high")
+    rcm = synth._rodrigues(np.array([0.1, 0.2, -0.05])).astype(np.float32)
+    net = make_net(synth_assets, 1)
+    net.live = True                                               # live_server.py:64-65
+    net.use_graph = True
+    sess = live.LiveSession(net)
+    ref = make_net(synth_assets, 1)
+    ref.live = True
+    ref.gravityc = t(rcm) @ torch.tensor([0.0, -1.0, 0.0])
+    first = None
+    for i in range(-1, T):
+        k = max(i, 0)
+        out = sess.handle(live.format_detector_packet(m["j2dc"][0, k], m["oric"][0, k], m["accc"][0, k], rcm))
+        if i < 0:
+            assert out is None
+            continue
+        p, tr = ref.forward_online(t(m["j2dc"][0, k]), t(m["accc"][0, k]), t(m["oric"][0, k]), first_frame=(i == 0))
+        p = p.clone()
+        p[0] = t(rcm).T @ p[0]
+        tr = t(rcm).T @ tr
+        first = tr.clone() if first is None else first
+        aa = rotation_matrix_to_axis_angle(p).cpu().view(-1)
+        assert out == live.format_unity_packet(aa.tolist(), (tr - first).tolist()), i
