@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Golden vectors for the smplify optimiser by RUNNING THE REFERENCE here.
+
+TEST INFRASTRUCTURE, like capture_reference.py. Extra stand-ins this part of the reference needs:
+  * ``data/dataset_work/gmm_08.pkl``: the external SMPLify prior -> a seeded synthetic GMM (synth.make_gmm).
+  * a contiguous() shim in front of the reference's rotation_matrix_to_axis_angle (torch-2 stride semantics).
+  * ``cv2.Rodrigues`` (OpenCV 4.2, absent): a numpy log-map. It feeds (a) the initial axis-angle parameters and
+    (b) the gradient-dead imu_ori term. PARITY vs OpenCV is therefore UNPINNED for those two conversions; everything
+    downstream (loss, gradient, L-BFGS) is the reference's own code.
+Writes tests/golden/smplify.npz (numbers only).
+"""
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from robustcap_amd import config as C  # noqa: E402
+from robustcap_amd import synth  # noqa: E402
+import capture_reference as cr  # noqa: E402
+
+
+def rodrigues_np(m):
+    m = np.asarray(m, np.float64)
+    if m.shape == (3, 3):
+        return synth._log_map(m[None])[0].astype(np.float32).reshape(3, 1), None
+    return synth._rodrigues(m.reshape(1, 3))[0].astype(np.float32), None
+
+
+def main():
+    body = synth.make_body(cr.BODY_SEED)
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="rc_ref_smplify_")
+    cr._write_body_pickle(os.path.join(tmp, "models", "SMPL_male.pkl"), body)
+    os.makedirs(os.path.join(tmp, "data", "dataset_work"))
+    with open(os.path.join(tmp, "data", "dataset_work", "gmm_08.pkl"), "wb") as f:
+        pickle.dump(synth.make_gmm(3), f)
+    os.chdir(tmp)
+    cr._install_stubs()
+    sys.modules["cv2"].Rodrigues = rodrigues_np
+    sys.path.insert(0, cr.REF)
+    import articulate as art  # noqa
+    # torch >= 2 keeps the strides of an advanced-indexing result through .clone(), which breaks the reference's
+    # ``r.clone().detach().cpu().view(-1, 3, 3)`` (angular.py:244) for ``gp[:, [joint_mask]]``: hand it a contiguous copy.
+    _r2aa = art.math.rotation_matrix_to_axis_angle
+    art.math.rotation_matrix_to_axis_angle = lambda r: _r2aa(r.contiguous())
+    from net.smplify import temporal_smplify as ts
+    from net.smplify import losses
+    from net.smplify.run import smplify_runner
+    import utils as ref_utils
+    t = torch.from_numpy
+    g = {}
+
+    def scene(seed, T):
+        m = synth.make_motion(seed, 1, T, body, conf="high")
+        K = torch.tensor([[1450.0, 0.0, 960.0], [0.0, 1452.0, 540.0], [0.0, 0.0, 1.0]])
+        pose_gt, tran_gt = t(m["pose"][0]), t(m["tran"][0])
+        _, jj, vv = ts.body_model.forward_kinematics(pose_gt, tran=tran_gt, calc_mesh=True)
+        j33 = ref_utils.sync_mp3d_from_smpl(vv, jj)
+        proj = (K @ (j33 / j33[..., 2:]).unsqueeze(-1)).squeeze(-1)[..., :2]
+        kp = torch.cat([proj + 4 * t(synth.normal(seed, 40, T * 66).reshape(T, 33, 2)), t(m["j2dc"][0][..., 2:].copy())], -1)
+        aa = t(synth._log_map(m["pose"][0].astype(np.float64)).astype(np.float32))            # [T,24,3]
+        aa0 = aa + 0.06 * t(synth.normal(seed, 41, T * 72).reshape(T, 24, 3))
+        tr0 = tran_gt + 0.03 * t(synth.normal(seed, 42, T * 3).reshape(T, 3))
+        return m, K, kp, aa0, tr0
+
+    # ---- (1) one evaluation of the optimiser's closure: total loss and its autograd gradient --------------------
+    T = 10
+    m, K, kp, aa0, tr0 = scene(31, T)
+    fit = ts.TemporalSMPLify(cam_k=K, imu_ori=t(m["oric"][0]), step_size=1e-3, batch_size=T)
+    body_pose = aa0.reshape(T, 72).clone().requires_grad_(True)
+    tran = tr0.clone().requires_grad_(True)
+    init_pose = ts.batch_rodrigues(aa0.reshape(-1, 3)).view(T, 24, 3, 3)
+    _, joint, vert = ts.body_model.forward_kinematics(init_pose.detach(), tran=tr0, calc_mesh=True)
+    ref3d = ref_utils.sync_mp3d_from_smpl(vert, joint).detach().clone()
+    # second parameter point (so that the 3D term is non-zero)
+    bp = (body_pose.detach() + 0.02 * t(synth.normal(31, 50, T * 72).reshape(T, 72))).requires_grad_(True)
+    tn = (tran.detach() + 0.01 * t(synth.normal(31, 51, T * 3).reshape(T, 3))).requires_grad_(True)
+    conf = kp[:, :, -1].clone()
+    conf[:, fit.ign_mp_joints] = 0.0
+    pose = ts.batch_rodrigues(bp.view(-1, 3)).view(T, 24, 3, 3)
+    gp, joint, vert = ts.body_model.forward_kinematics(pose=pose, tran=tn, calc_mesh=True)
+    mj = ref_utils.sync_mp3d_from_smpl(vert, joint)
+    loss = losses.temporal_body_fitting_loss(bp, mj, kp[:, :, :2], conf, fit.pose_prior, fit.cam_k, ref3d, fit.imu_ori, gp[:, [ts.joint_mask]])
+    loss.backward()
+    g.update(ev_T=np.int32(T), ev_K=K.numpy(), ev_kp=kp.numpy(), ev_imu_ori=m["oric"][0], ev_ref3d=ref3d.numpy(),
+             ev_pose=bp.detach().numpy(), ev_tran=tn.detach().numpy(), ev_loss=np.float64(loss.item()),
+             ev_grad_pose=bp.grad.numpy().copy(), ev_grad_tran=tn.grad.numpy().copy())
+    prior = fit.pose_prior(bp.detach()[:, 3:], None)
+    g["ev_prior"] = prior.numpy()
+    print("closure: loss %.6g |g_pose| %.4g |g_tran| %.4g" % (loss.item(), bp.grad.abs().max(), tn.grad.abs().max()))
+
+    # ---- (2) the whole runner: pre-check, L-BFGS(20, strong Wolfe), final residual, update mask ------------------
+    T = 16
+    m, K, kp, aa0, tr0 = scene(32, T)
+    pred_pose = ts.batch_rodrigues(aa0.reshape(-1, 3)).view(T, 24, 3, 3)
+    evals = []
+    _orig_loss = ts.temporal_body_fitting_loss
+
+    def _spy(*a, **k):                                    # record every closure evaluation of the optimiser
+        out = _orig_loss(*a, **k)
+        if k.get("output", "sum") == "sum":
+            evals.append(float(out.detach()))
+        return out
+    ts.temporal_body_fitting_loss = _spy
+    pose_o, tran_o, update = smplify_runner(pred_pose.clone(), tr0.clone(), kp.clone(), t(m["oric"][0]), batch_size=T, lr=0.001,
+                                            use_lbfgs=True, opt_steps=1, cam_k=K)
+    before = ts.TemporalSMPLify(cam_k=K, imu_ori=t(m["oric"][0]), batch_size=T).get_fitting_loss(pred_pose.clone(), tr0.clone(), kp.clone())
+    after = ts.TemporalSMPLify(cam_k=K, imu_ori=t(m["oric"][0]), batch_size=T).get_fitting_loss(pose_o.clone(), tran_o.clone(), kp.clone())
+    g.update(run_T=np.int32(T), run_K=K.numpy(), run_kp=kp.numpy(), run_imu_ori=m["oric"][0], run_pose0=pred_pose.numpy(),
+             run_tran0=tr0.numpy(), run_pose=pose_o.numpy(), run_tran=tran_o.numpy(), run_update=update.numpy(),
+             run_loss_before=before.numpy(), run_loss_after=after.numpy(), run_closure_losses=np.asarray(evals, np.float64))
+    ts.temporal_body_fitting_loss = _orig_loss
+    print("closure evaluations:", len(evals), ["%.6g" % v for v in evals[:6]], "...", "%.6g" % evals[-1])
+    print("runner: residual mean %.4g -> %.4g, updated %d/%d frames, |dpose| %.3g |dtran| %.3g" % (
+        before.mean(), after.mean(), int(update.sum()), T, (pose_o - pred_pose).abs().max(), (tran_o - tr0).abs().max()))
+    np.savez_compressed(os.path.join(cr.OUT, "smplify.npz"), **g)
+
+
+if __name__ == "__main__":
+    main()

@@ -308,3 +308,14 @@ def make_dataset(seed, n_seq, T, body, n_cam=3, conf="mixed", image_size=(1920, 
         ds["cam_T"].append(np.stack(Ts).astype(np.float32))
         ds["joint2d_mp"].append(np.stack(kps).astype(np.float32))
     return ds
+
+
+# ------------------------------------------------------------------------------------------------- smplify prior
+def make_gmm(seed=3, n=8, dim=69):
+    """Synthetic stand-in for the SMPLify pose prior ``gmm_08.pkl`` (external asset; net/smplify/prior.py:102-111 reads
+    a dict with 'means' [n,dim], 'covars' [n,dim,dim], 'weights' [n]): seeded means, low-rank + diagonal SPD covariances."""
+    means = 0.2 * normal(seed, 1, n * dim).reshape(n, dim).astype(np.float64)
+    Bm = 0.15 * normal(seed, 2, n * dim * 6).reshape(n, dim, 6).astype(np.float64)
+    covars = Bm @ np.swapaxes(Bm, 1, 2) + (0.08 ** 2) * np.eye(dim)[None]
+    w = uniform01(seed, 3, n).astype(np.float64) + 0.5
+    return {"means": means, "covars": covars, "weights": w / w.sum()}
