@@ -146,6 +146,49 @@ int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert,
 int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K,
                        float sigma, float* loss, int64_t T, void* stream);
 
+/* ---- smplify optimiser ------------------------------------------------------
+ * Replaces net/smplify/run.py:6-34 (smplify_runner) -> temporal_smplify.py:97-196 (TemporalSMPLify.__call__):
+ * L-BFGS (torch.optim.LBFGS, strong Wolfe) over [body_pose (T*72 axis-angle), tran (T*3)] of the whole sequence on
+ * temporal_body_fitting_loss (net/smplify/losses.py:23-87). Loss and analytic gradient run on the device
+ * (rc_smplify.hip), the line-search scalars on the host. */
+
+/* GMM pose prior of MaxMixturePrior (net/smplify/prior.py:102-147): HOST means[8,69], precisions[8,69,69]
+ * (inverse covariances) and nll_weights[8] (the weights already divided by the determinant term, prior.py:137-141). */
+int rc_smplify_set_prior(rc_ctx* ctx, const float* means_host, const float* precisions_host, const float* nll_weights_host);
+
+/* One closure evaluation (temporal_smplify.py:150-166): x DEVICE [T*72 | T*3] flat parameter vector, kp[T,33,3]
+ * pixels + confidence, ref3d[T,33,3] landmarks of the initial prediction, imu_aa[T,18] axis-angle of the IMU
+ * orientations (all DEVICE), K[3,3] HOST. Writes the total loss (HOST double) and grad DEVICE [T*72 | T*3].
+ * Synchronises `stream`. */
+int rc_smplify_loss_grad(rc_ctx* ctx, const float* x, const float* kp, const float* ref3d, const float* imu_aa,
+                         const float* K_host, int64_t T, double* loss_host, float* grad, void* stream);
+
+typedef struct rc_smplify_info {
+    int32_t status;          /* 0: rejected by the pre-check (run.py:27-29), 1: optimised */
+    int32_t n_iter, n_eval;  /* L-BFGS iterations / closure evaluations */
+    int32_t reserved;
+    double first_loss, final_loss;   /* closure value at the prediction / at the accepted point */
+    double host_ms, device_ms;       /* wall time of the call / HIP-event time of the closure evaluations */
+} rc_smplify_info;
+
+/* smplify_runner(pred_pose, pred_tran, j2dc, imu_ori, batch_size=T, cam_k, lr, opt_steps=1, use_lbfgs=True,
+ * loss_threshold): pose[T,24,3,3] local rotations, tran[T,3], kp[T,33,3], imu_ori[T,6,3,3] DEVICE; K HOST.
+ * Outputs pose_out / tran_out DEVICE (the inputs copied through when the pre-check rejects the sequence) and
+ * update HOST uint8[T] (new per-frame mean residual < old; all zero when rejected -- the reference returns None,
+ * see info->status). max_iter = 20 and max_eval = 25 are torch's defaults the reference leaves untouched. */
+int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* imu_ori,
+                   const float* K_host, int64_t T, float lr, int32_t max_iter, float loss_threshold, float* pose_out,
+                   float* tran_out, uint8_t* update_host, rc_smplify_info* info, void* stream);
+
+/* The optimiser alone, in float64, on a caller-supplied objective (HOST): same algorithm object as rc_smplify_run
+ * with Real = double. tests/ pin it against torch.optim.LBFGS evaluation by evaluation. objective returns the loss
+ * at x[n] and fills grad[n]. x is updated in place; losses_out (capacity cap) receives every objective value in
+ * evaluation order. */
+typedef double (*rc_objective_fn)(void* user, const double* x, double* grad, int64_t n);
+int rc_lbfgs_minimize(rc_objective_fn objective, void* user, int64_t n, double* x, double lr, int32_t max_iter,
+                      int32_t max_eval, int32_t history_size, double tolerance_grad, double tolerance_change,
+                      int32_t* n_iter_out, int32_t* n_eval_out, double* losses_out, int64_t cap);
+
 /* Harness input preparation of evaluate.py:38-51,70-73 for ONE (sequence, camera) of n frames:
  *   j2dc = K^-1 [u, v, 1] with the confidence copied into the last channel, accc = R_cw acc_w, oric = R_cw ori_w,
  *   gravity_out (HOST float[3]) = R_cw [0, -1, 0].

@@ -23,6 +23,14 @@ class RcParams(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class RcSmplifyInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_iter", C.c_int32), ("n_eval", C.c_int32), ("reserved", C.c_int32),
+                ("first_loss", C.c_double), ("final_loss", C.c_double), ("host_ms", C.c_double), ("device_ms", C.c_double)]
+
+
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+
+
 class RobustcapLibraryError(RuntimeError):
     pass
 
@@ -55,6 +63,11 @@ SIGNATURES = {
     "rc_body_mesh": (_I32, [_P, _P, _P, _P, _I64, _P]),
     "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),
     "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
+    "rc_smplify_set_prior": (_I32, [_P, _P, _P, _P]),
+    "rc_smplify_loss_grad": (_I32, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_double), _P, _P]),
+    "rc_smplify_run": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _F, _I32, _F, _P, _P, _P, C.POINTER(RcSmplifyInfo), _P]),
+    "rc_lbfgs_minimize": (_I32, [OBJECTIVE_FN, _P, _I64, C.POINTER(C.c_double), C.c_double, _I32, _I32, _I32, C.c_double,
+                                 C.c_double, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(C.c_double), _I64]),
     "rc_camera_inputs": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "rc_get_state": (_I32, [_P, C.c_char_p, _P, _P, _P]),
     "rc_get_trace": (_I32, [_P, _P, _P]),

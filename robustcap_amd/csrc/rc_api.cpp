@@ -78,6 +78,7 @@ struct rc_ctx {
     size_t ev_used = 0;
     double timed_ms = 0.0;
     long long timed_launches = 0;
+    SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
 };
 
 namespace {
@@ -345,6 +346,10 @@ int check_ready(rc_ctx* ctx) {
 }  // namespace
 
 // =============================================================================================== C ABI
+const BodyConst* rc_ctx_body(rc_ctx* ctx) { return ctx->have_body ? ctx->body : nullptr; }
+int rc_ctx_fail(rc_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg); }
+SmplifyState*& rc_ctx_smplify(rc_ctx* ctx) { return ctx->smplify; }
+
 extern "C" {
 
 int rc_default_params(int32_t live, rc_params* out) {
@@ -413,6 +418,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
 int rc_destroy(rc_ctx* ctx) {
     if (!ctx) return RC_OK;
     rc_live_end(ctx);
+    rc_smplify_free(ctx->smplify);
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;

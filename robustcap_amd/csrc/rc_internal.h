@@ -151,3 +151,34 @@ void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w,
                          float* vert, long long n, hipStream_t s);
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
                         float sigma, float* loss, long long T, hipStream_t s);
+
+// smplify optimiser (rc_smplify.hip): one evaluation = loss terms + analytic gradient of all T frames
+struct SmplifyArgs {
+    const float* aa;        // [T,72] axis-angle (root first)
+    const float* tran;      // [T,3]
+    const float* kp;        // [T,33,3] pixels + confidence (ignored landmarks count as 0)
+    const float* ref3d;     // [T,33,3] landmarks of the initial prediction
+    const float* imu_aa;    // [T,18] axis-angle of the measured IMU orientations
+    const float* means;     // [8,69]
+    const float* prec;      // [8,69,69]
+    const float* lognll;    // [8] log(nll_weights)
+    float* mj;              // [T,33,3] out (fwd) / in (grad)
+    float* proj;            // [T,33,2]
+    float* frame_loss;      // [T] reprojection + prior + angle + 3D of frame t
+    float* imu_loss;        // [T] 0.25 * |aa(imu) - aa(G[ji])|^2
+    float* smooth_loss;     // [T] smoothness terms of the pair (t-1, t)
+    int* argmin;            // [T] mixture component of the prior
+    float* grad_aa;         // [T,72]  } one flat vector [T*72 | T*3], the optimiser's parameter order
+    float* grad_tran;       // [T,3]   } (temporal_smplify.py:141: [body_pose, tran])
+    float K[9];
+    int T;
+};
+void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t s);
+
+// narrow view of the context for rc_smplify_api.cpp (the struct itself lives in rc_api.cpp)
+struct rc_ctx;
+struct SmplifyState;
+const BodyConst* rc_ctx_body(rc_ctx* ctx);                 // nullptr until rc_set_body
+int rc_ctx_fail(rc_ctx* ctx, int code, const char* msg);   // records the message, returns code
+SmplifyState*& rc_ctx_smplify(rc_ctx* ctx);
+void rc_smplify_free(SmplifyState* s);

@@ -1,43 +1,120 @@
-"""smplify forward residual on the GPU: the pre-check of ``smplify_runner`` (net/smplify/run.py:6-34).
+"""smplify on the GPU: the optimiser the reference's evaluate.py runs on every sequence (evaluate.py:89).
 
-What is built: ``TemporalSMPLify.get_fitting_loss`` ->
-``temporal_body_fitting_loss(output='reprojection')`` (temporal_smplify.py:198-220, losses.py:36-37,43-46) as
-one wave-per-frame HIP kernel (rc_reproj_residual), and the gate ``mean_k loss[0] > loss_threshold`` (run.py:27-29).
-
-What is NOT built yet (section 8(f) rank 1): the L-BFGS optimiser behind the gate (temporal_smplify.py:97-196).
-``smplify_runner`` therefore returns the network prediction unchanged with ``update`` all-False when the gate
-lets the sequence through, and -- exactly like the reference -- ``update=None`` when the gate rejects it.
+Mirrors ``net/smplify/run.py:smplify_runner`` and ``net/smplify/temporal_smplify.py:TemporalSMPLify``:
+  * ``get_fitting_loss`` -> ``temporal_body_fitting_loss(output='reprojection')`` (temporal_smplify.py:198-220,
+    losses.py:36-37,43-46): one wave-per-frame HIP kernel (rc_reproj_residual);
+  * ``__call__`` (temporal_smplify.py:97-196): L-BFGS with a strong-Wolfe line search over the axis-angle pose and the
+    translation of the WHOLE sequence. The closure (loss + analytic gradient) is two HIP kernels with one workgroup
+    per frame (csrc/rc_smplify.hip); the optimiser logic is csrc/rc_lbfgs.h, a restatement of torch.optim.LBFGS;
+  * the gate ``mean_k loss[0] > loss_threshold`` and the per-frame ``update`` mask (run.py:24-34).
+Everything numerical is in librobustcap_hip.so; this file prepares constants and marshals pointers.
 """
+import ctypes as C
+import pickle
+
+import numpy as np
 import torch
 
+from . import _lib
 from . import body as _body
 
 
-class ResidualRunner:
-    """Holds the body constants on the device; ``get_fitting_loss`` mirrors the reference method."""
+def load_gmm_pickle(path):
+    """gmm_08.pkl of the reference (net/smplify/prior.py:118-123): dict with means, covars, weights."""
+    with open(path, "rb") as f:
+        return pickle.load(f, encoding="latin1")
 
-    def __init__(self, body=None, smpl_file=None, device="cuda"):
+
+def prior_arrays(gmm):
+    """(means[8,69], precisions[8,69,69], nll_weights[8]) as float32, the buffers MaxMixturePrior registers
+    (net/smplify/prior.py:124-147): precisions = inv(covars), nll_weights = weights / (c * sqrt(det) / min sqrt(det))."""
+    means = np.asarray(gmm["means"], dtype=np.float32)
+    covs = np.asarray(gmm["covars"], dtype=np.float32)
+    w = np.asarray(gmm["weights"])
+    prec = np.stack([np.linalg.inv(c) for c in covs]).astype(np.float32)
+    sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in np.asarray(gmm["covars"])])
+    const = (2 * np.pi) ** (69 / 2.0)
+    nllw = np.asarray(w / (const * (sqrdets / sqrdets.min())), dtype=np.float32)
+    if means.shape != (8, 69) or prec.shape != (8, 69, 69) or nllw.shape != (8,):
+        raise ValueError("the pose prior must have 8 components of dimension 69")
+    return np.ascontiguousarray(means), np.ascontiguousarray(prec), np.ascontiguousarray(nllw)
+
+
+class TemporalSMPLify:
+    """Device-side optimiser state: body constants, pose prior, work buffers (reused across sequences)."""
+
+    def __init__(self, body=None, smpl_file=None, gmm=None, gmm_file=None, device="cuda"):
         self.model = _body.ParametricModel(smpl_file, device=device, body=body)
+        self.device = self.model.device
+        self._lib, self._ctx = self.model._lib, self.model._ctx
+        self.has_prior = False
+        if gmm is not None or gmm_file is not None:
+            self.set_prior(gmm if gmm is not None else load_gmm_pickle(gmm_file))
+        self.last_info = None
+
+    def set_prior(self, gmm):
+        means, prec, nllw = prior_arrays(gmm)
+        rc = self._lib.rc_smplify_set_prior(self._ctx, means.ctypes.data_as(C.c_void_p), prec.ctypes.data_as(C.c_void_p),
+                                            nllw.ctypes.data_as(C.c_void_p))
+        _lib.check(self._ctx, rc, "rc_smplify_set_prior")
+        self.has_prior = True
 
     def get_fitting_loss(self, pose, tran, keypoints_2d, cam_k, sigma=100.0):
         return self.model.reprojection_residual(pose, tran, keypoints_2d, cam_k, sigma)
 
+    def loss_and_grad(self, body_pose, tran, keypoints_2d, ref3d, imu_aa, cam_k):
+        """One closure evaluation (temporal_smplify.py:150-166). body_pose [T,72] axis-angle, tran [T,3],
+        keypoints_2d [T,33,3], ref3d [T,33,3], imu_aa [T,18]. Returns (loss float, grad_pose [T,72], grad_tran [T,3])."""
+        dev = self.device
+        T = body_pose.shape[0]
+        x = torch.cat([_body._f32c(body_pose, dev).reshape(-1), _body._f32c(tran, dev).reshape(-1)]).contiguous()
+        kp, ref, imu = (_body._f32c(a, dev) for a in (keypoints_2d, ref3d, imu_aa))
+        K = np.ascontiguousarray(torch.as_tensor(cam_k).detach().cpu().numpy(), dtype=np.float32).reshape(9)
+        grad = torch.empty_like(x)
+        loss = C.c_double()
+        rc = self._lib.rc_smplify_loss_grad(self._ctx, _lib.ptr(x), _lib.ptr(kp), _lib.ptr(ref), _lib.ptr(imu),
+                                            K.ctypes.data_as(C.c_void_p), T, C.byref(loss), _lib.ptr(grad), _lib.stream_ptr())
+        _lib.check(self._ctx, rc, "rc_smplify_loss_grad")
+        return loss.value, grad[:T * 72].view(T, 72), grad[T * 72:].view(T, 3)
+
+    def run(self, pose, tran, keypoints_2d, imu_ori, cam_k, lr=1.0, max_iter=20, loss_threshold=20000):
+        """Pre-check + optimise + update mask on the device. Returns (pose [T,24,3,3], tran [T,3], update | None)
+        as device tensors / a bool host tensor."""
+        dev = self.device
+        pose = _body._f32c(pose, dev).view(-1, 24, 3, 3)
+        T = pose.shape[0]
+        tran, kp, ori = _body._f32c(tran, dev).view(T, 3), _body._f32c(keypoints_2d, dev).view(T, 33, 3), _body._f32c(imu_ori, dev).view(T, 6, 3, 3)
+        K = np.ascontiguousarray(torch.as_tensor(cam_k).detach().cpu().numpy(), dtype=np.float32).reshape(9)
+        pose_out, tran_out = torch.empty_like(pose), torch.empty_like(tran)
+        update = np.zeros(T, dtype=np.uint8)
+        info = _lib.RcSmplifyInfo()
+        rc = self._lib.rc_smplify_run(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(kp), _lib.ptr(ori), K.ctypes.data_as(C.c_void_p),
+                                      T, C.c_float(lr), int(max_iter), C.c_float(loss_threshold), _lib.ptr(pose_out), _lib.ptr(tran_out),
+                                      update.ctypes.data_as(C.c_void_p), C.byref(info), _lib.stream_ptr())
+        _lib.check(self._ctx, rc, "rc_smplify_run")
+        self.last_info = {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+        return pose_out, tran_out, (torch.from_numpy(update.astype(bool)) if info.status == 1 else None)
+
+
+ResidualRunner = TemporalSMPLify        # earlier name of the residual-only object
+
 
 def smplify_runner(pred_pose, pred_tran, j2dc, imu_ori, batch_size, cam_k, lr=1.0, opt_steps=1, use_lbfgs=True,
-                   loss_threshold=20000, shape=None, use_head=False, runner=None, body=None):
+                   loss_threshold=20000, shape=None, use_head=False, runner=None, body=None, gmm=None):
     """Same signature and return convention as net/smplify/run.py:smplify_runner.
 
-    pred_pose [T,24,3,3], pred_tran [T,3], j2dc [T,33,3] in pixels, cam_k [3,3]. Returns
-    (pose [T,24,3,3] cpu, tran [T,3] cpu, update) with update None if the sequence failed the pre-check."""
+    pred_pose [T,24,3,3], pred_tran [T,3], j2dc [T,33,3] in pixels, imu_ori [T,6,3,3] in the camera frame,
+    cam_k [3,3]. Returns (pose [T,24,3,3] cpu, tran [T,3] cpu, update) with update None if the sequence failed the
+    pre-check. ``runner`` (a TemporalSMPLify with the prior set) is reused across calls; otherwise ``body`` and
+    ``gmm`` build one."""
     if shape is not None or use_head:
         raise NotImplementedError("shape / use_head variants are outside the built path (mean shape, ignored head landmarks)")
-    runner = runner or ResidualRunner(body=body)
+    if not use_lbfgs or opt_steps != 1:
+        raise NotImplementedError("the reference only runs use_lbfgs=True, opt_steps=1 (evaluate.py:89)")
+    runner = runner or TemporalSMPLify(body=body, gmm=gmm)
+    if not runner.has_prior:
+        raise _lib.RobustcapLibraryError("smplify_runner needs the GMM pose prior (gmm= or TemporalSMPLify.set_prior)")
     T = int(batch_size)
-    pose = pred_pose.reshape(T, 24, 3, 3)
-    tran = pred_tran.reshape(T, 3)
-    loss = runner.get_fitting_loss(pose, tran, j2dc.reshape(T, 33, 3), cam_k)       # [T,33] on the device
-    opt_joint_loss = loss.mean(dim=-1)
-    if float(opt_joint_loss[0].cpu()) > loss_threshold:                               # run.py:27-29
-        return pose.cpu().reshape(-1, 24, 3, 3), tran.cpu().reshape(-1, 3), None
-    update = torch.zeros(T, dtype=torch.bool)                                         # optimiser not built: nothing improves
+    pose, tran, update = runner.run(pred_pose.reshape(T, 24, 3, 3), pred_tran.reshape(T, 3), j2dc.reshape(T, 33, 3),
+                                    imu_ori.reshape(T, 6, 3, 3), cam_k, lr=lr, loss_threshold=loss_threshold)
     return pose.cpu().reshape(-1, 24, 3, 3), tran.cpu().reshape(-1, 3), update

@@ -99,17 +99,3 @@ def test_config4_occluded_batch_1024(synth_assets):
     half = _net(synth_assets, 512)
     ph, th = _run(half, m, rows=slice(512, 1024), first_tran=False)
     assert torch.equal(ph, pose[512:]) and torch.equal(th, tran[512:])
-
-
-def test_smplify_runner_gate(synth_assets):
-    from robustcap_amd.smplify import ResidualRunner, smplify_runner
-    import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
-    runner = ResidualRunner(body=synth_assets["body"])
-    T = g["res_pose"].shape[0]
-    args = (t(g["res_pose"]), t(g["res_tran"]), t(g["res_kp"]), None, T, t(g["res_K"]))
-    pose, tran, update = smplify_runner(*args, runner=runner)
-    assert update is not None and update.shape == (T,) and not update.any()              # gate passed (optimiser: next round)
-    assert float(g["res_gate_frame0_mean"]) < 20000
-    pose, tran, update = smplify_runner(*args, runner=runner, loss_threshold=float(g["res_gate_frame0_mean"]) - 1.0)
-    assert update is None and torch.equal(pose, t(g["res_pose"]))                        # rejected: input returned unchanged

@@ -1,0 +1,141 @@
+"""smplify optimiser on the GPU against the reference capture and the oracle.
+
+tests/golden/smplify.npz holds, from the reference itself (oracle/capture_smplify.py): loss and gradient of the
+closure at one point (ev_*) and one full smplify_runner call (run_*)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sig_mp_oracle as O
+from oracle import smplify_oracle as S
+from robustcap_amd import config as C
+from robustcap_amd import synth
+
+pytestmark = pytest.mark.gpu
+t = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "smplify.npz"))
+
+
+@pytest.fixture(scope="module")
+def runner(synth_assets):
+    from robustcap_amd.smplify import TemporalSMPLify
+    return TemporalSMPLify(body=synth_assets["body"], gmm=synth.make_gmm(3))
+
+
+def _imu_aa(ori):
+    return O.rotation_matrix_to_axis_angle(ori.reshape(-1, 3, 3)).reshape(ori.shape[0], 18)
+
+
+def test_closure_matches_reference_capture(g, runner):
+    """Loss to 1e-5 relative and gradient to 1e-4 of its scale against the reference's own autograd through the
+    6890-vertex mesh (the same bars tests/test_smplify_oracle.py holds the oracle to)."""
+    loss, gp, gt = runner.loss_and_grad(t(g["ev_pose"]), t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_ref3d"]), _imu_aa(t(g["ev_imu_ori"])),
+                                        t(g["ev_K"]))
+    assert abs(loss - float(g["ev_loss"])) <= 1e-5 * abs(float(g["ev_loss"]))
+    gs = max(np.abs(g["ev_grad_pose"]).max(), np.abs(g["ev_grad_tran"]).max())
+    assert float((gp.cpu() - t(g["ev_grad_pose"])).abs().max()) <= 1e-4 * gs
+    assert float((gt.cpu() - t(g["ev_grad_tran"])).abs().max()) <= 1e-4 * gs
+
+
+@pytest.mark.parametrize("T,seed", [(1, 5), (2, 6), (37, 7)])
+def test_closure_matches_oracle(T, seed, synth_assets, runner):
+    """Seeded poses away from the capture, including T=1 (no temporal terms) and a ragged length."""
+    body = synth_assets["body"]
+    obody, prior = O.OracleBody(body), S.Prior(synth.make_gmm(3))
+    rnd = lambda stream, *shape: synth.normal(seed, stream, int(np.prod(shape))).reshape(shape).astype(np.float32)
+    bp = t(0.35 * rnd(0, T, 72))
+    tr = t((np.array([0.1, -0.2, 3.0], np.float32) + 0.2 * rnd(1, T, 3)).astype(np.float32))
+    K = torch.tensor([[600.0, 0.0, 320.0], [0.0, 600.0, 240.0], [0.0, 0.0, 1.0]])
+    with torch.no_grad():
+        pose = S.batch_rodrigues(bp.view(-1, 3)).view(T, 24, 3, 3)
+        _, joint, vert = obody.forward_kinematics(pose, tr)
+        mj = obody.landmarks(vert, joint)
+        proj = (K @ (mj / mj[..., 2:]).unsqueeze(-1)).squeeze(-1)[..., :2]
+    kp = torch.cat([proj + 25.0 * t(rnd(2, T, 33, 2)), t(synth.uniform01(seed, 3, T * 33).reshape(T, 33, 1))], dim=-1)
+    ref3d = mj + 0.05 * t(rnd(4, T, 33, 3))
+    imu_ori = S.batch_rodrigues(t(0.5 * rnd(5, T * 6, 3))).view(T, 6, 3, 3)
+    conf = kp[:, :, 2].clone()
+    conf[:, list(C.smplify_ignored_landmarks)] = 0.0
+    a, b = bp.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    want = S.fitting_loss(obody, prior, a, b, kp[:, :, :2], conf, K, ref3d, imu_ori)
+    want.backward()
+    loss, gp, gt = runner.loss_and_grad(bp, tr, kp, ref3d, _imu_aa(imu_ori), K)
+    assert abs(loss - float(want)) <= 2e-5 * abs(float(want))
+    gs = float(max(a.grad.abs().max(), b.grad.abs().max()))
+    assert float((gp.cpu() - a.grad).abs().max()) <= 2e-4 * gs
+    assert float((gt.cpu() - b.grad).abs().max()) <= 2e-4 * gs
+
+
+def test_runner_against_reference_run(g, runner, synth_assets):
+    """Same bars as the oracle's own pin (tests/test_smplify_oracle.py): L-BFGS trajectories separate after a few
+    evaluations in float32, so the end state is compared through the pre-check, the evaluation budget, the update mask
+    and the size of the improvement."""
+    from robustcap_amd.smplify import smplify_runner
+    T = int(g["run_T"])
+    pose, tran, update = smplify_runner(t(g["run_pose0"]), t(g["run_tran0"]), t(g["run_kp"]), t(g["run_imu_ori"]), T, t(g["run_K"]),
+                                        lr=0.001, runner=runner)
+    info = runner.last_info
+    ref = g["run_closure_losses"]
+    assert info["status"] == 1 and info["n_eval"] == len(ref) == 26
+    assert abs(info["first_loss"] - ref[0]) <= 1e-5 * ref[0]
+    assert info["final_loss"] < 0.45 * info["first_loss"] and ref[-1] < 0.45 * ref[0]
+    assert update is not None and np.array_equal(update.numpy(), g["run_update"])
+    ob = O.OracleBody(synth_assets["body"])
+    after = float(O.reprojection_residual(ob, pose, tran, t(g["run_kp"]), t(g["run_K"])).mean())
+    before = float(g["run_loss_before"].mean())
+    assert after < 0.4 * before and float(g["run_loss_after"].mean()) < 0.4 * before
+    assert abs(after - float(g["run_loss_after"].mean())) < 0.15 * before            # same range as the reference's end state
+    # rotation matrices out, orthonormal
+    eye = torch.eye(3).expand(T, 24, 3, 3)
+    assert float((pose @ pose.transpose(-1, -2) - eye).abs().max()) < 1e-5
+
+
+def test_runner_gate_and_errors(g, runner, synth_assets):
+    from robustcap_amd import _lib
+    from robustcap_amd.smplify import TemporalSMPLify, smplify_runner
+    T = int(g["run_T"])
+    args = (t(g["run_pose0"]), t(g["run_tran0"]), t(g["run_kp"]), t(g["run_imu_ori"]), T, t(g["run_K"]))
+    gate = float(g["run_loss_before"][0].mean())
+    pose, tran, update = smplify_runner(*args, lr=0.001, runner=runner, loss_threshold=gate - 1.0)   # run.py:27-29
+    assert update is None and runner.last_info["status"] == 0
+    assert torch.equal(pose, t(g["run_pose0"])) and torch.equal(tran, t(g["run_tran0"]))
+    no_prior = TemporalSMPLify(body=synth_assets["body"])
+    with pytest.raises(_lib.RobustcapLibraryError):
+        smplify_runner(*args, runner=no_prior)
+    with pytest.raises(_lib.RobustcapLibraryError):
+        no_prior.loss_and_grad(t(g["ev_pose"]), t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_ref3d"]), torch.zeros(10, 18), t(g["ev_K"]))
+    res = runner.get_fitting_loss(t(g["run_pose0"]), t(g["run_tran0"]), t(g["run_kp"]), t(g["run_K"]))
+    assert float((res.cpu() - t(g["run_loss_before"])).abs().max()) <= 1e-4 * float(g["run_loss_before"].max())
+
+
+def test_long_sequence_improves(runner, synth_assets):
+    """A 600-frame sequence (the reference optimises whole sequences at once): the loss falls and the work buffers
+    grow past the earlier calls."""
+    body = synth_assets["body"]
+    m = synth.make_motion(11, 1, 600, body, conf="high")
+    K = torch.tensor([[600.0, 0.0, 320.0], [0.0, 600.0, 240.0], [0.0, 0.0, 1.0]])
+    obody = O.OracleBody(body)
+    pose = t(np.asarray(m["pose"][0], np.float32))
+    tran = t(np.asarray(m["tran"][0], np.float32))
+    with torch.no_grad():
+        _, joint, vert = obody.forward_kinematics(pose, tran)
+        mj = obody.landmarks(vert, joint)
+        proj = (K @ (mj / mj[..., 2:]).unsqueeze(-1)).squeeze(-1)[..., :2]
+    kp = torch.cat([proj, torch.full((600, 33, 1), 0.9)], dim=-1)
+    noisy = O.axis_angle_to_rotation_matrix((0.05 * t(synth.normal(12, 0, 600 * 24 * 3).reshape(-1, 3)))).view(600, 24, 3, 3)
+    pose0 = pose @ noisy
+    gp, _, _ = obody.forward_kinematics(pose0, tran)
+    imu_ori = gp[:, list(C.ji_mask)]
+    p, tr, update = runner.run(pose0, tran + 0.02, kp, imu_ori, K, lr=0.001)
+    info = runner.last_info
+    assert info["status"] == 1 and info["n_eval"] == 26 and info["final_loss"] < 0.95 * info["first_loss"]
+    assert update is not None and int(update.sum()) > 540                            # nearly every frame re-projects better
+    before = float(O.reprojection_residual(obody, pose0, tran + 0.02, kp, K).mean())
+    after = float(O.reprojection_residual(obody, p.cpu(), tr.cpu(), kp, K).mean())
+    assert after < 0.6 * before
