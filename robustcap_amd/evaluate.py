@@ -63,9 +63,15 @@ def labels(dataset, i, j, device="cuda"):
     return pose, tran
 
 
-def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda"):
+def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda",
+                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080)):
     """Run every (sequence, camera) row of ``dataset`` (or the given subset) through the net; rows are sharded over
-    the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU."""
+    the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU.
+
+    run_smplify=True refines every row with the smplify optimiser exactly where evaluate.py:86-90 does: after the
+    net, on the pixel keypoints and the camera-frame IMU orientations of that row, lr=0.001, and -- like the reference
+    -- takes the optimised pose and translation whether or not ``update`` says they improved. ``gmm`` is the pose
+    prior (dict means/covars/weights); ``smplify_info`` (a dict) receives the per-row optimiser records."""
     all_rows = rows_of(dataset) if rows is None else list(rows)
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -84,7 +90,7 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
         for r, (i, j) in enumerate(mine):
             T = len(dataset["pose"][i])
             k, ac, orc, g = camera_inputs(dataset["joint2d_mp"][i][j], dataset["imu_acc"][i], dataset["imu_ori"][i],
-                                          dataset["cam_K"][i][j], dataset["cam_T"][i][j], device=device)
+                                          dataset["cam_K"][i][j], dataset["cam_T"][i][j], image_size=image_size, device=device)
             j2d[r, :T], acc[r, :T], ori[r, :T], grav[r] = k, ac, orc, g
             ft[r] = labels(dataset, i, j, device)[1][0]                    # first_tran = label translation of frame 0
         net = Net(body=body, batch=n, device=device)
@@ -92,6 +98,20 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)
+        if run_smplify:
+            from .smplify import TemporalSMPLify
+            runner = TemporalSMPLify(body=body, gmm=gmm, device=device)
+            if not runner.has_prior:
+                raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")
+            for r, (i, j) in enumerate(mine):
+                T = len(dataset["pose"][i])
+                kp_pix = torch.as_tensor(dataset["joint2d_mp"][i][j], dtype=torch.float32).clone()
+                kp_pix[..., 0] *= image_size[0]                              # the pixels evaluate.py:43-44 builds, :87 passes on
+                kp_pix[..., 1] *= image_size[1]
+                p, t, _ = runner.run(out_p[r, :T], out_t[r, :T], kp_pix, ori[r, :T], dataset["cam_K"][i][j], lr=0.001)
+                out_p[r, :T], out_t[r, :T] = p, t
+                if smplify_info is not None:
+                    smplify_info[(i, j)] = dict(runner.last_info)
     del pose_all
     if world > 1:                                                       # the path's only collective
         cap_p = rdist.gather_rows(out_p[:n].reshape(n, -1), len(all_rows))

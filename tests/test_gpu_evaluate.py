@@ -87,3 +87,33 @@ def test_full_mesh_and_cal_mpjpe(synth_assets):
     Jr[np.arange(17), np.arange(17) * 400] = 1.0                                              # a stand-in regressor
     r = ev.cal_mpjpe(model, rot, pose, j_regressor=Jr)
     assert len(r) == 2 and r[0] > 0.0
+
+
+def test_run_dataset_with_smplify(synth_assets):
+    """evaluate.py:86-90: every row refined by the optimiser after the net; each row must equal a direct
+    smplify_runner call on that row's net output, and re-project better than the net output does."""
+    from robustcap_amd import synth
+    from robustcap_amd import evaluate as ev
+    from robustcap_amd.smplify import TemporalSMPLify, smplify_runner
+    body, sd, gmm = synth_assets["body"], synth_assets["state_dict"], synth.make_gmm(3)
+    ds = synth.make_dataset(8, 1, 24, body, n_cam=2, conf="high")
+    plain = ev.run_dataset(ds, sd, body)
+    info = {}
+    opt = ev.run_dataset(ds, sd, body, run_smplify=True, gmm=gmm, smplify_info=info)
+    runner = TemporalSMPLify(body=body, gmm=gmm)
+    with pytest.raises(ValueError):
+        ev.run_dataset(ds, sd, body, run_smplify=True)
+    for (i, j) in plain:
+        kp = torch.as_tensor(ds["joint2d_mp"][i][j], dtype=torch.float32).clone()
+        kp[..., 0] *= 1920
+        kp[..., 1] *= 1080
+        _, _, oric, _ = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])
+        K = torch.as_tensor(ds["cam_K"][i][j], dtype=torch.float32)
+        p, tr, update = smplify_runner(plain[(i, j)][0], plain[(i, j)][1], kp, oric, 24, K, lr=0.001, runner=runner)
+        st = info[(i, j)]["status"]
+        assert st == runner.last_info["status"]
+        assert torch.equal(p, opt[(i, j)][0]) and torch.equal(tr, opt[(i, j)][1])          # deterministic: same launches, same host search
+        if st == 1:
+            before = float(runner.get_fitting_loss(plain[(i, j)][0], plain[(i, j)][1], kp, K).mean())
+            after = float(runner.get_fitting_loss(p, tr, kp, K).mean())
+            assert after < before and info[(i, j)]["n_eval"] <= 26

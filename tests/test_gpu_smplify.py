@@ -66,7 +66,7 @@ def test_closure_matches_oracle(T, seed, synth_assets, runner):
     want = S.fitting_loss(obody, prior, a, b, kp[:, :, :2], conf, K, ref3d, imu_ori)
     want.backward()
     loss, gp, gt = runner.loss_and_grad(bp, tr, kp, ref3d, _imu_aa(imu_ori), K)
-    assert abs(loss - float(want)) <= 2e-5 * abs(float(want))
+    assert abs(loss - float(want.detach())) <= 2e-5 * abs(float(want.detach()))
     gs = float(max(a.grad.abs().max(), b.grad.abs().max()))
     assert float((gp.cpu() - a.grad).abs().max()) <= 2e-4 * gs
     assert float((gt.cpu() - b.grad).abs().max()) <= 2e-4 * gs
