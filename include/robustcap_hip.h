@@ -140,6 +140,20 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
  * pose[n,24,3,3] local, tran[n,3] -> vert[n,V,3]. */
 int rc_set_mesh(rc_ctx* ctx, const float* v_template_host, const float* weights_host, int32_t V);
 int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert, int64_t n, void* stream);
+/* Metrics of evaluate.py:120-133 (cal_mpjpe) fused on the device: both meshes skinned with zero translation,
+ * keypoints = J_regressor[:n_used] . vertices (rc_set_regressor: HOST [n_rows,V] row-major, n_used = 14 in the
+ * reference; without a regressor the 24 SMPL joints stand in), pelvis alignment, then per frame
+ * {MPJPE, PVE, PA-MPJPE (Procrustes, utils.py:138-203)} -> per_frame DEVICE [n,3]. mean_host (HOST double[3] or NULL)
+ * receives the means over the n frames (synchronises `stream`). */
+int rc_set_regressor(rc_ctx* ctx, const float* j_regressor_host, int32_t n_rows, int32_t n_used);
+int rc_mesh_metrics(rc_ctx* ctx, const float* pose, const float* gt_pose, int64_t n, float* per_frame, double* mean_host,
+                    void* stream);
+/* reconstruction_error(S1, S2, reduction=None) (utils.py:189-203) on raw point sets: S1, S2 DEVICE [n, n_points, 3]
+ * -> err DEVICE [n] = mean point distance after the optimal scale * rotation + translation of S1 onto S2. */
+int rc_procrustes_error(const float* S1, const float* S2, int64_t n, int32_t n_points, float* err, void* stream);
+/* PositionErrorEvaluator (articulate/evaluator.py:100-129): p[n,3], t[n,3] DEVICE -> dist[n] DEVICE and, if mean_host
+ * is not NULL, their mean (synchronises `stream`). */
+int rc_position_error(const float* p, const float* t, int64_t n, float* dist, double* mean_host, void* stream);
 /* smplify forward residual (net/smplify/temporal_smplify.py:198-220 -> losses.py:36-37,43-46): pose[T,24,3,3],
  * tran[T,3], kp[T,33,3] in pixels, K[3,3] (DEVICE) -> loss[T,33]. The confidences of landmarks
  * {1..9,31,32} count as zero. */

@@ -98,12 +98,7 @@ class ParametricModel:
     def forward_mesh(self, pose, tran=None):
         """All V vertices of ``forward_kinematics(pose, tran=tran, calc_mesh=True)[2]`` (articulate/model.py:235-241),
         for the mesh metrics of evaluate.py:120-133. Returns a device tensor [n, V, 3]."""
-        if not self.__dict__.get("_mesh_set"):
-            vt = np.ascontiguousarray(self._body["v_template"], dtype=np.float32)
-            w = np.ascontiguousarray(self._body["weights"], dtype=np.float32)
-            _lib.check(self._ctx, self._lib.rc_set_mesh(self._ctx, vt.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
-                                                        vt.shape[0]), "rc_set_mesh")
-            self._mesh_set, self._V = True, vt.shape[0]
+        self._ensure_mesh()
         pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
         n = pose.shape[0]
         tran = torch.zeros(n, 3, device=self.device) if tran is None else _f32c(tran, self.device).view(n, 3)
@@ -111,6 +106,39 @@ class ParametricModel:
         _lib.check(self._ctx, self._lib.rc_body_mesh(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(vert), n, _lib.stream_ptr()),
                    "rc_body_mesh")
         return vert
+
+    def _ensure_mesh(self):
+        if not self.__dict__.get("_mesh_set"):
+            vt = np.ascontiguousarray(self._body["v_template"], dtype=np.float32)
+            w = np.ascontiguousarray(self._body["weights"], dtype=np.float32)
+            _lib.check(self._ctx, self._lib.rc_set_mesh(self._ctx, vt.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                                        vt.shape[0]), "rc_set_mesh")
+            self._mesh_set, self._V = True, vt.shape[0]
+
+    def set_regressor(self, j_regressor, n_used=14):
+        """Upload ``J_regressor_h36m`` [n_rows, V]; the metrics keep its first ``n_used`` rows (evaluate.py:122-125)."""
+        self._ensure_mesh()
+        Jr = np.ascontiguousarray(np.asarray(j_regressor, dtype=np.float32))
+        if Jr.ndim != 2 or Jr.shape[1] != self._V:
+            raise ValueError(f"j_regressor must be [n_rows, {self._V}]")
+        _lib.check(self._ctx, self._lib.rc_set_regressor(self._ctx, Jr.ctypes.data_as(C.c_void_p), Jr.shape[0], int(n_used)), "rc_set_regressor")
+        self._regressor_id = id(j_regressor)
+
+    def mesh_metrics(self, pose, gt_pose):
+        """evaluate.py:120-133 in one kernel: returns (per-frame [n,3] device tensor of MPJPE / PVE / PA-MPJPE,
+        their three means as Python floats). Keypoints come from the regressor set by ``set_regressor`` (else the
+        24 SMPL joints)."""
+        self._ensure_mesh()
+        pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
+        gt = _f32c(gt_pose, self.device).view(-1, 24, 3, 3)
+        if gt.shape != pose.shape:
+            raise ValueError("pose and gt_pose must have the same number of frames")
+        n = pose.shape[0]
+        per_frame = torch.empty(n, 3, device=self.device)
+        mean = (C.c_double * 3)()
+        _lib.check(self._ctx, self._lib.rc_mesh_metrics(self._ctx, _lib.ptr(pose), _lib.ptr(gt), n, _lib.ptr(per_frame), mean, _lib.stream_ptr()),
+                   "rc_mesh_metrics")
+        return per_frame, [float(v) for v in mean]
 
     def reprojection_residual(self, pose, tran, keypoints_2d, cam_k, sigma=100.0):
         """``TemporalSMPLify.get_fitting_loss`` (temporal_smplify.py:198-220): [T,33] robust reprojection loss."""
@@ -148,3 +176,27 @@ def rotation_matrix_to_axis_angle(r, device="cuda"):
     lib = _lib.load()
     _lib.check(None, lib.rc_rotmat_to_axis_angle(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_rotmat_to_axis_angle")
     return out
+
+
+def position_error(p, t, device="cuda"):
+    """art.PositionErrorEvaluator()(p, t) (articulate/evaluator.py:100-129): mean Euclidean distance of n 3-D points."""
+    a, b = _f32c(p, torch.device(device)).reshape(-1, 3), _f32c(t, torch.device(device)).reshape(-1, 3)
+    if a.shape != b.shape:
+        raise ValueError("p and t must hold the same number of points")
+    d = torch.empty(a.shape[0], device=a.device)
+    mean = C.c_double()
+    lib = _lib.load()
+    _lib.check(None, lib.rc_position_error(_lib.ptr(a), _lib.ptr(b), a.shape[0], _lib.ptr(d), C.byref(mean), _lib.stream_ptr()), "rc_position_error")
+    return mean.value
+
+
+def reconstruction_error(S1, S2, device="cuda"):
+    """utils.reconstruction_error(S1, S2, reduction=None) (utils.py:189-203): per-frame mean point distance after
+    Procrustes alignment of S1 [n,k,3] onto S2 [n,k,3]. Returns a device tensor [n]."""
+    a, b = _f32c(S1, torch.device(device)), _f32c(S2, torch.device(device))
+    if a.shape != b.shape or a.dim() != 3 or a.shape[2] != 3:
+        raise ValueError("S1 and S2 must both be [n, k, 3]")
+    err = torch.empty(a.shape[0], device=a.device)
+    lib = _lib.load()
+    _lib.check(None, lib.rc_procrustes_error(_lib.ptr(a), _lib.ptr(b), a.shape[0], a.shape[1], _lib.ptr(err), _lib.stream_ptr()), "rc_procrustes_error")
+    return err

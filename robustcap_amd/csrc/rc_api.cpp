@@ -62,6 +62,8 @@ struct rc_ctx {
     BodyConst* body = nullptr;
     float *mesh_vt = nullptr, *mesh_w = nullptr;      // full mesh (metrics only): v_template [V,3], weights [V,24]
     int mesh_V = 0;
+    float* mesh_Jr = nullptr;                         // keypoint regressor [n_used, V] (metrics only)
+    int mesh_nk = 0;
     bool have_body = false, have_weights = false;
     std::map<std::string, std::vector<float>> staged;
     std::vector<void*> allocs;
@@ -695,6 +697,55 @@ int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert,
     if (!pose || !tran || !vert || n < 0) return fail(ctx, RC_ERR_INVALID, "rc_body_mesh: bad argument");
     rc_launch_body_mesh(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, pose, tran, vert, n, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_set_regressor(rc_ctx* ctx, const float* Jr, int32_t n_rows, int32_t n_used) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (ctx->mesh_V == 0) return fail(ctx, RC_ERR_STATE, "rc_set_regressor: rc_set_mesh first");
+    if (!Jr || n_used < 1 || n_used > n_rows || n_used > 17) return fail(ctx, RC_ERR_INVALID, "rc_set_regressor: 1 <= n_used <= min(n_rows, 17)");
+    if (int rc = dev_alloc(ctx, &ctx->mesh_Jr, (size_t)n_used * ctx->mesh_V, false)) return rc;
+    HIP_TRY(ctx, hipMemcpy(ctx->mesh_Jr, Jr, (size_t)n_used * ctx->mesh_V * sizeof(float), hipMemcpyHostToDevice));
+    ctx->mesh_nk = n_used;
+    return RC_OK;
+}
+int rc_mesh_metrics(rc_ctx* ctx, const float* pose, const float* gt_pose, int64_t n, float* per_frame, double* mean_host, void* stream) {
+    if (!ctx || !ctx->have_body || ctx->mesh_V == 0) return ctx ? fail(ctx, RC_ERR_STATE, "rc_mesh_metrics: rc_set_body / rc_set_mesh first") : RC_ERR_INVALID;
+    if (n <= 0 || !pose || !gt_pose || !per_frame) return fail(ctx, RC_ERR_INVALID, "rc_mesh_metrics: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    rc_launch_mesh_metrics(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, ctx->mesh_Jr, ctx->mesh_Jr ? ctx->mesh_nk : 24, pose, gt_pose,
+                           per_frame, n, st);
+    HIP_TRY(ctx, hipGetLastError());
+    if (mean_host) {                                       // evaluate.py:131-133: the three means over the sequence
+        std::vector<float> h((size_t)n * 3);
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), per_frame, h.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int64_t i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) acc[c] += h[(size_t)i * 3 + c];
+        for (int c = 0; c < 3; ++c) mean_host[c] = acc[c] / (double)n;
+    }
+    return RC_OK;
+}
+int rc_procrustes_error(const float* S1, const float* S2, int64_t n, int32_t n_points, float* err, void* stream) {
+    if (n < 0 || n_points < 1) return RC_ERR_INVALID;
+    if (n == 0) return RC_OK;
+    if (!S1 || !S2 || !err) return RC_ERR_INVALID;
+    rc_launch_procrustes(S1, S2, n_points, err, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_position_error(const float* p, const float* t, int64_t n, float* dist, double* mean_host, void* stream) {
+    if (n <= 0 || !p || !t || !dist) return RC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    rc_launch_point_distance(p, t, dist, n, st);
+    if (hipGetLastError() != hipSuccess) return RC_ERR_HIP;
+    if (mean_host) {
+        std::vector<float> h((size_t)n);
+        if (hipMemcpyAsync(h.data(), dist, h.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return RC_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return RC_ERR_HIP;
+        double acc = 0.0;
+        for (float v : h) acc += v;
+        *mean_host = acc / (double)n;
+    }
     return RC_OK;
 }
 int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K, float sigma, float* loss,

@@ -151,6 +151,10 @@ void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w,
                          float* vert, long long n, hipStream_t s);
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
                         float sigma, float* loss, long long T, hipStream_t s);
+void rc_launch_mesh_metrics(const BodyConst* body, const float* vt, const float* w, int V, const float* Jr, int nk, const float* pose_p,
+                            const float* pose_t, float* out, long long n, hipStream_t s);
+void rc_launch_procrustes(const float* S1, const float* S2, int nk, float* err, long long n, hipStream_t s);
+void rc_launch_point_distance(const float* a, const float* b, float* d, long long n, hipStream_t s);
 
 // smplify optimiser (rc_smplify.hip): one evaluation = loss terms + analytic gradient of all T frames
 struct SmplifyArgs {

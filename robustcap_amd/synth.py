@@ -319,3 +319,15 @@ def make_gmm(seed=3, n=8, dim=69):
     covars = Bm @ np.swapaxes(Bm, 1, 2) + (0.08 ** 2) * np.eye(dim)[None]
     w = uniform01(seed, 3, n).astype(np.float64) + 0.5
     return {"means": means, "covars": covars, "weights": w / w.sum()}
+
+
+# ------------------------------------------------------------------------------------------- metric regressor
+def make_j_regressor(seed=4, n_joint=17, num_vertex=6890, support=48):
+    """Synthetic stand-in for ``J_regressor_h36m.npy`` (external asset, evaluate.py:17): [17, V] float32, every row a
+    convex combination (non-negative, sums to 1) of ``support`` seeded vertices -- the structure of the real regressor."""
+    Jr = np.zeros((n_joint, num_vertex), np.float32)
+    for k in range(n_joint):
+        ids = (uniform01(seed, 2 * k, support).astype(np.float64) * num_vertex).astype(np.int64) % num_vertex
+        w = uniform01(seed, 2 * k + 1, support).astype(np.float64) + 0.05
+        np.add.at(Jr[k], ids, (w / w.sum()).astype(np.float32))
+    return Jr

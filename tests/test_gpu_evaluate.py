@@ -87,33 +87,57 @@ def test_full_mesh_and_cal_mpjpe(synth_assets):
     Jr[np.arange(17), np.arange(17) * 400] = 1.0                                              # a stand-in regressor
     r = ev.cal_mpjpe(model, rot, pose, j_regressor=Jr)
     assert len(r) == 2 and r[0] > 0.0
+    picked = vert[:, np.arange(14) * 400] - tran.to(vert.device)[:, None]                  # what that regressor selects
+    rv = model.forward_mesh(rot, tran)[:, np.arange(14) * 400] - tran.to(vert.device)[:, None]
+    want = float(((picked - picked[:, :1]) - (rv - rv[:, :1])).norm(dim=2).mean())
+    assert abs(r[0] - want) <= 1e-6
 
 
-def test_run_dataset_with_smplify(synth_assets):
-    """evaluate.py:86-90: every row refined by the optimiser after the net; each row must equal a direct
-    smplify_runner call on that row's net output, and re-project better than the net output does."""
-    from robustcap_amd import synth
+@pytest.mark.parametrize("name", ["near", "far", "same"])
+def test_cal_mpjpe_matches_reference_capture(name, synth_assets):
+    """rc_mesh_metrics against the reference's own cal_mpjpe (tests/golden/metrics.npz): per-frame MPJPE, PVE and
+    PA-MPJPE, and the three means."""
+    import os
     from robustcap_amd import evaluate as ev
-    from robustcap_amd.smplify import TemporalSMPLify, smplify_runner
-    body, sd, gmm = synth_assets["body"], synth_assets["state_dict"], synth.make_gmm(3)
-    ds = synth.make_dataset(8, 1, 24, body, n_cam=2, conf="high")
-    plain = ev.run_dataset(ds, sd, body)
-    info = {}
-    opt = ev.run_dataset(ds, sd, body, run_smplify=True, gmm=gmm, smplify_info=info)
-    runner = TemporalSMPLify(body=body, gmm=gmm)
-    with pytest.raises(ValueError):
-        ev.run_dataset(ds, sd, body, run_smplify=True)
-    for (i, j) in plain:
-        kp = torch.as_tensor(ds["joint2d_mp"][i][j], dtype=torch.float32).clone()
-        kp[..., 0] *= 1920
-        kp[..., 1] *= 1080
-        _, _, oric, _ = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])
-        K = torch.as_tensor(ds["cam_K"][i][j], dtype=torch.float32)
-        p, tr, update = smplify_runner(plain[(i, j)][0], plain[(i, j)][1], kp, oric, 24, K, lr=0.001, runner=runner)
-        st = info[(i, j)]["status"]
-        assert st == runner.last_info["status"]
-        assert torch.equal(p, opt[(i, j)][0]) and torch.equal(tr, opt[(i, j)][1])          # deterministic: same launches, same host search
-        if st == 1:
-            before = float(runner.get_fitting_loss(plain[(i, j)][0], plain[(i, j)][1], kp, K).mean())
-            after = float(runner.get_fitting_loss(p, tr, kp, K).mean())
-            assert after < before and info[(i, j)]["n_eval"] <= 26
+    from robustcap_amd import synth
+    from robustcap_amd.body import ParametricModel
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    model = ParametricModel(body=synth_assets["body"])
+    Jr = synth.make_j_regressor(4)
+    pose = t(g["pose_gt"] if name == "same" else g["pose_" + name])
+    out = ev.cal_mpjpe(model, pose, t(g["pose_gt"]), j_regressor=Jr, cal_pampjpe=True)
+    assert np.allclose(out, g["cal_" + name], atol=3e-6)
+    assert ev.cal_mpjpe(model, pose, t(g["pose_gt"]), j_regressor=Jr) == out[:2]
+    per_frame, _ = model.mesh_metrics(pose, t(g["pose_gt"]))
+    pf = per_frame.cpu().numpy()
+    assert np.abs(pf[:, 0] - g["frame_mpjpe_" + name]).max() <= 3e-6
+    assert np.abs(pf[:, 1] - g["frame_pve_" + name]).max() <= 3e-6
+    assert np.abs(pf[:, 2] - g["frame_pa_" + name]).max() <= 3e-6
+
+
+def test_procrustes_and_position_error_match_reference_capture(synth_assets):
+    """The Procrustes stage on the reference's raw point sets (incl. mirrored sets: the det < 0 branch of
+    utils.py:171-174), PositionErrorEvaluator, and the fused kernel against the oracle on a second pose pair."""
+    import os
+    from oracle import metrics_oracle as M
+    from robustcap_amd import synth
+    from robustcap_amd.body import ParametricModel, position_error, reconstruction_error
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    assert abs(position_error(t(g["pos_a"]), t(g["pos_b"])) - float(g["pos_err"])) <= 1e-6
+    err = reconstruction_error(t(g["pa_S1"]), t(g["pa_S2"])).cpu().numpy()
+    assert np.abs(err - g["pa_err"]).max() <= 1e-5 * np.abs(g["pa_err"]).max()
+    assert reconstruction_error(torch.zeros(0, 14, 3), torch.zeros(0, 14, 3)).shape == (0,)
+    body = synth_assets["body"]
+    model = ParametricModel(body=body)
+    model.set_regressor(synth.make_j_regressor(4), 14)
+    gt = t(g["pose_gt"])
+    Rz = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    rot = gt.clone()
+    rot[:, 0] = Rz @ rot[:, 0]
+    pf, mean = model.mesh_metrics(rot, gt)
+    assert mean[0] > 1e-3 and mean[2] < 1e-6                                                 # a rigid rotation is aligned away
+    want = M.frame_metrics(body, synth.make_j_regressor(4), t(g["pose_far"]), rot)
+    pf, _ = model.mesh_metrics(t(g["pose_far"]), rot)
+    pf = pf.cpu().numpy()
+    for c in range(3):
+        assert np.abs(pf[:, c] - want[c]).max() <= 3e-6
