@@ -148,6 +148,16 @@ int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert,
 int rc_set_regressor(rc_ctx* ctx, const float* j_regressor_host, int32_t n_rows, int32_t n_used);
 int rc_mesh_metrics(rc_ctx* ctx, const float* pose, const float* gt_pose, int64_t n, float* per_frame, double* mean_host,
                     void* stream);
+/* IMU synthesis of the dataset preparation (preprocess.py:22-33 `_syn_acc`, :206-214): pose[T,24,3,3] local rotations,
+ * tran[T,3] DEVICE; vertex_ids[6] (config.vi_mask) and joint_ids[6] (config.ji_mask) HOST; needs rc_set_mesh.
+ * -> imu_ori[T,6,3,3] = global rotations of joint_ids, vert6[T,6,3] = skinned vertices, imu_acc[T,6,3] =
+ * _syn_acc(vert6, smooth_n), joint3d[T,24,3] (or NULL). rc_syn_acc is the stencil alone on v[T,width]: second
+ * differences * 3600 with zero end frames, interior [n:-n] from the wide stencil / n^2 when smooth_n >= 2 (bit-exact).
+ * Like the reference, smooth_n >= 2 needs T >= 2 * smooth_n + 1. */
+int rc_synth_imu(rc_ctx* ctx, const float* pose, const float* tran, const int32_t* vertex_ids_host,
+                 const int32_t* joint_ids_host, int64_t T, int32_t smooth_n, float* imu_ori, float* imu_acc, float* joint3d,
+                 float* vert6, void* stream);
+int rc_syn_acc(const float* v, int64_t T, int64_t width, int32_t smooth_n, float* acc, void* stream);
 /* reconstruction_error(S1, S2, reduction=None) (utils.py:189-203) on raw point sets: S1, S2 DEVICE [n, n_points, 3]
  * -> err DEVICE [n] = mean point distance after the optimal scale * rotation + translation of S1 onto S2. */
 int rc_procrustes_error(const float* S1, const float* S2, int64_t n, int32_t n_points, float* err, void* stream);

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Golden vectors for the IMU synthesis of preprocess.py by RUNNING THE REFERENCE here.
+
+TEST INFRASTRUCTURE, like capture_reference.py. Calls the reference's ``preprocess._syn_acc`` (preprocess.py:22-33) and
+repeats its recipe lines 206-214 with the reference's own objects: ``body_model.forward_kinematics(p, tran=tran,
+calc_mesh=True)``, ``imu_ori = gp[:, ji_mask]``, ``imu_acc = _syn_acc(vert[:, vi_mask])``.
+Writes tests/golden/imu_synth.npz (numbers only).
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from robustcap_amd import synth  # noqa: E402
+import capture_reference as cr  # noqa: E402
+
+
+def main():
+    body = synth.make_body(cr.BODY_SEED)
+    tmp = tempfile.mkdtemp(prefix="rc_ref_imu_")
+    cr._write_body_pickle(os.path.join(tmp, "models", "SMPL_male.pkl"), body)
+    os.chdir(tmp)
+    cr._install_stubs()
+    sys.path.insert(0, cr.REF)
+    import articulate as art  # noqa
+    import preprocess as pre
+    t = torch.from_numpy
+    g = {}
+    for name, T in (("long", 40), ("five", 5), ("four", 4), ("three", 3)):       # short ones: the edge rules of _syn_acc
+        v = t(synth.normal(61, T, T * 18).reshape(T, 6, 3).copy())
+        g["v_" + name] = v.numpy()
+        for n in (2, 1):
+            if n == 2 and T < 5:                       # the reference raises (empty torch.stack) below 2n+1 frames
+                continue
+            g["acc%d_%s" % (n, name)] = pre._syn_acc(v.clone(), smooth_n=n).numpy()
+    T = 32
+    m = synth.make_motion(62, 1, T, body, conf="high")
+    aa = t(synth._log_map(m["pose"][0].astype(np.float64)).astype(np.float32)).reshape(T, 72)
+    tran = t(m["tran"][0].copy())
+    p = art.math.axis_angle_to_rotation_matrix(aa).view(-1, 24, 3, 3)
+    gp, joint3d, vert = pre.body_model.forward_kinematics(p, tran=tran, calc_mesh=True)
+    g.update(pose_aa=aa.numpy(), tran=tran.numpy(), imu_ori=gp[:, pre.ji_mask].numpy(), imu_acc=pre._syn_acc(vert[:, pre.vi_mask]).numpy(),
+             joint3d=joint3d.numpy(), vert6=vert[:, pre.vi_mask].numpy())
+    np.savez_compressed(os.path.join(cr.OUT, "imu_synth.npz"), **g)
+    print({k: v.shape for k, v in g.items()})
+
+
+if __name__ == "__main__":
+    main()

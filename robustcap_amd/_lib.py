@@ -63,6 +63,8 @@ SIGNATURES = {
     "rc_body_mesh": (_I32, [_P, _P, _P, _P, _I64, _P]),
     "rc_set_regressor": (_I32, [_P, _P, _I32, _I32]),
     "rc_mesh_metrics": (_I32, [_P, _P, _P, _I64, _P, C.POINTER(C.c_double), _P]),
+    "rc_synth_imu": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P]),
+    "rc_syn_acc": (_I32, [_P, _I64, _I64, _I32, _P, _P]),
     "rc_procrustes_error": (_I32, [_P, _P, _I64, _I32, _P, _P]),
     "rc_position_error": (_I32, [_P, _P, _I64, _P, C.POINTER(C.c_double), _P]),
     "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),

@@ -726,6 +726,29 @@ int rc_mesh_metrics(rc_ctx* ctx, const float* pose, const float* gt_pose, int64_
     }
     return RC_OK;
 }
+int rc_syn_acc(const float* v, int64_t T, int64_t width, int32_t smooth_n, float* acc, void* stream) {
+    if (T < 0 || width < 1 || smooth_n < 1) return RC_ERR_INVALID;
+    if (T == 0) return RC_OK;
+    if (!v || !acc) return RC_ERR_INVALID;
+    if (smooth_n / 2 != 0 && T < 2 * (int64_t)smooth_n + 1) return RC_ERR_INVALID;     // the reference raises here
+    rc_launch_syn_acc(v, acc, T, width, smooth_n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_synth_imu(rc_ctx* ctx, const float* pose, const float* tran, const int32_t* vertex_ids, const int32_t* joint_ids, int64_t T,
+                 int32_t smooth_n, float* imu_ori, float* imu_acc, float* joint3d, float* vert6, void* stream) {
+    if (!ctx || !ctx->have_body || ctx->mesh_V == 0) return ctx ? fail(ctx, RC_ERR_STATE, "rc_synth_imu: rc_set_body / rc_set_mesh first") : RC_ERR_INVALID;
+    if (T <= 0 || !pose || !tran || !vertex_ids || !joint_ids || !imu_ori || !imu_acc || !vert6 || smooth_n < 1)
+        return fail(ctx, RC_ERR_INVALID, "rc_synth_imu: bad argument");
+    if (smooth_n / 2 != 0 && T < 2 * (int64_t)smooth_n + 1) return fail(ctx, RC_ERR_INVALID, "rc_synth_imu: needs at least 2 * smooth_n + 1 frames");
+    for (int i = 0; i < 6; ++i)
+        if (vertex_ids[i] < 0 || vertex_ids[i] >= ctx->mesh_V || joint_ids[i] < 0 || joint_ids[i] > 23)
+            return fail(ctx, RC_ERR_INVALID, "rc_synth_imu: vertex / joint id out of range");
+    hipStream_t st = (hipStream_t)stream;
+    rc_launch_imu_frames(ctx->body, ctx->mesh_vt, ctx->mesh_w, vertex_ids, joint_ids, pose, tran, imu_ori, joint3d, vert6, T, st);
+    rc_launch_syn_acc(vert6, imu_acc, T, 18, smooth_n, st);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
 int rc_procrustes_error(const float* S1, const float* S2, int64_t n, int32_t n_points, float* err, void* stream) {
     if (n < 0 || n_points < 1) return RC_ERR_INVALID;
     if (n == 0) return RC_OK;

@@ -153,6 +153,9 @@ void rc_launch_residual(const BodyConst* body, const float* pose, const float* t
                         float sigma, float* loss, long long T, hipStream_t s);
 void rc_launch_mesh_metrics(const BodyConst* body, const float* vt, const float* w, int V, const float* Jr, int nk, const float* pose_p,
                             const float* pose_t, float* out, long long n, hipStream_t s);
+void rc_launch_imu_frames(const BodyConst* body, const float* vt, const float* w, const int* vid, const int* jid, const float* pose,
+                          const float* tran, float* ori, float* joint, float* vert6, long long T, hipStream_t s);
+void rc_launch_syn_acc(const float* v, float* acc, long long T, long long width, int n, hipStream_t s);
 void rc_launch_procrustes(const float* S1, const float* S2, int nk, float* err, long long n, hipStream_t s);
 void rc_launch_point_distance(const float* a, const float* b, float* d, long long n, hipStream_t s);
 
