@@ -170,7 +170,10 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    p.n_tiles = d.Np / (16 * d.nc); p.m_tiles = (ctx->B + 16 * d.mr - 1) / (16 * d.mr); p.Kp = d.Kp; p.nc = d.nc; p.mr = d.mr;
+    // batch <= 16 (live mode): every launch of the frame is weight streaming -> 16 x 32 tiles throughout, which also
+    // keeps each launch homogeneous so that it runs on the high-occupancy small-tile kernel
+    const int mr = ctx->B <= 16 ? 1 : d.mr, nc = ctx->B <= 16 ? 2 : d.nc;
+    p.n_tiles = d.Np / (16 * nc); p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr); p.Kp = d.Kp; p.nc = nc; p.mr = mr;
     return p;
 }
 

@@ -277,15 +277,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #ifndef RC_WPS
 #define RC_WPS 1   // waves per SIMD the register allocation must allow
 #endif
-__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmLaunch L) {
-    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
-    int pi = 0;
+// which problem and which tile of it this workgroup owns; false when the (XCD-padded) grid slot is empty
+__device__ __forceinline__ bool locate_tile(const GemmLaunch& L, int& pi, int& m_tile, int& n_tile) {
+    pi = 0;
 #pragma unroll
     for (int q = 1; q < RC_MAX_PROB; ++q)
         if (q < L.n && (int)blockIdx.x >= L.p[q].wg_base) pi = q;
     const GemmProblem& P = L.p[pi];
     const int local = blockIdx.x - P.wg_base;
-    int m_tile, n_tile;
     if ((P.n_tiles & 7) == 0) {   // XCD-aware: the row tiles of one weight slice share block-id % 8
         const int xcd = local & 7, s = local >> 3;
         m_tile = s % P.m_tiles;
@@ -294,7 +293,14 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
         m_tile = local % P.m_tiles;
         n_tile = local / P.m_tiles;
     }
-    if (n_tile >= P.n_tiles) return;
+    return n_tile < P.n_tiles;
+}
+
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+    int pi, m_tile, n_tile;
+    if (!locate_tile(L, pi, m_tile, n_tile)) return;
+    const GemmProblem& P = L.p[pi];
     switch (P.mr * 16 + P.nc) {
         case 4 * 16 + 5: gemm_tile<4, 5, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
         case 4 * 16 + 4: gemm_tile<4, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
@@ -306,6 +312,22 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
     }
 }
 
+// Launches whose problems all use 16-row tiles (batch <= 16: live mode, transition rows) are weight-streaming, not
+// MFMA-bound: their own kernel with a 12 KB LDS footprint and a register budget for 4 waves per SIMD keeps four
+// workgroups -- 4 x 32 KB of weight loads in flight -- on every CU instead of one.
+#define RC_SMALL_LDS_FLOATS (128 + RC_NW * 16 * (16 * 2 + LDS_PAD))
+__global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
+    int pi, m_tile, n_tile;
+    if (!locate_tile(L, pi, m_tile, n_tile)) return;
+    const GemmProblem& P = L.p[pi];
+    if (P.nc == 2) gemm_tile<1, 2, 4, true>(P, L.B, m_tile, n_tile, s_mem);
+    else gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem);
+}
+
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
-    hipLaunchKernelGGL(rc_gemm_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
+    bool small = true;
+    for (int q = 0; q < L.n; ++q) small = small && L.p[q].mr == 1 && L.p[q].nc <= 2;
+    if (small) hipLaunchKernelGGL(rc_gemm_small_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
+    else hipLaunchKernelGGL(rc_gemm_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
 }
