@@ -133,7 +133,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(pose).all() and torch.isfinite(tran).all()
@@ -152,7 +152,7 @@ def main():
         flop_per_launch = B * C.FLOPS_PER_BODY_FRAME * K / launches
         avg_s = ms * 1e-3 / launches
         ach = flop_per_launch / avg_s / 1e12
-        roof = {"bound": "mfma", "kernel": "rc_gemm_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "rc_gemm_kernel (+ rc_gemm_small_kernel for the 16-row transition launches)", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                 "traffic_note": "HBM bytes per launch, rocprofv3 PMC (profiles/r01_pmc_traffic.json); unique weight bytes per launch = 22.1e6",
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,

@@ -30,12 +30,14 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RC_DIST_SHARE_DEVICE") == "1":                  # dry runs of the N-rank flow on a 1-GPU box
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -51,6 +53,9 @@ def gather_rows(local, n_rows_total, dst=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    if local.is_cuda and dist.get_backend() == "gloo":                 # gloo gathers host tensors: stage through the host
+        out = gather_rows(local.cpu(), n_rows_total, dst)
+        return None if out is None else out.to(local.device)
     sizes = [shard_range(n_rows_total, r, world) for r in range(world)]
     cap = max(b - a for a, b in sizes)
     pad = local.new_zeros((cap,) + tuple(local.shape[1:]))
