@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librobustcap_hip.so")
+LIB_PATH = os.environ.get("RC_LIB_PATH") or os.path.join(_HERE, "csrc", "librobustcap_hip.so")   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "robustcap_hip.h")
 
 RC_FLAG_FIRST_FRAME = 1
