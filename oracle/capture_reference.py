@@ -183,6 +183,7 @@ SCENARIOS = {
     "live_post": dict(T=96, conf="mixed", first_frame=True, live="post"),
     "live_pre": dict(T=96, conf="livepre", first_frame=True, live="pre"),
     "reproj_opt": dict(T=96, conf="mixed_hi0", first_tran=True, use_reproj_opt=True),
+    "long_mixed": dict(T=512, conf="mixed", first_tran=True),       # the north-star sequence length
 }
 
 
