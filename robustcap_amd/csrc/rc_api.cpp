@@ -74,6 +74,8 @@ struct rc_ctx {
     hipGraphExec_t live_exec = nullptr;
     float *live_in_h = nullptr, *live_out_h = nullptr;      // pinned: [B,171] and [B,219]
     float *live_in_d = nullptr, *live_out_d = nullptr, *live_ft_d = nullptr;
+    float *live_in_io = nullptr, *live_out_io = nullptr;    // what the frame kernels read / write (device copy or mapped host memory)
+    bool live_zero_copy = false;
     // timing of the gate GEMM launches
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -170,9 +172,9 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
-    // batch <= 16 (live mode): every launch of the frame is weight streaming -> 16 x 32 tiles throughout, which also
+    // batch <= 16 (live mode): every launch of the frame is weight streaming -> 16 x 16 tiles throughout (twice the workgroups and the 8-deep load pipeline), which also
     // keeps each launch homogeneous so that it runs on the high-occupancy small-tile kernel
-    const int mr = ctx->B <= 16 ? 1 : d.mr, nc = ctx->B <= 16 ? 2 : d.nc;
+    const int mr = ctx->B <= 16 ? 1 : d.mr, nc = ctx->B <= 16 ? 1 : d.nc;
     p.n_tiles = d.Np / (16 * nc); p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr); p.Kp = d.Kp; p.nc = nc; p.mr = mr;
     return p;
 }
@@ -600,21 +602,30 @@ int rc_live_begin(rc_ctx* ctx) {
     rc_live_end(ctx);
     const size_t B = ctx->B;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->live_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_in_h, B * 171 * sizeof(float), hipHostMallocDefault));
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_out_h, B * 219 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_in_h, B * 171 * sizeof(float), hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_out_h, B * 219 * sizeof(float), hipHostMallocMapped));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->live_in_d, B * 171 * sizeof(float)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->live_out_d, B * 219 * sizeof(float)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->live_ft_d, B * 3 * sizeof(float)));
-    // capture: H2D -> frame -> D2H. Inputs are laid out [j2dc B*99 | accc B*18 | oric B*54], outputs [pose B*216 | tran B*3].
+    // Small batches: the frame kernels read the 684 B / body of inputs and write the 876 B of outputs straight from / to
+    // the pinned host buffers (two copy nodes and their barriers cost more than the PCIe reads). Larger batches keep
+    // H2D -> frame -> D2H. Layout: inputs [j2dc B*99 | accc B*18 | oric B*54], outputs [pose B*216 | tran B*3].
+    ctx->live_zero_copy = B <= 16;
+    ctx->live_in_io = ctx->live_in_d;
+    ctx->live_out_io = ctx->live_out_d;
+    if (ctx->live_zero_copy) {
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->live_in_io, ctx->live_in_h, 0));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->live_out_io, ctx->live_out_h, 0));
+    }
     hipStream_t st = ctx->live_stream;
     const bool timing = ctx->timing;
     ctx->timing = false;
     HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
-    FrameIO io{ctx->live_in_d, ctx->live_in_d + B * 99, ctx->live_in_d + B * 117, nullptr,
-               ctx->live_out_d, ctx->live_out_d + B * 216, 99, 18, 54, 216, 3};
+    if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+    FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, nullptr,
+               ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
     const int rc = step_impl(ctx, io, 0u, st);
-    (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
     hipError_t e = hipStreamEndCapture(st, &ctx->live_graph);
     ctx->timing = timing;
     if (rc) return rc;
@@ -633,12 +644,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     std::memcpy(ctx->live_in_h + B * 99, accc, B * 18 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 117, oric, B * 54 * sizeof(float));
     if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
+        if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
         if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
-        FrameIO io{ctx->live_in_d, ctx->live_in_d + B * 99, ctx->live_in_d + B * 117, first_tran ? ctx->live_ft_d : nullptr,
-                   ctx->live_out_d, ctx->live_out_d + B * 216, 99, 18, 54, 216, 3};
+        FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, first_tran ? ctx->live_ft_d : nullptr,
+                   ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
         if (int rc = step_impl(ctx, io, flags, st)) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
     } else {
         HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec, st));
     }
