@@ -76,6 +76,10 @@ struct rc_ctx {
     float *live_in_d = nullptr, *live_out_d = nullptr, *live_ft_d = nullptr;
     float *live_in_io = nullptr, *live_out_io = nullptr;    // what the frame kernels read / write (device copy or mapped host memory)
     bool live_zero_copy = false;
+    hipGraph_t live_graph_notr = nullptr;                   // the same frame without the transition launches
+    hipGraphExec_t live_exec_notr = nullptr;
+    std::vector<unsigned char> live_maybe_pend;             // host-side, conservative: row may carry a deferred updater step
+    bool live_prev_known = false;
     // timing of the gate GEMM launches
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -290,7 +294,7 @@ rc_params_dev dev_params(const rc_params& p) {
     return d;
 }
 
-int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
+int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bool with_tr = true) {
     const int B = ctx->B;
     const FrameBuffers& fb = ctx->fb;
     const rc_params_dev prm = dev_params(ctx->prm);
@@ -299,7 +303,7 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st) {
     rc_launch_prep(fb, io, prm, B, first, st);
     // deferred vision updater of the previous frame (L264-271) for rows that step again now: rnn6 then rnn4 in the
     // reference, independent nets here. State-only, linear2 skipped; usually no row qualifies and the tiles exit.
-    if (ctx->prm.use_vision_updater) {
+    if (ctx->prm.use_vision_updater && with_tr) {
         Stage t6{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         Stage t4{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         t6.rows_hint = t4.rows_hint = 8;  // regime changes: a handful of rows per frame -> narrow tiles
@@ -556,6 +560,7 @@ int rc_set_gravity(rc_ctx* ctx, const float* g) {
 
 int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream) {
     if (!ctx) return RC_ERR_INVALID;
+    ctx->live_prev_known = false;
     float* h[6]; float* c[6]; int H[6];
     for (int i = 0; i < 6; ++i) { h[i] = ctx->net[i].h; c[i] = ctx->net[i].c; H[i] = ctx->net[i].H; }
     rc_launch_reset(ctx->fb, h, c, H, row_mask, ctx->B, (hipStream_t)stream);
@@ -566,6 +571,7 @@ int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream) {
 int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran, uint32_t flags,
             float* pose_out, float* tran_out, void* stream) {
     if (int rc = check_ready(ctx)) return rc;
+    ctx->live_prev_known = false;                      // the live path's host-side flag mirror no longer knows the last frame
     if (!j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_step: null buffer");
     FrameIO io{j2dc, accc, oric, first_tran, pose_out, tran_out, 99, 18, 54, 216, 3};
     return step_impl(ctx, io, flags, (hipStream_t)stream);
@@ -575,6 +581,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                 int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out, int64_t rs_pose, float* tran_out,
                 int64_t rs_tran, void* stream) {
     if (int rc = check_ready(ctx)) return rc;
+    ctx->live_prev_known = false;
     if (T < 0 || !j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_sequence: bad argument");
     for (int t = 0; t < T; ++t) {
         FrameIO io{j2dc + (int64_t)t * 99, accc + (int64_t)t * 18, oric + (int64_t)t * 54, t == 0 ? first_tran : nullptr,
@@ -588,6 +595,8 @@ int rc_live_end(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
     if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
+    if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
+    if (ctx->live_graph_notr) { (void)hipGraphDestroy(ctx->live_graph_notr); ctx->live_graph_notr = nullptr; }
     if (ctx->live_stream) { (void)hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
     if (ctx->live_in_h) { (void)hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
     if (ctx->live_out_h) { (void)hipHostFree(ctx->live_out_h); ctx->live_out_h = nullptr; }
@@ -620,18 +629,26 @@ int rc_live_begin(rc_ctx* ctx) {
     hipStream_t st = ctx->live_stream;
     const bool timing = ctx->timing;
     ctx->timing = false;
-    HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+    // Two captures of the frame: with and without the three transition launches. rc_live_step replays the short one
+    // when the host can rule out that any row carries a deferred updater step into a frame it steps on camera data.
     FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, nullptr,
                ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
-    const int rc = step_impl(ctx, io, 0u, st);
-    if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
-    hipError_t e = hipStreamEndCapture(st, &ctx->live_graph);
+    int rc = RC_OK;
+    for (int v = 0; v < 2 && !rc; ++v) {
+        HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+        rc = step_impl(ctx, io, 0u, st, v == 0);
+        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+        hipGraph_t* g = v == 0 ? &ctx->live_graph : &ctx->live_graph_notr;
+        const hipError_t e = hipStreamEndCapture(st, g);
+        if (!rc && e != hipSuccess) rc = fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(v == 0 ? &ctx->live_exec : &ctx->live_exec_notr, *g, nullptr, nullptr, 0) != hipSuccess)
+            rc = fail(ctx, RC_ERR_HIP, "hipGraphInstantiate");
+    }
     ctx->timing = timing;
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    HIP_TRY(ctx, hipGraphInstantiate(&ctx->live_exec, ctx->live_graph, nullptr, nullptr, 0));
-    return RC_OK;
+    ctx->live_maybe_pend.assign(B, 1);
+    ctx->live_prev_known = false;
+    return rc;
 }
 
 int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran, uint32_t flags,
@@ -643,6 +660,23 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     std::memcpy(ctx->live_in_h, j2dc, B * 99 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 99, accc, B * 18 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 117, oric, B * 54 * sizeof(float));
+    // Host-side, CONSERVATIVE mirror of two device flags (rc_prep_kernel): a row needs a transition step iff it carries
+    // a deferred updater step (previous frame had c <= lo) and steps on camera data now (c > lo or first frame). The
+    // margin covers the summation-order difference between this double mean and the device's float butterfly; any
+    // doubt, or an unknown previous frame, selects the full graph, where unneeded transition tiles simply exit.
+    bool need_tr = !ctx->live_prev_known;
+    {
+        const double lo = ctx->prm.conf_lo, margin = 1e-4;
+        for (size_t b = 0; b < B; ++b) {
+            double acc = 0.0;
+            for (int k = 0; k < 33; ++k) acc += (double)j2dc[(b * 33 + k) * 3 + 2];
+            const double c = acc / 33.0;
+            const bool maybe_vis = !(c < lo - margin) || (flags & RC_FLAG_FIRST_FRAME);
+            if (ctx->live_maybe_pend[b] && maybe_vis) need_tr = true;
+            ctx->live_maybe_pend[b] = (ctx->prm.use_vision_updater && !(c > lo + margin)) ? 1 : 0;
+        }
+        ctx->live_prev_known = true;
+    }
     if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
         if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -651,7 +685,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         if (int rc = step_impl(ctx, io, flags, st)) return rc;
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
     } else {
-        HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec, st));
+        HIP_TRY(ctx, hipGraphLaunch(need_tr ? ctx->live_exec : ctx->live_exec_notr, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));

@@ -257,6 +257,8 @@ def test_live_graph_step_equals_eager(synth_assets):
     T = 40
     m = synth.make_motion(95, 1, T, synth_assets["body"], conf="mixed")
     m["j2dc"][0, 10:25, :, 2] = 0.4                              # an occluded stretch: exercises the deferred updater
+    for i, c in zip(range(28, 36), (0.7, 0.70001, 0.69999, 0.7, 0.9, 0.69995, 0.70005, 0.5)):
+        m["j2dc"][0, i, :, 2] = c                                # hugging conf_lo: the host-side graph choice must stay safe
     a, b = make_net(synth_assets, 1), make_net(synth_assets, 1)
     a.gravityc = b.gravityc = t(m["gravityc"])
     b.use_graph = True
