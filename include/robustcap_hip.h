@@ -167,6 +167,9 @@ int rc_position_error(const float* p, const float* t, int64_t n, float* dist, do
 /* smplify forward residual (net/smplify/temporal_smplify.py:198-220 -> losses.py:36-37,43-46): pose[T,24,3,3],
  * tran[T,3], kp[T,33,3] in pixels, K[3,3] (DEVICE) -> loss[T,33]. The confidences of landmarks
  * {1..9,31,32} count as zero. */
+/* Landmarks whose confidence smplify zeroes (temporal_smplify.py:92-94): default {1..9, 31, 32}; `use_head=True` of the
+ * reference = {31, 32}. ids HOST int32[n], each in 0..32. Applies to rc_reproj_residual and the optimiser. */
+int rc_set_ignored_landmarks(rc_ctx* ctx, const int32_t* ids_host, int32_t n);
 int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K,
                        float sigma, float* loss, int64_t T, void* stream);
 

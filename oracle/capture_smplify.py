@@ -91,6 +91,18 @@ def main():
     g.update(ev_T=np.int32(T), ev_K=K.numpy(), ev_kp=kp.numpy(), ev_imu_ori=m["oric"][0], ev_ref3d=ref3d.numpy(),
              ev_pose=bp.detach().numpy(), ev_tran=tn.detach().numpy(), ev_loss=np.float64(loss.item()),
              ev_grad_pose=bp.grad.numpy().copy(), ev_grad_tran=tn.grad.numpy().copy())
+    # the same evaluation with use_head=True (ignored landmarks {31, 32} only, temporal_smplify.py:93-94)
+    fit_h = ts.TemporalSMPLify(cam_k=K, imu_ori=t(m["oric"][0]), step_size=1e-3, batch_size=T, use_head=True)
+    conf_h = kp[:, :, -1].clone()
+    conf_h[:, fit_h.ign_mp_joints] = 0.0
+    bph, tnh = bp.detach().clone().requires_grad_(True), tn.detach().clone().requires_grad_(True)
+    pose_h = ts.batch_rodrigues(bph.view(-1, 3)).view(T, 24, 3, 3)
+    gph, jh, vh = ts.body_model.forward_kinematics(pose=pose_h, tran=tnh, calc_mesh=True)
+    mjh = ref_utils.sync_mp3d_from_smpl(vh, jh)
+    loss_h = losses.temporal_body_fitting_loss(bph, mjh, kp[:, :, :2], conf_h, fit_h.pose_prior, fit_h.cam_k, ref3d, fit_h.imu_ori, gph[:, [ts.joint_mask]])
+    loss_h.backward()
+    g.update(evh_loss=np.float64(loss_h.item()), evh_grad_pose=bph.grad.numpy().copy(), evh_grad_tran=tnh.grad.numpy().copy(),
+             evh_residual=fit_h.get_fitting_loss(pose_h.detach(), tnh.detach(), kp.clone()).numpy())
     prior = fit.pose_prior(bp.detach()[:, 3:], None)
     g["ev_prior"] = prior.numpy()
     print("closure: loss %.6g |g_pose| %.4g |g_tran| %.4g" % (loss.item(), bp.grad.abs().max(), tn.grad.abs().max()))

@@ -187,14 +187,14 @@ class OracleBody:
         return j
 
 
-def reprojection_residual(body, pose, tran, kp, K, sigma=100.0):
+def reprojection_residual(body, pose, tran, kp, K, sigma=100.0, ignored=C.smplify_ignored_landmarks):
     """smplify forward residual [T,33]: conf^2 * sum_xy gmof(K * (j33 / z) - kp) with the ignored landmarks'
     confidence zeroed (temporal_smplify.py:198-220, losses.py:36-37,43-46)."""
     _, joint, vert = body.forward_kinematics(pose, tran)
     j33 = body.landmarks(vert, joint)
     proj = (K @ (j33 / j33[..., 2:]).unsqueeze(-1)).squeeze(-1)[..., :2]
     conf = kp[..., 2].clone()
-    conf[:, list(C.smplify_ignored_landmarks)] = 0.0
+    conf[:, list(ignored)] = 0.0
     return conf * conf * gmof(proj - kp[..., :2], sigma).sum(dim=-1)
 
 

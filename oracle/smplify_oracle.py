@@ -67,16 +67,17 @@ def fitting_loss(obody, prior, body_pose, tran, kp, conf, K, ref3d, imu_ori, sig
     return total.sum()
 
 
-def smplify_runner(body, gmm, pred_pose, pred_tran, kp_in, imu_ori, K, lr=0.001, max_iter=20, loss_threshold=20000):
+def smplify_runner(body, gmm, pred_pose, pred_tran, kp_in, imu_ori, K, lr=0.001, max_iter=20, loss_threshold=20000, use_head=False):
     """run.py:6-34 + temporal_smplify.py:97-220. Returns (pose [T,24,3,3], tran [T,3], update mask | None)."""
     obody, prior = O.OracleBody(body), Prior(gmm)
+    ignored = (31, 32) if use_head else C.smplify_ignored_landmarks          # temporal_smplify.py:92-94
     T = pred_pose.shape[0]
     kp = kp_in.clone()
-    before = O.reprojection_residual(obody, pred_pose, pred_tran, kp, K)
+    before = O.reprojection_residual(obody, pred_pose, pred_tran, kp, K, ignored=ignored)
     if float(before.mean(-1)[0]) > loss_threshold:
         return pred_pose, pred_tran, None
     conf = kp[:, :, 2].clone()
-    conf[:, list(C.smplify_ignored_landmarks)] = 0.0
+    conf[:, list(ignored)] = 0.0
     body_pose = O.rotation_matrix_to_axis_angle(pred_pose).reshape(T, 72).clone().requires_grad_(True)
     tran = pred_tran.clone().requires_grad_(True)
     with torch.no_grad():
@@ -92,5 +93,5 @@ def smplify_runner(body, gmm, pred_pose, pred_tran, kp_in, imu_ori, K, lr=0.001,
 
     opt.step(closure)
     pose = O.axis_angle_to_rotation_matrix(body_pose.detach().reshape(-1, 3)).view(T, 24, 3, 3)
-    after = O.reprojection_residual(obody, pose, tran.detach(), kp, K)
+    after = O.reprojection_residual(obody, pose, tran.detach(), kp, K, ignored=ignored)
     return pose, tran.detach(), after.mean(-1) < before.mean(-1)

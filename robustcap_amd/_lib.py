@@ -68,6 +68,7 @@ SIGNATURES = {
     "rc_procrustes_error": (_I32, [_P, _P, _I64, _I32, _P, _P]),
     "rc_position_error": (_I32, [_P, _P, _I64, _P, C.POINTER(C.c_double), _P]),
     "rc_lstm_step": (_I32, [_P, C.c_char_p, _P, _P, _P, _P]),
+    "rc_set_ignored_landmarks": (_I32, [_P, _P, _I32]),
     "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
     "rc_smplify_set_prior": (_I32, [_P, _P, _P, _P]),
     "rc_smplify_loss_grad": (_I32, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_double), _P, _P]),

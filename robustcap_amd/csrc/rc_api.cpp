@@ -64,6 +64,7 @@ struct rc_ctx {
     int mesh_V = 0;
     float* mesh_Jr = nullptr;                         // keypoint regressor [n_used, V] (metrics only)
     int mesh_nk = 0;
+    unsigned long long ign_mask = RC_IGN_DEFAULT;     // smplify: landmarks with zeroed confidence
     bool have_body = false, have_weights = false;
     std::map<std::string, std::vector<float>> staged;
     std::vector<void*> allocs;
@@ -360,6 +361,7 @@ int check_ready(rc_ctx* ctx) {
 const BodyConst* rc_ctx_body(rc_ctx* ctx) { return ctx->have_body ? ctx->body : nullptr; }
 int rc_ctx_fail(rc_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg); }
 SmplifyState*& rc_ctx_smplify(rc_ctx* ctx) { return ctx->smplify; }
+unsigned long long rc_ctx_ign_mask(rc_ctx* ctx) { return ctx->ign_mask; }
 
 extern "C" {
 
@@ -819,11 +821,21 @@ int rc_position_error(const float* p, const float* t, int64_t n, float* dist, do
     }
     return RC_OK;
 }
+int rc_set_ignored_landmarks(rc_ctx* ctx, const int32_t* ids, int32_t n) {
+    if (!ctx || n < 0 || (n > 0 && !ids)) return RC_ERR_INVALID;
+    unsigned long long m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] > 32) return fail(ctx, RC_ERR_INVALID, "rc_set_ignored_landmarks: id outside 0..32");
+        m |= 1ull << ids[i];
+    }
+    ctx->ign_mask = m;
+    return RC_OK;
+}
 int rc_reproj_residual(rc_ctx* ctx, const float* pose, const float* tran, const float* kp, const float* K, float sigma, float* loss,
                        int64_t T, void* stream) {
     if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_reproj_residual: body not set") : RC_ERR_INVALID;
     if (!pose || !tran || !kp || !K || !loss) return fail(ctx, RC_ERR_INVALID, "rc_reproj_residual: null buffer");
-    rc_launch_residual(ctx->body, pose, tran, kp, K, sigma, loss, T, (hipStream_t)stream);
+    rc_launch_residual(ctx->body, pose, tran, kp, K, sigma, ctx->ign_mask, loss, T, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
 }

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void rc_body_mesh_kernel(const BodyConst* __re
 // smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
 // (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
 __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
-                                                         const float* kp, const float* K, float sigma, float* loss) {
+                                                         const float* kp, const float* K, float sigma, unsigned long long ign_mask,
+                                                         float* loss) {
     __shared__ WaveScratch s;
     const long long b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __rest
         const float u = (K[0] * q[0] + K[1] * q[1]) + K[2] * q[2];
         const float v = (K[3] * q[0] + K[4] * q[1]) + K[5] * q[2];
         const float* k3 = kp + (b * 33 + lane) * 3;
-        const bool ign = (lane >= 1 && lane <= 9) || lane == 31 || lane == 32;
+        const bool ign = (ign_mask >> lane) & 1ull;
         const float cf = ign ? 0.0f : k3[2];
         const float s2 = sigma * sigma;
         const float dx = u - k3[0], dy = v - k3[1];
@@ -644,7 +645,7 @@ void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w,
     hipLaunchKernelGGL(rc_body_mesh_kernel, dim3((unsigned)n), dim3(256), 0, st, body, vt, w, V, pose, tran, vert);
 }
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K, float sigma,
-                        float* loss, long long T, hipStream_t st) {
+                        unsigned long long ign_mask, float* loss, long long T, hipStream_t st) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(rc_residual_kernel, dim3((unsigned)T), dim3(64), 0, st, body, pose, tran, kp, K, sigma, loss);
+    hipLaunchKernelGGL(rc_residual_kernel, dim3((unsigned)T), dim3(64), 0, st, body, pose, tran, kp, K, sigma, ign_mask, loss);
 }

@@ -150,7 +150,8 @@ void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tr
 void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w, int V, const float* pose, const float* tran,
                          float* vert, long long n, hipStream_t s);
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
-                        float sigma, float* loss, long long T, hipStream_t s);
+                        float sigma, unsigned long long ign_mask, float* loss, long long T, hipStream_t s);
+#define RC_IGN_DEFAULT 0x1800003FEull     // MediaPipe landmarks {1..9, 31, 32} (temporal_smplify.py:92); use_head: {31, 32}
 void rc_launch_mesh_metrics(const BodyConst* body, const float* vt, const float* w, int V, const float* Jr, int nk, const float* pose_p,
                             const float* pose_t, float* out, long long n, hipStream_t s);
 void rc_launch_imu_frames(const BodyConst* body, const float* vt, const float* w, const int* vid, const int* jid, const float* pose,
@@ -178,6 +179,7 @@ struct SmplifyArgs {
     float* grad_aa;         // [T,72]  } one flat vector [T*72 | T*3], the optimiser's parameter order
     float* grad_tran;       // [T,3]   } (temporal_smplify.py:141: [body_pose, tran])
     float K[9];
+    unsigned long long ign_mask;   // landmarks whose confidence counts as zero (bit v)
     int T;
 };
 void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t s);
@@ -188,4 +190,5 @@ struct SmplifyState;
 const BodyConst* rc_ctx_body(rc_ctx* ctx);                 // nullptr until rc_set_body
 int rc_ctx_fail(rc_ctx* ctx, int code, const char* msg);   // records the message, returns code
 SmplifyState*& rc_ctx_smplify(rc_ctx* ctx);
+unsigned long long rc_ctx_ign_mask(rc_ctx* ctx);
 void rc_smplify_free(SmplifyState* s);

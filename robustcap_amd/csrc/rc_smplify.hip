@@ -21,7 +21,6 @@
 #define SM_NG 8
 #define SM_DIM 69
 
-__device__ __forceinline__ bool ignored_landmark(int v) { return (v >= 1 && v <= 9) || v == 31 || v == 32; }
 
 // net/smplify/temporal_smplify.py:25-59: R = I + sin(th) K + (1 - cos(th)) K^2, th = |v + 1e-8|, K = [v / th]x
 __device__ __forceinline__ void batch_rodrigues(const float* v, float* R) {
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const
         A.proj[((long long)t * 33 + lane) * 2] = u;
         A.proj[((long long)t * 33 + lane) * 2 + 1] = v;
         const float* k3 = A.kp + ((long long)t * 33 + lane) * 3;
-        const float cf = ignored_landmark(lane) ? 0.0f : k3[2];
+        const float cf = ((A.ign_mask >> lane) & 1ull) ? 0.0f : k3[2];
         part = (cf * cf) * (gmof(u - k3[0]) + gmof(v - k3[1]));                          // losses.py:43-46
         if (lane >= 1) {                                                               // losses.py:31-33
             const float* r = A.ref3d + (long long)t * 99;
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, con
         const int v = tid;
         const float x = s.J33[v][0], y = s.J33[v][1], z = s.J33[v][2];
         const float* k3 = A.kp + ((long long)t * 33 + v) * 3;
-        const float cf = ignored_landmark(v) ? 0.0f : k3[2], c2 = cf * cf;
+        const float cf = ((A.ign_mask >> v) & 1ull) ? 0.0f : k3[2], c2 = cf * cf;
         const float u = A.proj[((long long)t * 33 + v) * 2], w = A.proj[((long long)t * 33 + v) * 2 + 1];
         float du = c2 * gmof_d(u - k3[0]), dv = c2 * gmof_d(w - k3[1]);                 // reprojection
         float lam[3] = {0.f, 0.f, 0.f};
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, con
         }
         if (t + 1 < T) {                                                               // pair (t, t+1): conf of t+1
             const float* kn = A.kp + ((long long)(t + 1) * 33 + v) * 3;
-            const float cn = ignored_landmark(v) ? 0.0f : kn[2], cn2 = cn * cn;
+            const float cn = ((A.ign_mask >> v) & 1ull) ? 0.0f : kn[2], cn2 = cn * cn;
             const float* pn = A.proj + ((long long)(t + 1) * 33 + v) * 2;
             const float* mn = A.mj + ((long long)(t + 1) * 33 + v) * 3;
             du -= 1e-4f * cn2 * sgn(pn[0] - u);

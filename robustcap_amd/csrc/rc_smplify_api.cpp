@@ -84,7 +84,7 @@ int reserve(rc_ctx* ctx, SmplifyState* s, int64_t T) {
 }
 
 SmplifyArgs make_args(SmplifyState* s, const float* x, const float* kp, const float* ref3d, const float* imu_aa, const float* K,
-                      float* grad, int64_t T) {
+                      float* grad, int64_t T, unsigned long long ign_mask) {
     SmplifyArgs A{};
     A.aa = x; A.tran = x + T * 72;
     A.kp = kp; A.ref3d = ref3d; A.imu_aa = imu_aa;
@@ -94,6 +94,7 @@ SmplifyArgs make_args(SmplifyState* s, const float* x, const float* kp, const fl
     A.argmin = s->argmin;
     A.grad_aa = grad; A.grad_tran = grad + T * 72;
     for (int q = 0; q < 9; ++q) A.K[q] = K[q];
+    A.ign_mask = ign_mask;
     A.T = (int)T;
     return A;
 }
@@ -150,7 +151,7 @@ int rc_smplify_loss_grad(rc_ctx* ctx, const float* x, const float* kp, const flo
     if (!x || !kp || !ref3d || !imu_aa || !K || !grad) return rc_ctx_fail(ctx, RC_ERR_INVALID, "rc_smplify_loss_grad: null buffer");
     if (int rc = reserve(ctx, s, T)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    rc_launch_smplify(make_args(s, x, kp, ref3d, imu_aa, K, grad, T), body, st);
+    rc_launch_smplify(make_args(s, x, kp, ref3d, imu_aa, K, grad, T, rc_ctx_ign_mask(ctx)), body, st);
     SM_TRY(ctx, hipGetLastError());
     SM_TRY(ctx, hipMemcpyAsync(s->h_terms, s->terms, (size_t)T * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     SM_TRY(ctx, hipStreamSynchronize(st));
@@ -180,7 +181,7 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
 
     // pre-check (run.py:24-29): mean residual of the FIRST frame against the threshold
     SM_TRY(ctx, hipMemcpyAsync(s->Kd, K, 9 * sizeof(float), hipMemcpyHostToDevice, st));
-    rc_launch_residual(body, pose, tran, kp, s->Kd, 100.0f, s->res0, T, st);
+    rc_launch_residual(body, pose, tran, kp, s->Kd, 100.0f, rc_ctx_ign_mask(ctx), s->res0, T, st);
     SM_TRY(ctx, hipMemcpyAsync(s->h_res, s->res0, (size_t)T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
     SM_TRY(ctx, hipStreamSynchronize(st));
     auto frame_mean = [](const float* r) {                  // torch mean(dim=-1) of 33 fp32 values
@@ -209,7 +210,7 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
     const size_t n = (size_t)T * 75;
     L::Vec x(s->h_x, s->h_x + n);
     int hip_rc = RC_OK;
-    const SmplifyArgs A = make_args(s, s->x, kp, s->ref3d, s->imu_aa, K, s->grad, T);
+    const SmplifyArgs A = make_args(s, s->x, kp, s->ref3d, s->imu_aa, K, s->grad, T, rc_ctx_ign_mask(ctx));
     L::Objective closure = [&](const L::Vec& xv, L::Vec& g) -> float {
         std::memcpy(s->h_x, xv.data(), n * sizeof(float));
         hipError_t e = hipMemcpyAsync(s->x, s->h_x, n * sizeof(float), hipMemcpyHostToDevice, st);
@@ -242,7 +243,7 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
     SM_TRY(ctx, hipMemcpyAsync(s->x, s->h_x, n * sizeof(float), hipMemcpyHostToDevice, st));
     rc_launch_aa2R(s->x, pose_out, T * 24, st);
     SM_TRY(ctx, hipMemcpyAsync(tran_out, s->x + T * 72, (size_t)T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    rc_launch_residual(body, pose_out, tran_out, kp, s->Kd, 100.0f, s->res1, T, st);
+    rc_launch_residual(body, pose_out, tran_out, kp, s->Kd, 100.0f, rc_ctx_ign_mask(ctx), s->res1, T, st);
     SM_TRY(ctx, hipMemcpyAsync(s->h_res + T * 33, s->res1, (size_t)T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
     SM_TRY(ctx, hipStreamSynchronize(st));
     SM_TRY(ctx, hipGetLastError());

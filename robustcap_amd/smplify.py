@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from . import body as _body
+from . import config as cfg
 
 
 def load_gmm_pickle(path):
@@ -43,14 +44,26 @@ def prior_arrays(gmm):
 class TemporalSMPLify:
     """Device-side optimiser state: body constants, pose prior, work buffers (reused across sequences)."""
 
-    def __init__(self, body=None, smpl_file=None, gmm=None, gmm_file=None, device="cuda"):
+    def __init__(self, body=None, smpl_file=None, gmm=None, gmm_file=None, device="cuda", use_head=False):
         self.model = _body.ParametricModel(smpl_file, device=device, body=body)
         self.device = self.model.device
         self._lib, self._ctx = self.model._lib, self.model._ctx
         self.has_prior = False
+        self.use_head = None
+        self.set_use_head(use_head)
         if gmm is not None or gmm_file is not None:
             self.set_prior(gmm if gmm is not None else load_gmm_pickle(gmm_file))
         self.last_info = None
+
+    def set_use_head(self, use_head):
+        """temporal_smplify.py:92-94: the landmarks whose confidence is zeroed -- face + feet tips {1..9, 31, 32}, or only
+        {31, 32} with ``use_head=True`` (the TotalCapture evaluation, evaluate.py:352)."""
+        if use_head == self.use_head:
+            return
+        ids = (31, 32) if use_head else cfg.smplify_ignored_landmarks
+        arr = (C.c_int32 * len(ids))(*ids)
+        _lib.check(self._ctx, self._lib.rc_set_ignored_landmarks(self._ctx, arr, len(ids)), "rc_set_ignored_landmarks")
+        self.use_head = bool(use_head)
 
     def set_prior(self, gmm):
         means, prec, nllw = prior_arrays(gmm)
@@ -107,11 +120,12 @@ def smplify_runner(pred_pose, pred_tran, j2dc, imu_ori, batch_size, cam_k, lr=1.
     cam_k [3,3]. Returns (pose [T,24,3,3] cpu, tran [T,3] cpu, update) with update None if the sequence failed the
     pre-check. ``runner`` (a TemporalSMPLify with the prior set) is reused across calls; otherwise ``body`` and
     ``gmm`` build one."""
-    if shape is not None or use_head:
-        raise NotImplementedError("shape / use_head variants are outside the built path (mean shape, ignored head landmarks)")
+    if shape is not None:
+        raise NotImplementedError("shape= is outside the built path (mean shape only, articulate/model.py:86-87)")
     if not use_lbfgs or opt_steps != 1:
         raise NotImplementedError("the reference only runs use_lbfgs=True, opt_steps=1 (evaluate.py:89)")
     runner = runner or TemporalSMPLify(body=body, gmm=gmm)
+    runner.set_use_head(use_head)
     if not runner.has_prior:
         raise _lib.RobustcapLibraryError("smplify_runner needs the GMM pose prior (gmm= or TemporalSMPLify.set_prior)")
     T = int(batch_size)

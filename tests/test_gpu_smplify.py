@@ -43,6 +43,23 @@ def test_closure_matches_reference_capture(g, runner):
     assert float((gt.cpu() - t(g["ev_grad_tran"])).abs().max()) <= 1e-4 * gs
 
 
+def test_use_head_variant_matches_reference_capture(g, synth_assets):
+    """use_head=True (temporal_smplify.py:93-94, the TotalCapture evaluation): only landmarks {31, 32} ignored."""
+    from robustcap_amd.smplify import TemporalSMPLify
+    r = TemporalSMPLify(body=synth_assets["body"], gmm=synth.make_gmm(3), use_head=True)
+    loss, gp, gt = r.loss_and_grad(t(g["ev_pose"]), t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_ref3d"]), _imu_aa(t(g["ev_imu_ori"])), t(g["ev_K"]))
+    assert abs(loss - float(g["evh_loss"])) <= 1e-5 * abs(float(g["evh_loss"]))
+    gs = max(np.abs(g["evh_grad_pose"]).max(), np.abs(g["evh_grad_tran"]).max())
+    assert float((gp.cpu() - t(g["evh_grad_pose"])).abs().max()) <= 1e-4 * gs
+    assert float((gt.cpu() - t(g["evh_grad_tran"])).abs().max()) <= 1e-4 * gs
+    pose = S.batch_rodrigues(t(g["ev_pose"]).view(-1, 3)).view(-1, 24, 3, 3)
+    res = r.get_fitting_loss(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_K"]))
+    assert float((res.cpu() - t(g["evh_residual"])).abs().max()) <= 1e-4 * float(g["evh_residual"].max())
+    r.set_use_head(False)                                          # back to the default mask on the same context
+    loss0, _, _ = r.loss_and_grad(t(g["ev_pose"]), t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_ref3d"]), _imu_aa(t(g["ev_imu_ori"])), t(g["ev_K"]))
+    assert abs(loss0 - float(g["ev_loss"])) <= 1e-5 * abs(float(g["ev_loss"]))
+
+
 @pytest.mark.parametrize("T,seed", [(1, 5), (2, 6), (37, 7)])
 def test_closure_matches_oracle(T, seed, synth_assets, runner):
     """Seeded poses away from the capture, including T=1 (no temporal terms) and a ragged length."""

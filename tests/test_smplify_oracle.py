@@ -34,6 +34,25 @@ def test_closure_loss_and_gradient(g, synth_assets):
     assert float((tr.grad - t(g["ev_grad_tran"])).abs().max()) <= 1e-4 * gs
 
 
+def test_use_head_variant(g, synth_assets):
+    """use_head=True (temporal_smplify.py:93-94): only landmarks {31, 32} are ignored."""
+    obody, prior = O.OracleBody(synth_assets["body"]), S.Prior(synth.make_gmm(3))
+    bp = t(g["ev_pose"]).clone().requires_grad_(True)
+    tr = t(g["ev_tran"]).clone().requires_grad_(True)
+    kp = t(g["ev_kp"])
+    conf = kp[:, :, 2].clone()
+    conf[:, [31, 32]] = 0.0
+    loss = S.fitting_loss(obody, prior, bp, tr, kp[:, :, :2], conf, t(g["ev_K"]), t(g["ev_ref3d"]), t(g["ev_imu_ori"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["evh_loss"])) <= 1e-5 * abs(float(g["evh_loss"]))
+    gs = max(np.abs(g["evh_grad_pose"]).max(), np.abs(g["evh_grad_tran"]).max())
+    assert float((bp.grad - t(g["evh_grad_pose"])).abs().max()) <= 1e-4 * gs
+    pose = S.batch_rodrigues(t(g["ev_pose"]).view(-1, 3)).view(-1, 24, 3, 3)
+    res = O.reprojection_residual(obody, pose, t(g["ev_tran"]), kp, t(g["ev_K"]), ignored=(31, 32))
+    assert float((res - t(g["evh_residual"])).abs().max()) <= 1e-4 * float(g["evh_residual"].max())
+    assert float(g["evh_loss"]) > float(g["ev_loss"])                       # the head landmarks add residual
+
+
 def test_runner_matches_reference_statistically(g, synth_assets):
     """The first closure evaluations agree to 1e-7; from the third line-search step on, the cubic interpolation of
     torch's strong-Wolfe search amplifies float32 noise in the loss differences (37 on 1.2e5) and the two L-BFGS paths
