@@ -124,12 +124,23 @@ def main():
     run(0, W, True)
     sync()
     t0 = time.perf_counter()
-    pose, tran = run(W, T, False)
-    if world > 1:      # the path's only collective: final gather of the outputs to rank 0 (RCCL over xGMI)
-        gp = rdist.gather_rows(pose.reshape(B, -1), B * world, dst=0)
-        gt = rdist.gather_rows(tran.reshape(B, -1), B * world, dst=0)
+    if world > 1:
+        # The path's only exchange: the outputs go to rank 0 (RCCL over xGMI). The K steps are enqueued in 4 chunks and
+        # each chunk's gather starts as soon as its kernels are queued, so all but the last transfer hide behind compute.
+        edges = [W + (K * c) // 4 for c in range(5)]
+        gathers = []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi > lo:
+                p, tr = run(lo, hi, False)
+                gathers.append((rdist.RowGather(p.reshape(B, -1)), rdist.RowGather(tr.reshape(B, -1)), hi - lo))
+        parts = [(gp.result(), gt.result(), n) for gp, gt, n in gathers]
         if rank == 0:
-            pose, tran = gp, gt
+            pose = torch.cat([p.view(world * B, n, 24, 3, 3) for p, _, n in parts], dim=1)
+            tran = torch.cat([q.view(world * B, n, 3) for _, q, n in parts], dim=1)
+        else:
+            pose, tran = p, tr
+    else:
+        pose, tran = run(W, T, False)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

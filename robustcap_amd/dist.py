@@ -72,6 +72,28 @@ def gather_rows(local, n_rows_total, dst=None):
     return torch.cat([o[:b - a] for o, (a, b) in zip(out, sizes)], dim=0)
 
 
+class RowGather:
+    """Asynchronous gather of EQUAL-sized row blocks to rank ``dst``: started right after the producing kernels are
+    enqueued, it runs on the collective's own stream (RCCL over xGMI: 7 point-to-point transfers into ``dst``) while the
+    caller keeps enqueueing compute; ``result()`` makes the current stream wait and returns the [world * n, ...] tensor on
+    ``dst`` (None elsewhere). Under gloo (CPU hosts, dry runs) the block is staged through the host."""
+
+    def __init__(self, local, dst=0):
+        self.dst, self.device = dst, local.device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.stage = dist.get_backend() == "gloo" and local.is_cuda
+        self.src = local.contiguous().cpu() if self.stage else local.contiguous()       # kept alive until result()
+        self.parts = [torch.empty_like(self.src) for _ in range(self.world)] if self.rank == dst else None
+        self.work = dist.gather(self.src, self.parts, dst=dst, async_op=True)
+
+    def result(self):
+        self.work.wait()
+        if self.rank != self.dst:
+            return None
+        out = torch.cat(self.parts, dim=0)
+        return out.to(self.device) if self.stage else out
+
+
 def run_sharded(step_fn, inputs, n_rows_total):
     """Run ``step_fn(*row_block_of_each_input)`` on this rank's rows and gather every output over all ranks.
 

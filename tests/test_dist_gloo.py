@@ -51,6 +51,14 @@ def _worker(rank, world, port, B, T, out_dir):
     a, b = rdist.shard_range(B, rank, world)                       # gather-to-root variant (bench.py uses it)
     g = rdist.gather_rows(tran[a:b].contiguous(), B, dst=0)
     assert (g is None) == (rank != 0) and (rank != 0 or torch.equal(g, tran))
+    # asynchronous equal-block gathers, several in flight (bench.py's chunked output exchange)
+    blocks = [torch.full((2, 5), float(10 * rank + c)) for c in range(3)]
+    pending = [rdist.RowGather(blk, dst=0) for blk in blocks]
+    for c, h in enumerate(pending):
+        out = h.result()
+        assert (out is None) == (rank != 0)
+        if rank == 0:
+            assert out.shape == (2 * world, 5) and all(float(out[2 * q, 0]) == 10 * q + c for q in range(world))
     torch.save((pose, tran), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
