@@ -59,3 +59,40 @@ def test_errors_are_codes_not_exceptions():
             Net(body={"J": None}, batch=1)
     assert lib.rc_step(None, None, None, None, None, 0, None, None, None) == -1
     assert lib.rc_destroy(None) == 0
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is usable from C: the header compiles as strict C99 and a C program links against the library and
+    calls host-only entry points (no GPU needed: parameter defaults, error strings, the float64 L-BFGS)."""
+    import shutil
+    import subprocess
+    from robustcap_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "robustcap_hip.h"
+static double quad(void* user, const double* x, double* g, int64_t n) {
+    double f = 0.0; (void)user;
+    for (int64_t i = 0; i < n; ++i) { const double d = x[i] - (double)(i + 1); f += d * d; g[i] = 2.0 * d; }
+    return f;
+}
+int main(void) {
+    rc_params p;
+    if (rc_default_params(1, &p) != 0 || p.conf_lo != 0.85 || p.live != 1) return 2;
+    if (rc_destroy(NULL) != 0) return 3;
+    double x[4] = {0, 0, 0, 0}, losses[32];
+    int32_t it = 0, ev = 0;
+    if (rc_lbfgs_minimize(quad, NULL, 4, x, 1.0, 20, 25, 100, 1e-7, 1e-9, &it, &ev, losses, 32) != 0) return 4;
+    for (int i = 0; i < 4; ++i) if (x[i] < i + 1 - 1e-6 || x[i] > i + 1 + 1e-6) return 5;
+    printf("ok %d %d\n", it, ev);
+    return 0;
+}
+''')
+    inc = os.path.dirname(_lib.HEADER_PATH)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                    _lib.LIB_PATH, "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok ")
