@@ -233,7 +233,8 @@ int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, voi
 int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream);
 
 /* Timing hook for bench.py: accumulate HIP-event time of the gate-GEMM launches on their own stream.
- * enable != 0 starts recording; rc_gemm_timing_read returns total milliseconds and launch count so far. */
+ * enable = 1 records every gate-GEMM launch, enable = 2 only those of the wide-tile kernel rc_gemm_kernel (the 16-row
+ * launches run on rc_gemm_small_kernel), 0 stops; rc_gemm_timing_read returns total milliseconds and launch count so far. */
 int rc_gemm_timing(rc_ctx* ctx, int32_t enable);
 int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches);
 

@@ -45,6 +45,9 @@ INIT_NET = ((69, 512), (512, 1024), (1024, 2048))
 
 # 2 * MACs of one pass of all six nets (linear1 + 2 LSTM layers + linear2), SURVEY.md section 8(d)
 FLOPS_PER_BODY_FRAME = 121_379_840
+# of which the six linear2 layers (2 * H * out each); at batch > 16 they run on rc_gemm_small_kernel, everything else
+# (linear1 + both LSTM layers of all six sub-nets) on rc_gemm_kernel
+FLOPS_LINEAR2_PER_BODY_FRAME = 2 * (512 * 69 + 512 * 3 + 1280 * 69 + 1024 * 3 + 512 * 144 + 512 * 2)
 
 
 def state_dict_spec():

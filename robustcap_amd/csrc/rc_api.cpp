@@ -83,6 +83,7 @@ struct rc_ctx {
     bool live_prev_known = false;
     // timing of the gate GEMM launches
     bool timing = false;
+    int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernel (rc_gemm_kernel)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double timed_ms = 0.0;
@@ -205,6 +206,9 @@ GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
     GemmProblem p = dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit,
                                   s.flags ? s.flags : c->fb.flags, n.steps, true);
+    if (s.rows_hint >= 0 && s.rows_hint <= 16) {      // few-row stage: 16 x 16 tiles like its LSTM launches (small-tile kernel)
+        p.mr = 1; p.nc = 1; p.n_tiles = n.lin1.Np / 16;
+    }
     if (s.rows_hint >= 0 && s.rows_hint < c->B) p.m_tiles = (s.rows_hint + 16 * p.mr - 1) / (16 * p.mr);
     p.alt_base = s.x_alt; p.sel_flags = c->fb.flags; p.sel_bit = s.x_alt ? s.sel_bit : 0;
     return p;
@@ -252,7 +256,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
         L.p[i] = ordered[i];
     }
     L.n = (int)ordered.size();
-    if (ctx->timing) {
+    if (ctx->timing && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
         if (ctx->ev_used == ctx->ev_pool.size()) {
             hipEvent_t a, b;
             HIP_TRY(ctx, hipEventCreate(&a));
@@ -910,6 +914,7 @@ int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream) {
 int rc_gemm_timing(rc_ctx* ctx, int32_t enable) {
     if (!ctx) return RC_ERR_INVALID;
     ctx->timing = enable != 0;
+    if (enable) ctx->timing_mode = enable == 2 ? 2 : 1;
     if (enable) { ctx->ev_used = 0; ctx->timed_ms = 0.0; ctx->timed_launches = 0; }
     return RC_OK;
 }

@@ -325,9 +325,13 @@ __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const Gemm
     else gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem);
 }
 
-void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
+bool rc_gemm_is_small(const GemmLaunch& L) {
     bool small = true;
     for (int q = 0; q < L.n; ++q) small = small && L.p[q].mr == 1 && L.p[q].nc <= 2;
-    if (small) hipLaunchKernelGGL(rc_gemm_small_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
+    return small;
+}
+
+void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
+    if (rc_gemm_is_small(L)) hipLaunchKernelGGL(rc_gemm_small_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
     else hipLaunchKernelGGL(rc_gemm_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
 }

@@ -127,6 +127,7 @@ struct rc_params_dev {
 };
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
+bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_gemm_small_kernel (16-row tiles only)
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,

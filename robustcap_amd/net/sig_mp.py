@@ -248,6 +248,7 @@ class Net:
         return t
 
     def gemm_timing(self, enable):
+        """0 off, 1 (True) every gate-GEMM launch, 2 only the launches of the wide-tile kernel rc_gemm_kernel."""
         _lib.check(self._ctx, self._lib.rc_gemm_timing(self._ctx, int(enable)), "rc_gemm_timing")
 
     def gemm_timing_read(self):
