@@ -180,8 +180,11 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     p.open_step = open_step ? 1 : 0;
     // batch <= 16 (live mode): every launch of the frame is weight streaming -> 16 x 16 tiles throughout (twice the workgroups and the 8-deep load pipeline), which also
     // keeps each launch homogeneous so that it runs on the high-occupancy small-tile kernel
-    const int mr = ctx->B <= 16 ? 1 : d.mr, nc = ctx->B <= 16 ? 1 : d.nc;
-    p.n_tiles = d.Np / (16 * nc); p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr); p.Kp = d.Kp; p.nc = nc; p.mr = mr;
+    // narrow layers (linear2, N <= 160) also run 16 x 16 tiles at any batch: +0.7 % on the bench over 16 x 32
+    const bool narrow = ctx->B <= 16 || d.N <= 160;
+    const int mr = narrow ? 1 : d.mr, nc = narrow ? 1 : d.nc;
+    p.n_tiles = nc == 1 ? (d.N + 15) / 16 : d.Np / (16 * nc);          // 16-wide tiles: skip the all-padding ones
+    p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr); p.Kp = d.Kp; p.nc = nc; p.mr = mr;
     return p;
 }
 
@@ -207,7 +210,7 @@ GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     GemmProblem p = dense_problem(c, n.lin1, seg(s.x, s.ldx, 0), Out{n.x1, n.H, 0, true}, true, s.flag_bit,
                                   s.flags ? s.flags : c->fb.flags, n.steps, true);
     if (s.rows_hint >= 0 && s.rows_hint <= 16) {      // few-row stage: 16 x 16 tiles like its LSTM launches (small-tile kernel)
-        p.mr = 1; p.nc = 1; p.n_tiles = n.lin1.Np / 16;
+        p.mr = 1; p.nc = 1; p.n_tiles = (n.lin1.N + 15) / 16;
     }
     if (s.rows_hint >= 0 && s.rows_hint < c->B) p.m_tiles = (s.rows_hint + 16 * p.mr - 1) / (16 * p.mr);
     p.alt_base = s.x_alt; p.sel_flags = c->fb.flags; p.sel_bit = s.x_alt ? s.sel_bit : 0;
