@@ -89,6 +89,7 @@ struct rc_ctx {
     double timed_ms = 0.0;
     long long timed_launches = 0;
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
+    int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
 };
 
 namespace {
@@ -256,9 +257,11 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
         ordered[i].wg_base = base;
         if (flags_override) ordered[i].flags = flags_override;
         base += round_up(ordered[i].n_tiles * ordered[i].m_tiles, 8);
+        ordered[i].trace_base = ctx->trace_next;
         L.p[i] = ordered[i];
     }
     L.n = (int)ordered.size();
+    ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
     if (ctx->timing && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
         if (ctx->ev_used == ctx->ev_pool.size()) {
             hipEvent_t a, b;

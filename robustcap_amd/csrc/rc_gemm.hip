@@ -20,6 +20,21 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DRC_TRACE_TILES (tools/tile_trace.py): every workgroup stores {block, tile shape | rows, CU, tile, 4 wall-clock
+// stamps} into slot (launch base + block id) of a host-provided buffer -- per-CU timelines of a launch, no atomics.
+// Not compiled into the product library.
+#ifdef RC_TRACE_TILES
+__device__ unsigned long long* g_trace_buf = nullptr;
+__device__ unsigned long long g_trace_cap = 0;
+extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long cap_records) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap_records, sizeof(cap_records)) == hipSuccess ? 0 : -1;
+}
+#define TRACE_T(i) do { if (threadIdx.x == 0) trace_t[i] = wall_clock64(); } while (0)
+#else
+#define TRACE_T(i) do { } while (0)
+#endif
+
 #define LDS_PAD 16            // floats added to a partial-sum row: epilogue rows land on different banks
 
 #ifndef RC_ABLATE
@@ -81,6 +96,10 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 template <int MR, int NC, int D, bool PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
+#ifdef RC_TRACE_TILES
+    unsigned long long trace_t[4] = {0, 0, 0, 0};
+    bool traced = false;
+#endif
   // Row tiles m_tile0, m_tile0 + m_tiles, ... : stages that expect only a few active rows launch a single row tile per
   // column tile and still cover any number of rows (a full grid of row tiles would mostly be workgroups that scan the
   // flags and exit: 9,216 of them per launch at batch 256 with 16-row tiles).
@@ -90,6 +109,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     float* s_part = s_mem + 128;                                    // [RC_NW][MT][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    TRACE_T(0);
     // ---- active rows of this tile -------------------------------------------------------------------------
     const int lo = m_tile * MT;
     int nrows;
@@ -154,6 +174,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     const float* pb = P.W + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
     const int kbase = wave * Qw * RC_KC;
 
+    TRACE_T(1);
     f32x4 acc[MR][NC];
 #pragma unroll
     for (int r = 0; r < MR; ++r)
@@ -216,6 +237,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #undef LOADC
 #undef SB
 
+    TRACE_T(2);
     // ---- split-K reduction through LDS (C layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg) --------
 #pragma unroll
     for (int r = 0; r < MR; ++r)
@@ -267,6 +289,18 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             }
         }
     }
+#ifdef RC_TRACE_TILES
+    if (threadIdx.x == 0 && !traced && g_trace_buf) {
+        traced = true;
+        const unsigned long long idx = (unsigned long long)P.trace_base + blockIdx.x;
+        if (idx < g_trace_cap) {
+            unsigned long long* r = g_trace_buf + idx * 8;
+            r[0] = (unsigned long long)blockIdx.x + 1; r[1] = (unsigned long long)(MR * 16 + NC) | ((unsigned long long)nrows << 16);
+            r[2] = __smid(); r[3] = (unsigned long long)n_tile | ((unsigned long long)m_tile << 32);
+            r[4] = trace_t[0]; r[5] = trace_t[1]; r[6] = trace_t[2]; r[7] = wall_clock64();
+        }
+    }
+#endif
   }   // row-tile loop
 }
 

@@ -73,6 +73,8 @@ struct GemmProblem {
     int n_tiles, m_tiles, wg_base, Kp;
     int nc;                 // 16-column blocks per tile
     int mr;                 // 16-row blocks per tile (2 or 4); (mr, nc) must be one of the instantiated shapes
+    int trace_base;         // first record slot of this launch (read by -DRC_TRACE_TILES builds only)
+    int pad_;
 };
 
 struct GemmLaunch {
