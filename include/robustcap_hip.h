@@ -105,7 +105,9 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
 /* ---- live / streaming mode (BASELINE config 5) ------------------------------------------------------------- */
 /* The live_server.py loop (live_server.py:40-48): one frame per call, HOST tensors in and out exactly like
  * forward_online's CPU tensors. rc_live_begin captures the steady-state frame (H2D of the 171 input floats per row,
- * the 17 kernels, D2H of the 219 output floats) into ONE hipGraph on a private stream; rc_live_step replays it
+ * the 14 kernels, D2H of the 219 output floats; for batch <= 16 the kernels access the pinned host buffers directly and
+ * the copies disappear) into a hipGraph on a private stream -- twice, with and without the three transition launches;
+ * rc_live_step replays the short one when the confidences it was handed rule out a transition step, else the full one
  * (frames with first_tran / RC_FLAG_FIRST_FRAME take the ordinary enqueue path) and returns when the outputs are in
  * host memory. j2dc[batch,33,3], accc[batch,6,3], oric[batch,6,3,3], first_tran[batch,3]|NULL -> pose[batch,24,3,3],
  * tran[batch,3]. */

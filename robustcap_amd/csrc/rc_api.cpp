@@ -1,13 +1,15 @@
 // C ABI of librobustcap_hip.so (see include/robustcap_hip.h): context, weight repacking, per-frame launch plan.
 //
-// Host logic only; all arithmetic runs in rc_gemm.hip / rc_frame.hip. The launch plan of one frame mirrors the
-// data flow of Net.forward_online (net/sig_mp.py:113-274):
-//   prep -> {rnn2, rnn4}            (4 fused launches: linear1, LSTM l0, LSTM l1, linear2)
+// Host logic only; all arithmetic runs in the .hip files. The launch plan of one frame mirrors the data flow of
+// Net.forward_online (net/sig_mp.py:113-274), with the vision updater of frame t-1 executed at the start of frame t:
+//   prep -> {rnn6, rnn4} transition steps of rows whose deferred updater step must precede this frame's own step
+//                                          (3 fused launches: linear1, LSTM l0, LSTM l1; usually a handful of rows)
+//        -> {rnn4 (+ rows whose deferred step merges into it), rnn2}          (4 fused launches: + linear2)
 //        -> [first frame: rnn6 on every row, L155-156]
-//        -> fuse -> {rnn3, rnn6, rnn7, rnn8, rnn2.init_net}   (4 fused launches)
-//        -> tail -> {rnn6, rnn4} on re-projected landmarks  (3 fused launches, outputs unused)
-// Independent sub-nets share a launch ("problems" of one rc_gemm_kernel grid) so the chip sees 500-1300
-// workgroups per launch instead of 128-640.
+//        -> fuse -> {rnn6 (+ merged deferred rows), rnn3, rnn7, rnn8, rnn2.init_net}          (4 fused launches)
+//        -> tail (fusion logic, FK, landmarks; marks the rows whose updater step is now pending)
+// Independent sub-nets share a launch ("problems" of one gate-GEMM grid) so the chip sees 500-1300 workgroups per
+// LSTM launch instead of 128-640. 14 kernel launches per frame, no host synchronisation.
 #include "../../include/robustcap_hip.h"
 #include "rc_internal.h"
 

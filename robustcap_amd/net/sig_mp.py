@@ -188,7 +188,7 @@ class Net:
     @torch.no_grad()
     def forward_live(self, j2dc, accc, oric, first_tran=None, first_frame=False):
         """Streaming step for all rows with HOST tensors in and out (live_server.py:40-48): one captured hipGraph
-        per frame (H2D + 17 kernels + D2H). Returns CPU tensors pose [B,24,3,3], tran [B,3]."""
+        per frame (14 kernels, or 11 when no row can need a transition step; inputs and outputs in pinned host memory). Returns CPU tensors pose [B,24,3,3], tran [B,3]."""
         B = self.batch
         self._sync_gravity()
         if not self.__dict__.get("_live_on"):
