@@ -9,7 +9,8 @@ A step = one frame of the hot path (prep -> 6 LSTM sub-nets -> fusion/FK tail ->
 of 256 bodies per GPU, inputs resident in HBM. Workload = BASELINE.json configs[1]: synthetic 60 fps sequences,
 6 IMUs + 33 keypoints, batch 256 x 512 frames, mixed-confidence schedule (50 % high /
 20 % mid / 30 % occluded, which forces the frame-stepped path incl. the vision updater). Weak scaling: every rank
-runs its own 256 bodies; outputs are gathered to rank 0 (RCCL) inside the timed region for N > 1.
+runs its own 256 bodies; for N > 1 the outputs are gathered to rank 0 (RCCL) inside the timed region, in four
+asynchronous chunks that overlap the remaining frames.
 
 Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
 """
@@ -30,7 +31,6 @@ from robustcap_amd import dist as rdist  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA (16x16x4 / 32x32x2), dense
-GEMM_LAUNCHES_PER_FRAME = 11           # 3 + 4 + 4 fused gate-GEMM launches (rc_api.cpp step_impl): 6 wide-tile, 5 small-tile
 
 
 def pmc_traffic():
@@ -59,7 +59,7 @@ def make_inputs(body, B, T, conf, seed, unique=32):
     return out
 
 
-def cpu_baseline(sd, body, m, frames_batched=6, frames_single=48):
+def cpu_baseline(sd, body, m, frames_batched=16, frames_single=96):
     """The oracle (a port, parity-pinned to the reference) on this host's cores: batched B=256 and batch-1."""
     from oracle import sig_mp_oracle as O
     t = torch.from_numpy
