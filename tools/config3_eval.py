@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 on one GPU: an AIST++-shaped evaluation (N sequences x 9 cameras, real data absent -> synthetic
+dataset with the reference's test.pt layout) through the harness: camera inputs -> batched net -> smplify -> metrics.
+usage: python tools/config3_eval.py [n_seq] [frames]   (under torch.distributed.run the rows are sharded over the ranks)"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from robustcap_amd import dist as rdist  # noqa: E402
+from robustcap_amd import evaluate as ev  # noqa: E402
+from robustcap_amd import synth  # noqa: E402
+from robustcap_amd.body import ParametricModel  # noqa: E402
+
+
+def main():
+    n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+    rank, world, local = rdist.init_from_env()
+    torch.cuda.set_device(local if world > 1 else 0)
+    sd, body, gmm = synth.make_state_dict(0), synth.make_body(1), synth.make_gmm(3)
+    ds = synth.make_dataset(21, n_seq, T, body, n_cam=9, conf="mixed")
+    rows = len(ev.rows_of(ds))
+    out = {"sequences": n_seq, "cameras": 9, "frames": T, "rows": rows, "world": world}
+    for smp in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = {}
+        res = ev.run_dataset(ds, sd, body, run_smplify=smp, gmm=gmm if smp else None, smplify_info=info)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        key = "with_smplify" if smp else "net_only"
+        out[key] = {"seconds": round(dt, 3), "body_frames_per_s": round(rows * T / dt, 1)}
+        if smp and info:
+            out[key]["smplify_rows_optimised"] = int(sum(1 for v in info.values() if v["status"] == 1))
+            out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
+    if rank == 0:
+        model = ParametricModel(body=body)
+        model.set_regressor(synth.make_j_regressor(4), 14)
+        t0 = time.perf_counter()
+        errs = []
+        for (i, j), (pose, tran) in res.items():
+            pt, tt = ev.labels(ds, i, j)
+            errs.append(model.mesh_metrics(pose, pt)[1])              # cal_mpjpe's three means (evaluate.py:120-133)
+        torch.cuda.synchronize()
+        out["metrics"] = {"seconds": round(time.perf_counter() - t0, 3), "rows": len(errs),
+                          "mean_mpjpe_pve_pampjpe_m": [round(float(v), 4) for v in np.mean(errs, axis=0)],
+                          "note": "random-weight network: the values only show that the metric path runs end to end"}
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
