@@ -326,3 +326,31 @@ def test_live_session_over_the_wire_format(synth_assets):
         first = tr.clone() if first is None else first
         aa = rotation_matrix_to_axis_angle(p).cpu().view(-1)
         assert out == live.format_unity_packet(aa.tolist(), (tr - first).tolist()), i
+
+
+@pytest.mark.parametrize("vis,imu", [(False, True), (True, False), (False, False)])
+def test_updater_switches_vs_oracle(vis, imu, synth_assets):
+    """use_vision_updater / use_imu_updater off (net/sig_mp.py:33-34,178,264): no deferred rnn6/rnn4 steps, no init_net
+    write -- against the oracle with the same switches."""
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd import synth
+    B, T = 6, 36
+    m = synth.make_motion(131, B, T, synth_assets["body"], conf="mixed")
+    m["j2dc"][2, 8:20, :, 2] = 0.45
+    m["j2dc"][4, :6, :, 2] = 0.5
+    net, ora = make_net(synth_assets, B), make_oracle(synth_assets, B)
+    net.use_vision_updater = ora.use_vision_updater = vis
+    net.use_imu_updater = ora.use_imu_updater = imu
+    net.gravityc = t(m["gravityc"])
+    ora.gravityc = t(m["gravityc"])
+    pose, tran = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    for i in range(T):
+        p, tr = ora.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]), None, i == 0)
+        assert maxdiff(tran[:, i], tr) <= 1e-4, i
+        assert float(O.rotation_angle_deg(pose[:, i].cpu(), p).max()) <= 0.1, i
+    for n in ("rnn2", "rnn4", "rnn6"):
+        h, c = net.get_state(n)
+        assert maxdiff(h, ora.h[n]) <= 1e-4 and maxdiff(c, ora.c[n]) <= 2e-4, n
+    tr8 = net.get_trace()
+    if not imu:
+        assert int(tr8[:, 4].sum()) == 0                                   # init_net never fired
