@@ -184,6 +184,7 @@ SCENARIOS = {
     "live_pre": dict(T=96, conf="livepre", first_frame=True, live="pre"),
     "reproj_opt": dict(T=96, conf="mixed_hi0", first_tran=True, use_reproj_opt=True),
     "long_mixed": dict(T=512, conf="mixed", first_tran=True),       # the north-star sequence length
+    "no_updaters": dict(T=72, conf="lowstart", first_frame=True, use_vision_updater=False, use_imu_updater=False),
 }
 
 
@@ -235,6 +236,8 @@ def capture_sequences(art, sig_mp, body):
             net.live = True
         net.use_flat_floor = sc.get("use_flat_floor", True)
         net.use_reproj_opt = sc.get("use_reproj_opt", False)
+        net.use_vision_updater = sc.get("use_vision_updater", True)
+        net.use_imu_updater = sc.get("use_imu_updater", True)
         net.gravityc = torch.from_numpy(m["gravityc"][0].copy())
         ft = sc.get("first_tran")
         if ft is True:
@@ -283,6 +286,7 @@ def capture_sequences(art, sig_mp, body):
             first_tran=np.zeros(0, np.float32) if ft is None else ft.numpy(), first_frame=np.int32(ff),
             live=np.str_(live or ""), use_flat_floor=np.int32(sc.get("use_flat_floor", True)),
             use_reproj_opt=np.int32(sc.get("use_reproj_opt", False)),
+            use_vision_updater=np.int32(sc.get("use_vision_updater", True)), use_imu_updater=np.int32(sc.get("use_imu_updater", True)),
             pose=np.stack(poses), tran=np.stack(trans), trace=np.asarray(trace, np.float64),
             net_out=np.stack(outs), last_pfoot=net.last_pfoot.numpy(), **hid)
         tr = np.asarray(trace)

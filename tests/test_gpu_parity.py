@@ -160,6 +160,8 @@ def test_sequence_vs_reference_capture(path, synth_assets):
         net.live = True
     net.use_flat_floor = bool(s["use_flat_floor"])
     net.use_reproj_opt = bool(s["use_reproj_opt"]) if "use_reproj_opt" in s else False
+    net.use_vision_updater = bool(s["use_vision_updater"]) if "use_vision_updater" in s else True
+    net.use_imu_updater = bool(s["use_imu_updater"]) if "use_imu_updater" in s else True
     net.gravityc = t(s["gravityc"])
     ft = t(s["first_tran"]) if s["first_tran"].size else None
     T = s["pose"].shape[0]
