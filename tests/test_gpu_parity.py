@@ -356,3 +356,21 @@ def test_updater_switches_vs_oracle(vis, imu, synth_assets):
     tr8 = net.get_trace()
     if not imu:
         assert int(tr8[:, 4].sum()) == 0                                   # init_net never fired
+
+
+def test_rotmat_to_axis_angle_against_scipy():
+    """rc_rotmat_to_axis_angle against scipy's Rotation.as_rotvec (an independent implementation of the log map the
+    reference takes from OpenCV, which is absent here: parity with cv2 itself stays unpinned)."""
+    from scipy.spatial.transform import Rotation
+    from robustcap_amd import synth
+    from robustcap_amd.body import rotation_matrix_to_axis_angle
+    aa = synth.normal(9, 0, 3000).reshape(-1, 3).astype(np.float64)
+    aa[:100] *= 1e-4
+    ax = aa[100:200] / np.linalg.norm(aa[100:200], axis=1, keepdims=True)
+    aa[100:200] = ax * (np.pi - 0.01 - 0.04 * synth.uniform01(9, 1, 100)[:, None])
+    n = np.linalg.norm(aa, axis=1)
+    aa[n > np.pi] *= ((np.pi - 0.05) / n[n > np.pi])[:, None]
+    R = Rotation.from_rotvec(aa).as_matrix().astype(np.float32)
+    got = rotation_matrix_to_axis_angle(t(R)).cpu().numpy()
+    want = Rotation.from_matrix(R.astype(np.float64)).as_rotvec()
+    assert np.abs(got - want).max() <= 2e-4 and np.abs(got[200:] - want[200:]).max() <= 5e-6

@@ -147,3 +147,22 @@ def test_batch_rows_equal_single_runs(synth_assets):
             p, tr = singles[b].forward_online(t(m["j2dc"][b, i]), t(m["accc"][b, i]), t(m["oric"][b, i]), None, i == 0)
             assert maxdiff(P[b], p) <= 2e-5 and maxdiff(Tr[b], tr) <= 2e-5
             assert int(nb.trace["n4"][b]) == int(singles[b].trace["n4"][0])
+
+
+def test_rotmat_to_axis_angle_against_scipy():
+    """The reference calls OpenCV's cv2.Rodrigues here (absent: parity unpinned). An independent
+    implementation of the same log map -- scipy's Rotation.as_rotvec -- agrees with the restatement on random
+    rotations, including angles close to 0 and close to pi."""
+    from scipy.spatial.transform import Rotation
+    from robustcap_amd import synth
+    aa = synth.normal(9, 0, 3000).reshape(-1, 3).astype(np.float64)
+    aa[:100] *= 1e-4                                                        # tiny angles
+    ax = aa[100:200] / np.linalg.norm(aa[100:200], axis=1, keepdims=True)
+    aa[100:200] = ax * (np.pi - 0.01 - 0.04 * synth.uniform01(9, 1, 100)[:, None])   # 0.6 .. 2.9 degrees below pi
+    n = np.linalg.norm(aa, axis=1)
+    aa[n > np.pi] *= ((np.pi - 0.05) / n[n > np.pi])[:, None]                # keep the principal branch
+    R = Rotation.from_rotvec(aa).as_matrix().astype(np.float32)
+    got = O.rotation_matrix_to_axis_angle(t(R)).numpy()
+    want = Rotation.from_matrix(R.astype(np.float64)).as_rotvec()
+    assert np.abs(got - want).max() <= 2e-4                                  # float32 matrices: the log map is ill-conditioned near pi
+    assert np.abs(got[200:] - want[200:]).max() <= 5e-6
