@@ -35,7 +35,9 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #define TRACE_T(i) do { } while (0)
 #endif
 
+#ifndef LDS_PAD
 #define LDS_PAD 16            // floats added to a partial-sum row: epilogue rows land on different banks
+#endif
 
 #ifndef RC_ABLATE
 #define RC_ABLATE 0           // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
