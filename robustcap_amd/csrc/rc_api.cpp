@@ -20,6 +20,10 @@
 #include <string>
 #include <vector>
 
+#ifndef RC_NC1280
+#define RC_NC1280 10      // 16-column blocks per rnn4 LSTM tile (probe builds: 8 lets two workgroups share a CU's LDS)
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -203,7 +207,7 @@ struct Stage {                 // which rows of which net, reading which (rc_pk)
 // LSTM tile shape (16*mr rows x 4*nc units) for a stage expected to touch `rows` rows: wide tiles when the row tiles
 // alone fill the chip, narrow ones (more column tiles, each streaming a slice of the weights) when few rows are active.
 void pick_tile(int H, int rows, int* mr, int* nc) {
-    if (rows >= 128) { *mr = 2; *nc = H == 1280 ? 10 : (H == 1024 ? 8 : 4); return; }
+    if (rows >= 128) { *mr = 2; *nc = H == 1280 ? RC_NC1280 : (H == 1024 ? 8 : 4); return; }
     if (rows > 16) { *mr = 2; *nc = rows >= 64 ? 4 : 2; if (*nc == 2) { *mr = 1; } return; }
     *mr = 1; *nc = 1;
 }
