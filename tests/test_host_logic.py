@@ -70,3 +70,33 @@ def test_dataset_layout_matches_reference_test_pt():
     assert np.allclose(ds["cam_T"][0][0], np.eye(4))                               # camera 0 frame == world frame
     R = synth._rodrigues(ds["pose"][0].reshape(-1, 3).astype(np.float64))
     assert np.allclose(synth._log_map(R), ds["pose"][0].reshape(-1, 3), atol=1e-5)
+
+
+def test_prior_arrays_match_the_oracle_prior():
+    """smplify.prior_arrays (host preparation of the GMM buffers, net/smplify/prior.py:124-147) == the oracle's Prior."""
+    import numpy as np
+    from oracle import smplify_oracle as S
+    from robustcap_amd import synth
+    from robustcap_amd.smplify import prior_arrays
+    gmm = synth.make_gmm(3)
+    means, prec, nllw = prior_arrays(gmm)
+    ref = S.Prior(gmm)
+    assert means.dtype == prec.dtype == nllw.dtype == np.float32
+    assert np.array_equal(means, ref.means.numpy()) and np.array_equal(prec, ref.precisions.numpy())
+    assert np.array_equal(nllw, ref.nll_weights.numpy().reshape(-1)) and (nllw > 0).all()
+    bad = dict(gmm, means=np.asarray(gmm["means"])[:7])
+    import pytest
+    with pytest.raises(Exception):
+        prior_arrays(bad)
+
+
+def test_smplify_info_struct_matches_the_header():
+    import ctypes as C
+    import re
+    from robustcap_amd import _lib
+    header = open(_lib.HEADER_PATH).read()
+    body = re.search(r"typedef struct rc_smplify_info \{(.*?)\} rc_smplify_info;", header, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in body.split(";") if decl.strip() for n in decl.strip().split(None, 1)[1].split(",")]
+    assert names == [f for f, _ in _lib.RcSmplifyInfo._fields_]
+    assert C.sizeof(_lib.RcSmplifyInfo) == 4 * 4 + 4 * 8
