@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the sig_mp per-frame path on MI355X: body-frames/s at batch 256 (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--conf mixed|high|occ]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A step = one frame of the hot path (prep -> 6 LSTM sub-nets -> fusion/FK tail -> vision updater) for one batch
-of 256 bodies per GPU, inputs resident in HBM. Workload = BASELINE.json configs[1]: synthetic 60 fps sequences,
-6 IMUs + 33 keypoints, batch 256 x 512 frames, mixed-confidence schedule (50 % high /
-20 % mid / 30 % occluded, which forces the frame-stepped path incl. the vision updater). Weak scaling: every rank
-runs its own 256 bodies; for N > 1 the outputs are gathered to rank 0 (RCCL) inside the timed region, in four
-asynchronous chunks that overlap the remaining frames.
+of bodies, inputs resident in HBM. Workload = BASELINE.json configs[1]: synthetic 60 fps sequences, 6 IMUs + 33
+keypoints, batch 256 x 512 frames, mixed-confidence schedule (50 % high / 20 % mid /
+30 % occluded, which forces the frame-stepped path incl. the vision updater); the all-visible variant (config 2a,
+which the sequence-mode engine accelerates) is timed too and reported under "variants".
 
-Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline).
+Scaling: ``weak`` (default) = 256 bodies on EVERY rank; ``strong`` = 256 bodies in total, split over the ranks with
+dist.shard_range. For N > 1 the outputs are gathered to rank 0 (RCCL) inside the timed region, in four asynchronous
+chunks that overlap the remaining frames.
+
+Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline). The roofline pass and the CPU leg are
+guarded: a failure there is recorded as {"error": ...} and the line is still printed.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,17 +36,25 @@ from robustcap_amd import dist as rdist  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA (16x16x4 / 32x32x2), dense
+CPU_FRAMES_BATCHED = 16                # cpu_baseline sample: B x 16 frames batched + 96 frames batch-1 (~10-30 s)
+CPU_FRAMES_SINGLE = 96
 
 
-def pmc_traffic():
-    """Fabric-side bytes per gate-GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-    correction + WRITE_SIZE, x1024), or None. PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic(batch, conf):
+    """Fabric-side bytes per gate-GEMM launch from a committed rocprofv3 PMC pass of THIS workload (batch and
+    confidence schedule must match the keys stored with the measurement), else None: PMC counters cannot be read
+    from inside this process, and a figure measured on another batch is not evidence for this run."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.endswith(".json") and "pmc_traffic" in name):
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if int(d.get("batch", -1)) == batch and d.get("conf") == conf:
+                return float(d["traffic_bytes_per_launch"]), name
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
 
 
 def make_inputs(body, B, T, conf, seed, unique=32):
@@ -59,11 +72,15 @@ def make_inputs(body, B, T, conf, seed, unique=32):
     return out
 
 
-def cpu_baseline(sd, body, m, frames_batched=16, frames_single=96):
-    """The oracle (a port, parity-pinned to the reference) on this host's cores: batched B=256 and batch-1."""
+def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=CPU_FRAMES_SINGLE):
+    """The oracle (a port, parity-pinned to the reference) on this host's cores: batched and batch-1.
+    ``m`` only has to hold ONE frame more than it is asked to time; shorter inputs shorten the sample."""
     from oracle import sig_mp_oracle as O
     t = torch.from_numpy
-    B = m["j2dc"].shape[0]
+    B, T = m["j2dc"].shape[:2]
+    if T < 2:
+        raise ValueError("cpu_baseline needs at least 2 frames of input")
+    frames_batched, frames_single = min(frames_batched, T - 1), min(frames_single, T - 1)
     threads = torch.get_num_threads()
     net = O.OracleNet(body, batch=B)
     net.load_numpy_state_dict(sd)
@@ -86,111 +103,172 @@ def cpu_baseline(sd, body, m, frames_batched=16, frames_single=96):
                       f"({frames_single} frames = {dt_1:.1f}s); nproc={os.cpu_count()}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--conf", default="mixed", choices=["mixed", "high", "occ"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def guarded(fn, *a, **k):
+    """fn(*a, **k), or {"error": ...} -- the bench line must be printed whatever the side legs do."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:  # noqa: BLE001 - deliberately broad: report, do not die
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(e).__name__}: {e}"}
 
-    rank, world, local = rdist.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    torch.cuda.set_device(local if world > 1 else 0)
-    from robustcap_amd.net.sig_mp import Net
 
-    B, K, W = args.batch, args.steps, args.warmup
-    T = W + K
-    sd, body = synth.make_state_dict(0), synth.make_body(1)
-    m = make_inputs(body, B, T, args.conf, seed=2 + rank)
-    dev = torch.device("cuda")
-    j2d, acc, ori = (torch.from_numpy(m[k]).to(dev) for k in ("j2dc", "accc", "oric"))
-    ft = torch.from_numpy(m["first_tran"]).to(dev)
-    net = Net(body=body, batch=B)
-    net.load_state_dict(sd)
-    net.gravityc = torch.from_numpy(m["gravityc"])
+class Workload:
+    """One confidence schedule: inputs resident on the device, a context of this rank's rows, timed/instrumented runs."""
 
-    def run(lo, hi, first):
-        return net.forward_sequence(j2d[:, lo:hi], acc[:, lo:hi], ori[:, lo:hi], first_tran=ft if first else None)
+    def __init__(self, sd, body, conf, B, W, K, rank, world, seed_base=2):
+        from robustcap_amd.net.sig_mp import Net
+        self.conf, self.B, self.W, self.K, self.rank, self.world = conf, B, W, K, rank, world
+        self.m = make_inputs(body, B, W + K, conf, seed=seed_base + rank)
+        dev = torch.device("cuda")
+        self.dev = dev
+        self.j2d, self.acc, self.ori = (torch.from_numpy(self.m[k]).to(dev) for k in ("j2dc", "accc", "oric"))
+        self.ft = torch.from_numpy(self.m["first_tran"]).to(dev)
+        self.net = Net(body=body, batch=B)
+        self.net.load_state_dict(sd)
+        self.net.gravityc = torch.from_numpy(self.m["gravityc"])
 
-    def sync():
-        if world > 1:
+    def run(self, lo, hi, first):
+        return self.net.forward_sequence(self.j2d[:, lo:hi], self.acc[:, lo:hi], self.ori[:, lo:hi],
+                                         first_tran=self.ft if first else None)
+
+    def sync(self):
+        if self.world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup (the first W frames of the sequences), then exactly K timed steps -------------------------
-    run(0, W, True)
-    sync()
-    t0 = time.perf_counter()
-    if world > 1:
-        # The path's only exchange: the outputs go to rank 0 (RCCL over xGMI). The K steps are enqueued in 4 chunks and
-        # each chunk's gather starts as soon as its kernels are queued, so all but the last transfer hide behind compute.
-        edges = [W + (K * c) // 4 for c in range(5)]
-        gathers = []
-        for lo, hi in zip(edges[:-1], edges[1:]):
-            if hi > lo:
-                p, tr = run(lo, hi, False)
-                gathers.append((rdist.RowGather(p.reshape(B, -1)), rdist.RowGather(tr.reshape(B, -1)), hi - lo))
-        parts = [(gp.result(), gt.result(), n) for gp, gt, n in gathers]
-        if rank == 0:
-            pose = torch.cat([p.view(world * B, n, 24, 3, 3) for p, _, n in parts], dim=1)
-            tran = torch.cat([q.view(world * B, n, 3) for _, q, n in parts], dim=1)
+    def timed(self, gather_rows_total=None):
+        """W untimed warmup frames, then exactly K timed frames between barrier + synchronize; max over ranks."""
+        B, W, K, world, rank = self.B, self.W, self.K, self.world, self.rank
+        self.net.reset_states()
+        if W > 0:
+            self.run(0, W, True)
+        self.sync()
+        t0 = time.perf_counter()
+        if world > 1:
+            # The path's only exchange: the outputs go to rank 0 (RCCL over xGMI). The K steps are enqueued in 4 chunks
+            # and each chunk's gather starts as soon as its kernels are queued, so all but the last transfer hide
+            # behind compute. Row blocks may differ by one row under strong scaling: gather_rows pads.
+            edges = [W + (K * c) // 4 for c in range(5)]
+            parts = []
+            for ci, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+                if hi > lo:
+                    p, tr = self.run(lo, hi, W == 0 and ci == 0)
+                    if gather_rows_total is None:
+                        parts.append((rdist.RowGather(p.reshape(B, -1)), rdist.RowGather(tr.reshape(B, -1))))
+                    else:
+                        parts.append((p, tr))
+            if gather_rows_total is None:
+                outs = [(gp.result(), gt.result()) for gp, gt in parts]
+            else:
+                outs = [(rdist.gather_rows(p.reshape(B, -1), gather_rows_total, dst=0),
+                         rdist.gather_rows(tr.reshape(B, -1), gather_rows_total, dst=0)) for p, tr in parts]
+            pose, tran = (outs[-1] if rank == 0 else (p, tr))
         else:
-            pose, tran = p, tr
-    else:
-        pose, tran = run(W, T, False)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert torch.isfinite(pose).all() and torch.isfinite(tran).all()
+            pose, tran = self.run(W, W + K, W == 0)
+        self.sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=self.dev if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        assert torch.isfinite(pose).all() and torch.isfinite(tran).all()
+        return dt
 
-    # ---- dominant kernel: HIP-event timing of every rc_gemm_kernel launch over the same K steps -----------
-    # rc_gemm_kernel (wide MFMA tiles) runs linear1 and both LSTM layers of all six sub-nets: 99.7 % of the algorithmic
-    # FLOPs in 6 launches per frame. The 16-row launches (the three transition launches, the two linear2 launches) run
-    # on rc_gemm_small_kernel, a weight-streaming kernel, and are not part of this roofline; `path_frac` is the whole
-    # frame (every kernel, the timed region's own clock) against the same peak.
-    roof = None
-    if rank == 0:
+    def roofline(self, dt, bodies_total):
+        """Dominant kernel: HIP-event timing (on the launch stream, inside the library) of every wide-tile gate-GEMM
+        launch over the same K steps. rc_gemm_kernel runs linear1 and both LSTM layers of all six sub-nets: 99.7 % of
+        the algorithmic FLOPs. The 16-row launches (transition steps, linear2) run on rc_gemm_small_kernel, a
+        weight-streaming kernel outside this roofline; `path_frac` is the whole frame (every kernel, the timed
+        region's own clock) against the same peak."""
+        B, W, K, net = self.B, self.W, self.K, self.net
         net.reset_states()
-        run(0, W, True)
+        if W > 0:
+            self.run(0, W, True)
         torch.cuda.synchronize()
         net.gemm_timing(2)
-        run(W, T, False)
+        self.run(W, W + K, W == 0)
         torch.cuda.synchronize()
         ms, launches = net.gemm_timing_read()
         net.gemm_timing(0)
+        if launches <= 0 or ms <= 0:
+            raise RuntimeError("no gate-GEMM launch was timed")
         flop_per_launch = B * (C.FLOPS_PER_BODY_FRAME - C.FLOPS_LINEAR2_PER_BODY_FRAME) * K / launches
         avg_s = ms * 1e-3 / launches
         ach = flop_per_launch / avg_s / 1e12
-        path = world * B * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / world
-        roof = {"bound": "mfma", "kernel": "rc_gemm_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
-                "traffic_note": "fabric-side L2 miss bytes per gate-GEMM launch (both kernels), rocprofv3 PMC "
-                                "(profiles/r01_pmc_traffic.json); unique weight bytes per launch = 22.1e6",
+        path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
+        traffic, src = pmc_traffic(B, self.conf)
+        return {"bound": "mfma", "kernel": "rc_gemm_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": (f"fabric-side L2 miss bytes per gate-GEMM launch, rocprofv3 PMC pass of this batch/schedule "
+                                 f"(profiles/{src})" if src else
+                                 "no PMC pass committed for this batch/schedule (profiles/*pmc_traffic*.json are keyed by batch + conf)"),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches, "launches_per_step": round(launches / K, 2),
                 "flop_per_launch": flop_per_launch,
                 "path_achieved": round(path, 2), "path_frac": round(path / PEAK_FP32_MFMA_TFLOPS, 4),
                 "note": "frac: rc_gemm_kernel alone (its algorithmic FLOPs / its HIP-event time); path_frac: whole frame incl. "
                         "the weight-streaming 16-row launches and the per-frame logic kernels"}
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=256, help="bodies per GPU (weak) or in total (strong)")
+    ap.add_argument("--conf", default="mixed", choices=["mixed", "high", "occ"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the all-visible (config 2a) variant")
+    args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.batch < 1:
+        ap.error("--steps >= 1, --warmup >= 0, --batch >= 1")
+
+    rank, world, local = rdist.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local if world > 1 else 0)
+
+    K, W = args.steps, args.warmup
+    if args.scaling == "strong":
+        a, b = rdist.shard_range(args.batch, rank, world)
+        B, bodies_total = b - a, args.batch
+        if B < 1:
+            raise SystemExit(f"strong scaling: {args.batch} bodies cannot be split over {world} ranks")
+    else:
+        B, bodies_total = args.batch, args.batch * world
+    sd, body = synth.make_state_dict(0), synth.make_body(1)
+    # equal row blocks use the asynchronous RowGather; uneven strong splits (batch % world != 0) the padded gather
+    strong_total = bodies_total if (args.scaling == "strong" and world > 1 and args.batch % world) else None
+
+    main_w = Workload(sd, body, args.conf, B, W, K, rank, world)
+    dt = main_w.timed(strong_total)
+    roof = guarded(main_w.roofline, dt, bodies_total) if rank == 0 else None
+
+    variants = None
+    if not args.no_variants and args.conf != "high":
+        del main_w.j2d, main_w.acc, main_w.ori
+        hi_w = Workload(sd, body, "high", B, W, K, rank, world)
+        dt_hi = guarded(hi_w.timed, strong_total)
+        if rank == 0:
+            variants = {"high": dt_hi if isinstance(dt_hi, dict) else {
+                "value": round(bodies_total * K / dt_hi, 1), "ms_per_step": round(dt_hi / K * 1e3, 4),
+                "workload": "SURVEY.md 8(d) config 2a: every frame visible (c >= 0.8), same batch and frame count"}}
+
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd, body, m)
-        value = world * B * K / dt
+            m_cpu = make_inputs(body, B, 1 + max(CPU_FRAMES_BATCHED, CPU_FRAMES_SINGLE), args.conf, seed=2)
+            cpu = guarded(cpu_baseline, sd, body, m_cpu)
+        value = bodies_total * K / dt
         print(json.dumps({
             "metric": "body-frames/sec (sig_mp fwd + FK) at batch 256", "value": round(value, 1), "unit": "body-frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic 60 fps, 6 IMU + 33 keypoints, batch {B} x {K} frames per GPU, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic 60 fps, 6 IMU + 33 keypoints, batch {B} x {K} frames per GPU "
+                                   f"({bodies_total} bodies in total, {args.scaling} scaling), "
                                    f"confidence schedule '{args.conf}', seeded random weights (63.4 M params)",
-                       "batch_per_gpu": B, "frames": K, "conf": args.conf, "parallelism": f"dp{world} (sequence sharding)"},
-            "roofline": roof, "cpu_baseline": cpu}))
+                       "batch_per_gpu": B, "bodies_total": bodies_total, "frames": K, "conf": args.conf,
+                       "parallelism": f"dp{world} (sequence sharding)"},
+            "roofline": roof, "cpu_baseline": cpu, "variants": variants}), flush=True)
     if world > 1:
         torch.distributed.barrier()          # rank 0 may still be in its instrumented pass
         torch.distributed.destroy_process_group()

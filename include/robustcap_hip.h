@@ -122,8 +122,30 @@ int rc_r6d_to_rotmat(const float* r6d, float* R, int64_t n, void* stream);
 /* art.math.axis_angle_to_rotation_matrix (articulate/math/angular.py:221-233): aa[n,3] -> R[n,3,3]. */
 int rc_axis_angle_to_rotmat(const float* aa, float* R, int64_t n, void* stream);
 /* art.math.rotation_matrix_to_axis_angle (articulate/math/angular.py:236-246; the reference loops cv2.Rodrigues on
- * the host): R[n,3,3] -> aa[n,3], angle in [0, pi]. Computed in float64 (atan2 form). */
+ * the host): R[n,3,3] -> aa[n,3], angle in [0, pi]. Restates the matrix -> vector branch of OpenCV 4.2's cvRodrigues2 in
+ * float64: range check, nearest orthonormal matrix, acos, the s < 1e-5 branches (zero near the identity, sqrt of the
+ * diagonal near pi). */
 int rc_rotmat_to_axis_angle(const float* R, float* aa, int64_t n, void* stream);
+/* art.math.rotation_matrix_to_r6d (articulate/math/angular.py:267-274): R[n,3,3] -> r6d[n,6] = first two columns. */
+int rc_rotmat_to_r6d(const float* R, float* r6d, int64_t n, void* stream);
+/* art.math.angle_between(rot1, rot2) for rotation matrices (angular.py:128-141): |Rodrigues(R1^T R2)| -> out[n]. */
+int rc_angle_between(const float* R1, const float* R2, float* out, int64_t n, void* stream);
+/* art.math.lerp(a, b, t) with a Python-double weight (articulate/math/general.py:15-24): out[n] = a * float(1 - t) +
+ * b * float(t), the weights formed in double on the host exactly like `tensor * python_float`. */
+int rc_lerp(const float* a, const float* b, double t, float* out, int64_t n, void* stream);
+/* art.math.normalize_tensor(x, dim=-1, return_norm) (general.py:27-39): x[rows,width] -> out = x / |x|, norm[rows]|NULL. */
+int rc_normalize_rows(const float* x, float* out, float* norm, int64_t rows, int32_t width, void* stream);
+/* Keypoint normalisation of forward_online (net/sig_mp.py:150-152 with get_bbox_scale L277-284): kp[n,33,3] -> out[n,33,3]
+ * (xy / max(bbox width, height), rows != 23 relative to row 23, confidence copied). */
+int rc_bbox_normalise(const float* kp, float* out, int64_t n, void* stream);
+/* ParametricModel.forward_kinematics_R (articulate/math/spatial.py:170-194): Rl[n,24,3,3] local -> Rg[n,24,3,3] global. */
+int rc_fk_r(rc_ctx* ctx, const float* Rlocal, float* Rglobal, int64_t n, void* stream);
+/* ParametricModel.bone_vector_to_joint_position / joint_position_to_bone_vector (spatial.py:126-167): [n,24,3] both. */
+int rc_bone_to_joint(rc_ctx* ctx, const float* bone, float* joint, int64_t n, void* stream);
+int rc_joint_to_bone(rc_ctx* ctx, const float* joint, float* bone, int64_t n, void* stream);
+/* ParametricModel.get_zero_pose_joint_and_vertex(shape=None) (articulate/model.py:78-93): joint[24,3] = J - J[0] and,
+ * when vert is not NULL (needs rc_set_mesh), vert[V,3] = v_template - J[0]. */
+int rc_zero_pose(rc_ctx* ctx, float* joint, float* vert, void* stream);
 /* ParametricModel.inverse_kinematics_R (articulate/math/spatial.py:197-221): Rg[n,24,3,3] -> Rl[n,24,3,3]. */
 int rc_ik_r(rc_ctx* ctx, const float* Rglobal, float* Rlocal, int64_t n, void* stream);
 /* fk() of forward_online (net/sig_mp.py:131-135): joints[n,24,3] from GLOBAL rotations + rest bone vectors. */

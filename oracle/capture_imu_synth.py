@@ -18,6 +18,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 from robustcap_amd import synth  # noqa: E402
 import capture_reference as cr  # noqa: E402
+from oracle import _npz  # noqa: E402
 
 
 def main():
@@ -46,7 +47,8 @@ def main():
     gp, joint3d, vert = pre.body_model.forward_kinematics(p, tran=tran, calc_mesh=True)
     g.update(pose_aa=aa.numpy(), tran=tran.numpy(), imu_ori=gp[:, pre.ji_mask].numpy(), imu_acc=pre._syn_acc(vert[:, pre.vi_mask]).numpy(),
              joint3d=joint3d.numpy(), vert6=vert[:, pre.vi_mask].numpy())
-    np.savez_compressed(os.path.join(cr.OUT, "imu_synth.npz"), **g)
+    _npz.save(os.path.join(cr.OUT, "imu_synth.npz"), **g)
+    cr.write_hashes()
     print({k: v.shape for k, v in g.items()})
 
 

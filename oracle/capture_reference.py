@@ -11,7 +11,9 @@ What is stored: numbers only -- seeded inputs, the reference's outputs, a per-fr
 per-frame outputs of each sub-net's ``linear2`` (forward hooks). Weights / body are NOT stored: fixtures hold
 the generator seed + checksums (robustcap_amd.synth regenerates them bit-identically).
 
-Usage:  python oracle/capture_reference.py            (writes tests/golden/)
+Usage:  python oracle/capture_reference.py            (writes tests/golden/: ops.npz, seq_*.npz, meta.json with sha256)
+        python oracle/capture_reference.py NAME...    (only these scenarios)
+        python oracle/capture_reference.py --check    (re-runs the reference on the STORED inputs: outputs must be bit-equal)
 """
 import os
 import pickle
@@ -27,6 +29,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from robustcap_amd import config as C  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
+from oracle import _npz  # noqa: E402
 
 REF = "/root/reference"
 OUT = os.path.join(REPO, "tests", "golden")
@@ -139,6 +142,12 @@ def capture_ops(art, sig_mp, body):
     ks = np.array([0.0, 0.123456789, 0.5, 0.987654321, 1.0])
     g["lerp_a"], g["lerp_b"], g["lerp_k"] = a, b, ks
     g["lerp_out"] = np.stack([art.math.lerp(t(a), t(b), float(k)).numpy() for k in ks])
+    # rotation matrix -> 6D (angular.py:267-274) and normalize_tensor with norms (general.py:27-39)
+    g["rot2r6d_out"] = art.math.rotation_matrix_to_r6d(t(Rg.copy())).numpy()
+    nx = synth.normal(19, 0, N * 7).reshape(N, 7).astype(np.float32)
+    nx[3] = 0                                                 # zero row -> NaN, like the reference
+    nn, nl = art.math.normalize_tensor(t(nx.copy()), return_norm=True)
+    g["norm_in"], g["norm_out"], g["norm_len"] = nx, nn.numpy(), nl.numpy()
     # axis-angle -> R (angular.py:221-233), pure torch
     aa = (6 * synth.uniform01(17, 0, N * 3) - 3).reshape(N, 3).astype(np.float32)
     aa[0] = 0
@@ -167,7 +176,7 @@ def capture_ops(art, sig_mp, body):
     g["res_pose"], g["res_tran"], g["res_kp"], g["res_K"] = rp, rt, kp2.numpy().copy(), K.numpy()
     g["res_loss"] = fit.get_fitting_loss(t(rp.copy()), t(rt.copy()), kp2.clone()).numpy()
     g["res_gate_frame0_mean"] = np.float32(g["res_loss"].mean(-1)[0])
-    np.savez_compressed(os.path.join(OUT, "ops.npz"), **g)
+    _npz.save(os.path.join(OUT, "ops.npz"), **g)
     print("ops.npz:", {k: v.shape for k, v in g.items() if hasattr(v, "shape")})
 
 
@@ -185,6 +194,10 @@ SCENARIOS = {
     "reproj_opt": dict(T=96, conf="mixed_hi0", first_tran=True, use_reproj_opt=True),
     "long_mixed": dict(T=512, conf="mixed", first_tran=True),       # the north-star sequence length
     "no_updaters": dict(T=72, conf="lowstart", first_frame=True, use_vision_updater=False, use_imu_updater=False),
+    # every frame visible at the north-star length: the regime the sequence-mode engine (hoisted input projections,
+    # skewed stage pipeline) accelerates; mid stretches inside exercise the lerp there
+    "allvis_long": dict(T=512, conf="allvis", first_tran=True),
+    "allvis_ff": dict(T=160, conf="allvis", first_frame=True),
 }
 
 
@@ -204,14 +217,105 @@ def _conf(kind, T, seed):
         c[35:80] = 0.84 + 0.12 * u[35:80]
     elif kind == "midheavy":
         c[:] = np.where(u < 0.6, 0.715 + 0.07 * u / 0.6, c)
+    elif kind == "allvis":           # c > 0.7 everywhere: high with mid stretches
+        c = synth.conf_schedule(seed, 7, T, "high")
+        seg = (np.arange(T) // 37) % 4
+        c = np.where(seg == 2, 0.715 + 0.07 * u, c)
+        c[0] = 0.9
     elif kind == "livepre":          # thresholds (0.85, 0.9)
         seg = (np.arange(T) // 16) % 3
         c = np.where(seg == 0, 0.915 + 0.07 * u, np.where(seg == 1, 0.862 + 0.026 * u, 0.5 + 0.3 * u))
     return c
 
 
-def capture_sequences(art, sig_mp, body):
+def run_reference(sig_mp, sd, inputs, sc):
+    """One scenario through the REFERENCE's ``Net.forward_online`` frame loop on the given inputs (j2dc [T,33,3],
+    accc [T,6,3], oric [T,6,3,3], gravityc [3], first_tran [3] or empty). Returns the dict of everything a fixture stores
+    besides its inputs: pose, tran, trace, net_out (last linear2 output of every sub-net per frame), final (h, c)."""
     Net = sig_mp.Net
+    T = inputs["j2dc"].shape[0]
+    live = sc.get("live")
+    Net.live = (live == "pre")
+    Net.update_vision_count = 0
+    Net.j_temp = None
+    net = Net()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    if live == "post":
+        net.live = True
+    net.use_flat_floor = bool(sc.get("use_flat_floor", True))
+    net.use_reproj_opt = bool(sc.get("use_reproj_opt", False))
+    net.use_vision_updater = bool(sc.get("use_vision_updater", True))
+    net.use_imu_updater = bool(sc.get("use_imu_updater", True))
+    net.gravityc = torch.from_numpy(np.asarray(inputs["gravityc"], np.float32).copy())
+    ft = inputs.get("first_tran")
+    ft = None if ft is None or np.size(ft) == 0 else torch.tensor(np.asarray(ft, np.float32))
+    ff = bool(sc.get("first_frame", False))
+    calls = []                                               # hooks: every linear2 call, in order
+    hooks = [getattr(net, n).linear2.register_forward_hook(
+        lambda mod, inp, out, n=n: calls.append((n, out.detach().numpy().reshape(-1).copy())))
+        for n, *_ in C.NETS]
+    poses, trans, trace, outs = [], [], [], []
+    for t in range(T):
+        calls.clear()
+        j2 = torch.from_numpy(inputs["j2dc"][t].copy())
+        ac = torch.from_numpy(inputs["accc"][t].copy())
+        ori = torch.from_numpy(inputs["oric"][t].copy())
+        n_floor0 = len(net.floor_y)
+        reach0 = net.first_reach
+        if t == 0:
+            p, tr = net.forward_online(j2, ac, ori, first_tran=ft, first_frame=ff)
+        else:
+            p, tr = net.forward_online(j2, ac, ori)
+        poses.append(p.numpy().copy())
+        trans.append(tr.numpy().copy())
+        order = [n for n, _ in calls]
+        rec = np.zeros(6 * 144 + 16, np.float32)             # last output of each net this frame (padded)
+        for n, o in calls:
+            k = C.NET_INDEX[n]
+            rec[k * 144:k * 144 + o.size] = o
+        outs.append(rec)
+        trace.append([float(inputs["j2dc"][t, :, 2].mean()), order.count("rnn4"), order.count("rnn6"),
+                      len(net.floor_y) - n_floor0, len(net.floor_y), int(reach0 and not net.first_reach),
+                      int(net.update_vision_count) if live else 0])
+    for h in hooks:
+        h.remove()
+    res = dict(pose=np.stack(poses), tran=np.stack(trans), trace=np.asarray(trace, np.float64), net_out=np.stack(outs),
+               last_pfoot=net.last_pfoot.numpy())
+    for n, *_ in C.NETS:
+        slot = int(n[3:]) - 1
+        hc = net.hidden[slot]
+        res["h_" + n] = hc[0].numpy()[:, 0].copy()
+        res["c_" + n] = hc[1].numpy()[:, 0].copy()
+    Net.live = False
+    return res
+
+
+def _scenario_of(z):
+    """flags stored in a fixture -> the scenario dict run_reference takes"""
+    return dict(live=str(z["live"]) or None, first_frame=bool(int(z["first_frame"])), use_flat_floor=bool(int(z["use_flat_floor"])),
+                use_reproj_opt=bool(int(z["use_reproj_opt"])), use_vision_updater=bool(int(z["use_vision_updater"])),
+                use_imu_updater=bool(int(z["use_imu_updater"])))
+
+
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def write_hashes():
+    """sha256 of every tests/golden/*.npz into meta.json (tests/test_oracle_golden.py verifies them on every run)."""
+    import json
+    path = os.path.join(OUT, "meta.json")
+    with open(path) as f:
+        meta = json.load(f)
+    meta["sha256"] = {n: _sha256(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT)) if n.endswith(".npz")}
+    with open(path, "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def capture_sequences(art, sig_mp, body):
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(WEIGHT_SEED).items()}
     meta = {"weight_seed": WEIGHT_SEED, "body_seed": BODY_SEED,
             "weight_checksum": {k: synth.checksum(v.numpy()) for k, v in list(sd.items())[::7]},
@@ -225,80 +329,54 @@ def capture_sequences(art, sig_mp, body):
         mseed = 100 + si
         conf = _conf(sc["conf"], T, mseed * 7919)
         m = synth.make_motion(mseed, 1, T, body, conf=conf)
-        live = sc.get("live")
-        Net.live = (live == "pre")
-        Net.update_vision_count = 0
-        Net.j_temp = None
-        net = Net()
-        net.load_state_dict(sd, strict=True)
-        net.eval()
-        if live == "post":
-            net.live = True
-        net.use_flat_floor = sc.get("use_flat_floor", True)
-        net.use_reproj_opt = sc.get("use_reproj_opt", False)
-        net.use_vision_updater = sc.get("use_vision_updater", True)
-        net.use_imu_updater = sc.get("use_imu_updater", True)
-        net.gravityc = torch.from_numpy(m["gravityc"][0].copy())
         ft = sc.get("first_tran")
         if ft is True:
             ft = m["first_tran"][0]
-        ft = None if ft is None else torch.tensor(np.asarray(ft, np.float32))
-        ff = bool(sc.get("first_frame", False))
-        # hooks: every linear2 call, in order
-        calls = []
-        hooks = [getattr(net, n).linear2.register_forward_hook(
-            lambda mod, inp, out, n=n: calls.append((n, out.detach().numpy().reshape(-1).copy())))
-            for n, *_ in C.NETS]
-        poses, trans, trace, outs = [], [], [], []
-        for t in range(T):
-            calls.clear()
-            j2 = torch.from_numpy(m["j2dc"][0, t].copy())
-            ac = torch.from_numpy(m["accc"][0, t].copy())
-            ori = torch.from_numpy(m["oric"][0, t].copy())
-            n_floor0 = len(net.floor_y)
-            reach0 = net.first_reach
-            if t == 0:
-                p, tr = net.forward_online(j2, ac, ori, first_tran=ft, first_frame=ff)
-            else:
-                p, tr = net.forward_online(j2, ac, ori)
-            poses.append(p.numpy().copy())
-            trans.append(tr.numpy().copy())
-            order = [n for n, _ in calls]
-            rec = np.zeros(6 * 144 + 16, np.float32)      # last output of each net this frame (padded)
-            for n, o in calls:
-                k = C.NET_INDEX[n]
-                rec[k * 144:k * 144 + o.size] = o
-            outs.append(rec)
-            trace.append([float(m["j2dc"][0, t, :, 2].mean()), order.count("rnn4"), order.count("rnn6"),
-                          len(net.floor_y) - n_floor0, len(net.floor_y), int(reach0 and not net.first_reach),
-                          int(net.update_vision_count) if live else 0])
-        for h in hooks:
-            h.remove()
-        hid = {}
-        for n, *_ in C.NETS:
-            slot = int(n[3:]) - 1
-            hc = net.hidden[slot]
-            hid["h_" + n] = hc[0].numpy()[:, 0].copy()
-            hid["c_" + n] = hc[1].numpy()[:, 0].copy()
-        np.savez_compressed(
-            os.path.join(OUT, f"seq_{name}.npz"),
-            j2dc=m["j2dc"][0], accc=m["accc"][0], oric=m["oric"][0], gravityc=m["gravityc"][0],
-            first_tran=np.zeros(0, np.float32) if ft is None else ft.numpy(), first_frame=np.int32(ff),
-            live=np.str_(live or ""), use_flat_floor=np.int32(sc.get("use_flat_floor", True)),
+        ft = np.zeros(0, np.float32) if ft is None else np.asarray(ft, np.float32)
+        inputs = dict(j2dc=m["j2dc"][0], accc=m["accc"][0], oric=m["oric"][0], gravityc=m["gravityc"][0], first_tran=ft)
+        res = run_reference(sig_mp, sd, inputs, sc)
+        _npz.save(
+            os.path.join(OUT, f"seq_{name}.npz"), **inputs, first_frame=np.int32(bool(sc.get("first_frame", False))),
+            live=np.str_(sc.get("live") or ""), use_flat_floor=np.int32(sc.get("use_flat_floor", True)),
             use_reproj_opt=np.int32(sc.get("use_reproj_opt", False)),
             use_vision_updater=np.int32(sc.get("use_vision_updater", True)), use_imu_updater=np.int32(sc.get("use_imu_updater", True)),
-            pose=np.stack(poses), tran=np.stack(trans), trace=np.asarray(trace, np.float64),
-            net_out=np.stack(outs), last_pfoot=net.last_pfoot.numpy(), **hid)
-        tr = np.asarray(trace)
+            **res)
+        tr = res["trace"]
         print(f"seq_{name}: T={T} c>=hi {np.mean(tr[:,0]>=0.8):.2f} rnn4x2 {int((tr[:,1]==2).sum())} "
               f"rnn6x2 {int((tr[:,2]==2).sum())} floor {int(tr[-1,4])} reach@{np.argmax(tr[:,5]) if tr[:,5].any() else -1} "
-              f"|tran| {np.abs(np.stack(trans)).max():.2f}")
-        Net.live = False
+              f"|tran| {np.abs(res['tran']).max():.2f}")
     import json
-    if only:
-        return
-    with open(os.path.join(OUT, "meta.json"), "w") as f:
-        json.dump(meta, f, indent=1, sort_keys=True)
+    if not only:
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+    write_hashes()
+
+
+def check_sequences(sig_mp):
+    """--check: re-run the reference on the STORED inputs of every committed sequence fixture and require the stored
+    outputs back bit for bit (pose, tran, branch trace, sub-net outputs, final states). Independent of today's
+    ``synth.make_motion``: it proves the fixtures are the reference's own numbers for the inputs they carry."""
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(WEIGHT_SEED).items()}
+    bad = 0
+    for name in sorted(os.listdir(OUT)):
+        if not (name.startswith("seq_") and name.endswith(".npz")):
+            continue
+        z = np.load(os.path.join(OUT, name))
+        inputs = {k: z[k] for k in ("j2dc", "accc", "oric", "gravityc", "first_tran")}
+        res = run_reference(sig_mp, sd, inputs, _scenario_of(z))
+        diffs = {k: (float(np.abs(v.astype(np.float64) - z[k].astype(np.float64)).max()) if v.size else 0.0) for k, v in res.items()}
+        ok = all(np.array_equal(v, z[k]) for k, v in res.items())
+        bad += 0 if ok else 1
+        print(f"{name}: {'bit-exact' if ok else 'MISMATCH ' + str({k: d for k, d in diffs.items() if d})}  (T={inputs['j2dc'].shape[0]})")
+    import json
+    with open(os.path.join(OUT, "meta.json")) as f:
+        want = json.load(f).get("sha256", {})
+    for n, h in want.items():
+        if _sha256(os.path.join(OUT, n)) != h:
+            bad += 1
+            print(f"{n}: sha256 differs from meta.json")
+    print("check:", "OK" if bad == 0 else f"{bad} problem(s)")
+    return bad
 
 
 if __name__ == "__main__":
@@ -306,6 +384,8 @@ if __name__ == "__main__":
     art, sig_mp, body = import_reference()
     torch.manual_seed(0)
     with torch.no_grad():
+        if "--check" in sys.argv[1:]:
+            sys.exit(1 if check_sequences(sig_mp) else 0)
         if not [a for a in sys.argv[1:] if not a.startswith("-")]:
             capture_ops(art, sig_mp, body)
         capture_sequences(art, sig_mp, body)

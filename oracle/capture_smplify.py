@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 from robustcap_amd import config as C  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
 import capture_reference as cr  # noqa: E402
+from oracle import _npz  # noqa: E402
 
 
 def rodrigues_np(m):
@@ -131,7 +132,8 @@ def main():
     print("closure evaluations:", len(evals), ["%.6g" % v for v in evals[:6]], "...", "%.6g" % evals[-1])
     print("runner: residual mean %.4g -> %.4g, updated %d/%d frames, |dpose| %.3g |dtran| %.3g" % (
         before.mean(), after.mean(), int(update.sum()), T, (pose_o - pred_pose).abs().max(), (tran_o - tr0).abs().max()))
-    np.savez_compressed(os.path.join(cr.OUT, "smplify.npz"), **g)
+    _npz.save(os.path.join(cr.OUT, "smplify.npz"), **g)
+    cr.write_hashes()
 
 
 if __name__ == "__main__":

@@ -62,23 +62,47 @@ def axis_angle_to_rotation_matrix(a):
 
 
 def rotation_matrix_to_axis_angle(R):
-    """[N,3,3] -> [N,3]. PARITY UNPINNED (reference: cv2.Rodrigues, angular.py:236-246). float64 atan2 form."""
-    R = R.reshape(-1, 3, 3).double()
-    v = torch.stack((R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]), dim=1) * 0.5
-    s = v.norm(dim=1)
-    c = (R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2] - 1) * 0.5
-    theta = torch.atan2(s, c)
-    k = torch.where(s > 1e-9, theta / s.clamp_min(1e-30), torch.ones_like(s))
-    out = v * k.unsqueeze(1)
-    # theta ~ pi: axis from the symmetric part
-    near_pi = (s <= 1e-9) & (c < 0)
-    if near_pi.any():
-        S = (R[near_pi] + torch.eye(3, dtype=R.dtype)) * 0.5
-        ax = torch.sqrt(torch.diagonal(S, dim1=1, dim2=2).clamp_min(0))
-        i = ax.argmax(dim=1)
-        sign = torch.sign(S[torch.arange(S.shape[0]), i]).masked_fill_(S[torch.arange(S.shape[0]), i] == 0, 1)
-        out[near_pi] = ax * sign * math.pi
-    return out.float()
+    """[N,3,3] -> [N,3]. The reference loops ``cv2.Rodrigues`` (angular.py:236-246; opencv-python-headless 4.2.0.34,
+    requirements.txt:7). OpenCV is absent here, so this restates the matrix -> vector branch of its ``cvRodrigues2``
+    (modules/calib3d/src/calibration.cpp in 4.2) step by step, in float64 like OpenCV's own arithmetic:
+
+      1. entries outside [-100, 100] or NaN              -> zero vector
+      2. R <- U V^T of the SVD of R                      (nearest orthonormal matrix)
+      3. r = (R21 - R12, R02 - R20, R10 - R01);  s = sqrt(|r|^2 / 4);  c = clamp((tr R - 1) / 2, -1, 1);  theta = acos(c)
+      4. s < 1e-5:  c > 0 -> 0;  else r = sqrt(max((R_ii + 1) / 2, 0)) with the signs of R01, R02 (and the R12 fix-up
+         when r_x is the smallest component), scaled to length theta
+      5. otherwise  r * theta / (2 s)
+      6. result rounded to the input depth (float32).
+
+    PARITY UNPINNED: no OpenCV build is available to run against; the restatement is cross-checked against scipy's
+    independent log map (tests) and by round trip with the pinned axis_angle_to_rotation_matrix."""
+    Rn = R.reshape(-1, 3, 3).double().numpy()
+    N = Rn.shape[0]
+    out = np.zeros((N, 3))
+    bad = ~np.all(np.isfinite(Rn) & (np.abs(Rn) < 100.0), axis=(1, 2))          # cv::checkRange(-100, 100), NaN fails
+    ok = np.where(~bad)[0]
+    if ok.size:
+        U, _, Vt = np.linalg.svd(Rn[ok])
+        Q = U @ Vt
+        r = np.stack((Q[:, 2, 1] - Q[:, 1, 2], Q[:, 0, 2] - Q[:, 2, 0], Q[:, 1, 0] - Q[:, 0, 1]), axis=1)
+        s = np.sqrt((r * r).sum(1) * 0.25)
+        c = np.clip((Q[:, 0, 0] + Q[:, 1, 1] + Q[:, 2, 2] - 1.0) * 0.5, -1.0, 1.0)
+        theta = np.arccos(c)
+        res = np.zeros_like(r)
+        big = s >= 1e-5
+        res[big] = r[big] * (theta[big] / (2.0 * s[big]))[:, None]
+        flip = np.where(~big & ~(c > 0))[0]
+        for k in flip:                                                           # theta ~ pi (rare): scalar code like OpenCV's
+            q = Q[k]
+            rx = math.sqrt(max((q[0, 0] + 1) * 0.5, 0.0))
+            ry = math.sqrt(max((q[1, 1] + 1) * 0.5, 0.0)) * (-1.0 if q[0, 1] < 0 else 1.0)
+            rz = math.sqrt(max((q[2, 2] + 1) * 0.5, 0.0)) * (-1.0 if q[0, 2] < 0 else 1.0)
+            if abs(rx) < abs(ry) and abs(rx) < abs(rz) and ((q[1, 2] > 0) != (ry * rz > 0)):
+                rz = -rz
+            n = math.sqrt(rx * rx + ry * ry + rz * rz)
+            res[k] = np.array([rx, ry, rz]) * (theta[k] / n) if n > 0 else 0.0
+        out[ok] = res
+    return torch.from_numpy(out.astype(np.float32))
 
 
 def rotation_angle_deg(Ra, Rb):
@@ -399,7 +423,7 @@ class OracleNet(torch.nn.Module):
         _, joint, vert = body.forward_kinematics(pose, tran)
         j_new = body.landmarks(vert, joint)
         j33 = torch.where(refresh.view(B, 1, 1), j_new, self.j_temp)
-        if self.live:
+        if self.live and (self.use_reproj_opt or self.use_vision_updater):    # L228: the counter only moves inside this block
             self.j_temp = j33.clone()
             self.update_vision_count = torch.where(refresh, torch.full_like(self.update_vision_count, self.update_vision_freq),
                                                    self.update_vision_count - 1)

@@ -56,6 +56,15 @@ SIGNATURES = {
     "rc_r6d_to_rotmat": (_I32, [_P, _P, _I64, _P]),
     "rc_axis_angle_to_rotmat": (_I32, [_P, _P, _I64, _P]),
     "rc_rotmat_to_axis_angle": (_I32, [_P, _P, _I64, _P]),
+    "rc_rotmat_to_r6d": (_I32, [_P, _P, _I64, _P]),
+    "rc_angle_between": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_lerp": (_I32, [_P, _P, C.c_double, _P, _I64, _P]),
+    "rc_normalize_rows": (_I32, [_P, _P, _P, _I64, _I32, _P]),
+    "rc_bbox_normalise": (_I32, [_P, _P, _I64, _P]),
+    "rc_fk_r": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_bone_to_joint": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_joint_to_bone": (_I32, [_P, _P, _P, _I64, _P]),
+    "rc_zero_pose": (_I32, [_P, _P, _P, _P]),
     "rc_ik_r": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_fk_bone": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_body_fk": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _P]),

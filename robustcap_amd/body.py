@@ -73,6 +73,37 @@ class ParametricModel:
         _lib.check(self._ctx, self._lib.rc_ik_r(self._ctx, _lib.ptr(Rg), _lib.ptr(out), Rg.shape[0], _lib.stream_ptr()), "rc_ik_r")
         return out
 
+    def forward_kinematics_R(self, R_local):
+        """articulate/model.py:131-145: global rotations from local ones (chained down the tree)."""
+        Rl = _f32c(R_local, self.device).view(-1, 24, 3, 3)
+        out = torch.empty_like(Rl)
+        _lib.check(self._ctx, self._lib.rc_fk_r(self._ctx, _lib.ptr(Rl), _lib.ptr(out), Rl.shape[0], _lib.stream_ptr()), "rc_fk_r")
+        return out
+
+    def bone_vector_to_joint_position(self, bone_vec):
+        """articulate/model.py:95-111: joint positions from parent->child bone vectors, [n,24,3]."""
+        b = _f32c(bone_vec, self.device).view(-1, 24, 3)
+        out = torch.empty_like(b)
+        _lib.check(self._ctx, self._lib.rc_bone_to_joint(self._ctx, _lib.ptr(b), _lib.ptr(out), b.shape[0], _lib.stream_ptr()), "rc_bone_to_joint")
+        return out
+
+    def joint_position_to_bone_vector(self, joint_pos):
+        """articulate/model.py:113-129: bone vectors (child - parent; root kept) from joint positions, [n,24,3]."""
+        j = _f32c(joint_pos, self.device).view(-1, 24, 3)
+        out = torch.empty_like(j)
+        _lib.check(self._ctx, self._lib.rc_joint_to_bone(self._ctx, _lib.ptr(j), _lib.ptr(out), j.shape[0], _lib.stream_ptr()), "rc_joint_to_bone")
+        return out
+
+    def get_zero_pose_joint_and_vertex(self, shape=None):
+        """articulate/model.py:78-93 for the mean shape: (joints [24,3], vertices [V,3]), root joint at the origin."""
+        if shape is not None:
+            raise NotImplementedError("shape=None (mean shape) on this path, model.py:86-87")
+        self._ensure_mesh()
+        j = torch.empty(24, 3, device=self.device)
+        v = torch.empty(self._V, 3, device=self.device)
+        _lib.check(self._ctx, self._lib.rc_zero_pose(self._ctx, _lib.ptr(j), _lib.ptr(v), _lib.stream_ptr()), "rc_zero_pose")
+        return j, v
+
     def bone_fk(self, R_global):
         """fk() of forward_online (net/sig_mp.py:131-135): joints from GLOBAL rotations, root at the origin."""
         Rg = _f32c(R_global, self.device).view(-1, 24, 3, 3)
@@ -175,6 +206,56 @@ def rotation_matrix_to_axis_angle(r, device="cuda"):
     out = torch.empty(x.shape[0], 3, device=x.device)
     lib = _lib.load()
     _lib.check(None, lib.rc_rotmat_to_axis_angle(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_rotmat_to_axis_angle")
+    return out
+
+
+def rotation_matrix_to_r6d(r, device="cuda"):
+    """art.math.rotation_matrix_to_r6d (angular.py:267-274): [n,3,3] -> [n,6] (first two columns)."""
+    x = _f32c(r, torch.device(device)).view(-1, 3, 3)
+    out = torch.empty(x.shape[0], 6, device=x.device)
+    _lib.check(None, _lib.load().rc_rotmat_to_r6d(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_rotmat_to_r6d")
+    return out
+
+
+def angle_between(rot1, rot2, device="cuda"):
+    """art.math.angle_between for rotation matrices (angular.py:128-141): [n] angles in radians."""
+    a, b = _f32c(rot1, torch.device(device)).view(-1, 3, 3), _f32c(rot2, torch.device(device)).view(-1, 3, 3)
+    if a.shape != b.shape:
+        raise ValueError("rot1 and rot2 must hold the same number of rotations")
+    out = torch.empty(a.shape[0], device=a.device)
+    _lib.check(None, _lib.load().rc_angle_between(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), a.shape[0], _lib.stream_ptr()), "rc_angle_between")
+    return out
+
+
+def lerp(a, b, t, device="cuda"):
+    """art.math.lerp (general.py:15-24) with a Python-float weight: a * (1 - t) + b * t, unclamped."""
+    x, y = _f32c(a, torch.device(device)), _f32c(b, torch.device(device))
+    if x.shape != y.shape:
+        raise ValueError("a and b must have the same shape")
+    out = torch.empty_like(x)
+    _lib.check(None, _lib.load().rc_lerp(_lib.ptr(x), _lib.ptr(y), C.c_double(float(t)), _lib.ptr(out), x.numel(), _lib.stream_ptr()), "rc_lerp")
+    return out
+
+
+def normalize_tensor(x, dim=-1, return_norm=False, device="cuda"):
+    """art.math.normalize_tensor (general.py:27-39) over the last dimension; the norm keeps that dimension (size 1)."""
+    v = _f32c(x, torch.device(device))
+    if dim not in (-1, v.dim() - 1):
+        raise NotImplementedError("normalize_tensor: only the last dimension (the path's only use)")
+    width = v.shape[-1]
+    rows = v.numel() // max(width, 1)
+    out = torch.empty_like(v)
+    norm = torch.empty(v.shape[:-1] + (1,), device=v.device) if return_norm else None
+    _lib.check(None, _lib.load().rc_normalize_rows(_lib.ptr(v), _lib.ptr(out), _lib.ptr(norm), rows, width, _lib.stream_ptr()), "rc_normalize_rows")
+    return (out, norm) if return_norm else out
+
+
+def normalize_keypoints(kp, device="cuda"):
+    """The bbox normalisation forward_online applies to its keypoints (net/sig_mp.py:150-152, get_bbox_scale L277-284):
+    [n,33,3] -> [n,33,3]."""
+    x = _f32c(kp, torch.device(device)).view(-1, 33, 3)
+    out = torch.empty_like(x)
+    _lib.check(None, _lib.load().rc_bbox_normalise(_lib.ptr(x), _lib.ptr(out), x.shape[0], _lib.stream_ptr()), "rc_bbox_normalise")
     return out
 
 

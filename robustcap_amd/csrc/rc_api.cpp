@@ -72,8 +72,14 @@ struct rc_ctx {
     int mesh_nk = 0;
     unsigned long long ign_mask = RC_IGN_DEFAULT;     // smplify: landmarks with zeroed confidence
     bool have_body = false, have_weights = false;
-    std::map<std::string, std::vector<float>> staged;
+    std::map<std::string, std::vector<float>> staged;    // host copy of every loaded tensor: kept, so that a partial
+                                                         // (non-strict) load_state_dict re-packs on top of the rest
     std::vector<void*> allocs;
+    std::vector<void*> weight_allocs;    // packed weights of the current rc_finalize_weights (freed by the next one)
+    bool alloc_weights = false;          // dev_alloc books into weight_allocs
+    // ordering between the eager entry points (caller's stream) and the live graph (private stream)
+    hipEvent_t eager_ev = nullptr;
+    bool eager_dirty = false;
     std::string err;
     // live mode: one captured frame on a private stream, pinned host staging
     hipStream_t live_stream = nullptr;
@@ -116,8 +122,17 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
     void* q = nullptr;
     HIP_TRY(ctx, hipMalloc(&q, count * sizeof(T)));
     if (zero) HIP_TRY(ctx, hipMemset(q, 0, count * sizeof(T)));
-    ctx->allocs.push_back(q);
+    (ctx->alloc_weights ? ctx->weight_allocs : ctx->allocs).push_back(q);
     *p = static_cast<T*>(q);
+    return RC_OK;
+}
+
+// Eager work was enqueued on the caller's stream `st`: the next live-graph replay (private stream) must wait for it.
+// (The other direction needs nothing: rc_live_step synchronises its stream before it returns.)
+int mark_eager(rc_ctx* ctx, hipStream_t st) {
+    if (!ctx->eager_ev) return RC_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->eager_ev, st));
+    ctx->eager_dirty = true;
     return RC_OK;
 }
 
@@ -406,6 +421,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->B = batch;
     ctx->Bp = round_up(batch, RC_MT);
     (void)hipGetDevice(&ctx->dev);
+    if (hipEventCreateWithFlags(&ctx->eager_ev, hipEventDisableTiming) != hipSuccess) ctx->eager_ev = nullptr;
     rc_default_params(live, &ctx->prm);
     const size_t B = (size_t)batch, Bp = (size_t)ctx->Bp;
     int rc = RC_OK;
@@ -449,6 +465,8 @@ int rc_destroy(rc_ctx* ctx) {
     rc_live_end(ctx);
     rc_smplify_free(ctx->smplify);
     for (void* p : ctx->allocs) (void)hipFree(p);
+    for (void* p : ctx->weight_allocs) (void)hipFree(p);
+    if (ctx->eager_ev) (void)hipEventDestroy(ctx->eager_ev);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
@@ -499,8 +517,25 @@ int rc_load_weight(rc_ctx* ctx, const char* key, const float* host, int64_t nume
     return RC_OK;
 }
 
+static int finalize_weights_impl(rc_ctx* ctx);
+
 int rc_finalize_weights(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
+    // A captured live frame has the old weight pointers baked into its kernel arguments: drop it (the next live step
+    // re-captures). Then wait for everything in flight and release the previous packed weights -- a reload must not
+    // leak a 242 MB copy per call.
+    rc_live_end(ctx);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    for (void* p : ctx->weight_allocs) (void)hipFree(p);
+    ctx->weight_allocs.clear();
+    ctx->have_weights = false;
+    ctx->alloc_weights = true;
+    const int rc = finalize_weights_impl(ctx);
+    ctx->alloc_weights = false;
+    return rc;
+}
+
+static int finalize_weights_impl(rc_ctx* ctx) {
     for (int i = 0; i < 6; ++i) {
         const NetSpec& s = kNets[i];
         NetDev& n = ctx->net[i];
@@ -536,7 +571,6 @@ int rc_finalize_weights(rc_ctx* ctx) {
         if (!w || !b) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing " + p);
         if (int rc = make_dense(ctx, ctx->init[q], *w, *b, kInit[q][1], kInit[q][0])) return rc;
     }
-    ctx->staged.clear();
     ctx->have_weights = true;
     HIP_TRY(ctx, hipDeviceSynchronize());
     return RC_OK;
@@ -583,7 +617,7 @@ int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream) {
     for (int i = 0; i < 6; ++i) { h[i] = ctx->net[i].h; c[i] = ctx->net[i].c; H[i] = ctx->net[i].H; }
     rc_launch_reset(ctx->fb, h, c, H, row_mask, ctx->B, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
-    return RC_OK;
+    return mark_eager(ctx, (hipStream_t)stream);
 }
 
 int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric, const float* first_tran, uint32_t flags,
@@ -592,7 +626,8 @@ int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric
     ctx->live_prev_known = false;                      // the live path's host-side flag mirror no longer knows the last frame
     if (!j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_step: null buffer");
     FrameIO io{j2dc, accc, oric, first_tran, pose_out, tran_out, 99, 18, 54, 216, 3};
-    return step_impl(ctx, io, flags, (hipStream_t)stream);
+    if (int rc = step_impl(ctx, io, flags, (hipStream_t)stream)) return rc;
+    return mark_eager(ctx, (hipStream_t)stream);
 }
 
 int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const float* accc, int64_t rs_acc, const float* oric,
@@ -606,7 +641,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                    pose_out + (int64_t)t * 216, tran_out + (int64_t)t * 3, rs_j2d, rs_acc, rs_ori, rs_pose, rs_tran};
         if (int rc = step_impl(ctx, io, t == 0 ? flags : 0u, (hipStream_t)stream)) return rc;
     }
-    return RC_OK;
+    return mark_eager(ctx, (hipStream_t)stream);
 }
 
 int rc_live_end(rc_ctx* ctx) {
@@ -675,6 +710,10 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (!j2dc || !accc || !oric || !pose || !tran) return fail(ctx, RC_ERR_INVALID, "rc_live_step: null buffer");
     const size_t B = ctx->B;
     hipStream_t st = ctx->live_stream;
+    if (ctx->eager_dirty) {          // e.g. reset_states() on the caller's stream just before this frame
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->eager_ev, 0));
+        ctx->eager_dirty = false;
+    }
     std::memcpy(ctx->live_in_h, j2dc, B * 99 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 99, accc, B * 18 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 117, oric, B * 54 * sizeof(float));
@@ -728,6 +767,65 @@ int rc_rotmat_to_axis_angle(const float* R, float* aa, int64_t n, void* stream) 
     if (!aa || !R || n < 0) return RC_ERR_INVALID;
     rc_launch_R2aa(R, aa, n, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_rotmat_to_r6d(const float* R, float* r6d, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!R || !r6d || n < 0) return RC_ERR_INVALID;
+    rc_launch_rotmat_to_r6d(R, r6d, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_angle_between(const float* R1, const float* R2, float* out, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!R1 || !R2 || !out || n < 0) return RC_ERR_INVALID;
+    rc_launch_angle_between(R1, R2, out, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_lerp(const float* a, const float* b, double t, float* out, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!a || !b || !out || n < 0) return RC_ERR_INVALID;
+    rc_launch_lerp(a, b, (float)(1.0 - t), (float)t, out, n, (hipStream_t)stream);     // general.py:24: a * (1 - t) + b * t
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_normalize_rows(const float* x, float* out, float* norm, int64_t rows, int32_t width, void* stream) {
+    if (rows == 0) return RC_OK;
+    if (!x || !out || rows < 0 || width < 1) return RC_ERR_INVALID;
+    rc_launch_normalize_rows(x, out, norm, rows, width, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_bbox_normalise(const float* kp, float* out, int64_t n, void* stream) {
+    if (n == 0) return RC_OK;
+    if (!kp || !out || n < 0) return RC_ERR_INVALID;
+    rc_launch_bbox_normalise(kp, out, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+int rc_fk_r(rc_ctx* ctx, const float* Rl, float* Rg, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_fk_r: body not set") : RC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!Rl || !Rg))) return fail(ctx, RC_ERR_INVALID, "rc_fk_r: bad argument");
+    rc_launch_fk_r(ctx->body, Rl, Rg, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_bone_to_joint(rc_ctx* ctx, const float* bone, float* joint, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_bone_to_joint: body not set") : RC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!bone || !joint))) return fail(ctx, RC_ERR_INVALID, "rc_bone_to_joint: bad argument");
+    rc_launch_bone_to_joint(ctx->body, bone, joint, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_joint_to_bone(rc_ctx* ctx, const float* joint, float* bone, int64_t n, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_joint_to_bone: body not set") : RC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!bone || !joint))) return fail(ctx, RC_ERR_INVALID, "rc_joint_to_bone: bad argument");
+    rc_launch_joint_to_bone(ctx->body, joint, bone, n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+int rc_zero_pose(rc_ctx* ctx, float* joint, float* vert, void* stream) {
+    if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_zero_pose: body not set") : RC_ERR_INVALID;
+    if (!joint) return fail(ctx, RC_ERR_INVALID, "rc_zero_pose: null buffer");
+    if (vert && ctx->mesh_V == 0) return fail(ctx, RC_ERR_STATE, "rc_zero_pose: vertices need rc_set_mesh");
+    rc_launch_zero_pose(ctx->body, ctx->mesh_vt, ctx->mesh_V, joint, vert, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
 }
 int rc_ik_r(rc_ctx* ctx, const float* Rg, float* Rl, int64_t n, void* stream) {
     if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_ik_r: body not set") : RC_ERR_INVALID;
@@ -871,7 +969,7 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
         GemmProblem p = phase == 0 ? lin1_problem(ctx, s) : (phase == 3 ? lin2_problem(ctx, s) : lstm_problem(ctx, s, phase - 1));
         if (int rc = launch_problems(ctx, {p}, row_mask, st)) return rc;
     }
-    return RC_OK;
+    return mark_eager(ctx, st);
 }
 
 int rc_camera_inputs(const float* kp, const float* acc, const float* ori, const float* K, const float* Tcw, float* j2dc,

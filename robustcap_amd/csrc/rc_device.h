@@ -165,31 +165,56 @@ __device__ __forceinline__ void bbox_normalise(float x, float y, int lane, float
     if (lane != 23) { xn -= hx; yn -= hy; }
 }
 
-// art.math.rotation_matrix_to_axis_angle (angular.py:236-246 loops cv2.Rodrigues on the host). Restated from the
-// Rodrigues formula in float64: theta = atan2(|v|, (tr - 1) / 2), v = vee(R - R^T) / 2; near pi the axis comes
-// from the symmetric part. PARITY UNPINNED against OpenCV (absent); validated by round trip.
+// art.math.rotation_matrix_to_axis_angle (angular.py:236-246 loops cv2.Rodrigues on the host): the matrix -> vector
+// branch of OpenCV 4.2's cvRodrigues2 restated step by step in float64 (see oracle/sig_mp_oracle.py for the list):
+// range check -> nearest orthonormal matrix (OpenCV: U V^T of the SVD; here the same polar factor by scaled Newton
+// iteration Q <- (g Q + Q^-T / g) / 2, which converges to U V^T for any non-singular input) -> theta = acos(clamp c),
+// s = |vee(Q - Q^T)| / 2 -> s < 1e-5 ? (c > 0 ? 0 : sqrt-diagonal branch) : r theta / (2 s) -> float32.
+// PARITY UNPINNED against OpenCV itself (absent); cross-checked against scipy and the SVD-based oracle.
 __device__ __forceinline__ void rotmat_to_aa(const float* Rm, float* aa) {
-    double R[9];
+    double Q[9];
+    bool ok = true;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) R[q] = (double)Rm[q];
-    const double v[3] = {(R[7] - R[5]) * 0.5, (R[2] - R[6]) * 0.5, (R[3] - R[1]) * 0.5};
-    const double sn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
-    const double th = atan2(sn, c);
-    double o[3];
-    if (sn > 1e-9) {
-        const double kf = th / sn;
-        o[0] = v[0] * kf; o[1] = v[1] * kf; o[2] = v[2] * kf;
-    } else if (c > 0.0) {
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-    } else {                                     // theta = pi: R + I = 2 a a^T
-        const double d[3] = {sqrt(fmax((R[0] + 1.0) * 0.5, 0.0)), sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)), sqrt(fmax((R[8] + 1.0) * 0.5, 0.0))};
-        int m = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
-        double ax[3] = {d[0], d[1], d[2]};
-        for (int q = 0; q < 3; ++q)
-            if (q != m && (R[3 * m + q] + R[3 * q + m]) < 0.0) ax[q] = -ax[q];
-        const double pi = 3.14159265358979323846;
-        o[0] = ax[0] * pi; o[1] = ax[1] * pi; o[2] = ax[2] * pi;
+    for (int q = 0; q < 9; ++q) { Q[q] = (double)Rm[q]; ok = ok && (fabs(Q[q]) < 100.0); }   // NaN fails the compare
+    aa[0] = 0.0f; aa[1] = 0.0f; aa[2] = 0.0f;
+    if (!ok) return;
+    for (int it = 0; it < 24; ++it) {
+        double C[9];                                     // cofactors: Q^-T = C / det
+        C[0] = Q[4] * Q[8] - Q[5] * Q[7]; C[1] = Q[5] * Q[6] - Q[3] * Q[8]; C[2] = Q[3] * Q[7] - Q[4] * Q[6];
+        C[3] = Q[2] * Q[7] - Q[1] * Q[8]; C[4] = Q[0] * Q[8] - Q[2] * Q[6]; C[5] = Q[1] * Q[6] - Q[0] * Q[7];
+        C[6] = Q[1] * Q[5] - Q[2] * Q[4]; C[7] = Q[2] * Q[3] - Q[0] * Q[5]; C[8] = Q[0] * Q[4] - Q[1] * Q[3];
+        const double det = Q[0] * C[0] + Q[1] * C[1] + Q[2] * C[2];
+        if (!(fabs(det) > 1e-300)) return;               // singular input: OpenCV's U V^T is not unique either
+        double nq = 0.0, nc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { nq += Q[q] * Q[q]; nc += C[q] * C[q]; }
+        const double g = sqrt(sqrt(nc) / (fabs(det) * sqrt(nq)));   // sqrt(|Q^-1|_F / |Q|_F)
+        double delta = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double n = 0.5 * (g * Q[q] + C[q] / (det * g));
+            delta = fmax(delta, fabs(n - Q[q]));
+            Q[q] = n;
+        }
+        if (delta < 1e-15) break;
     }
-    aa[0] = (float)o[0]; aa[1] = (float)o[1]; aa[2] = (float)o[2];
+    double r[3] = {Q[7] - Q[5], Q[2] - Q[6], Q[3] - Q[1]};
+    const double s = sqrt((r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * 0.25);
+    double c = (Q[0] + Q[4] + Q[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0.0) return;
+        r[0] = sqrt(fmax((Q[0] + 1.0) * 0.5, 0.0));
+        r[1] = sqrt(fmax((Q[4] + 1.0) * 0.5, 0.0)) * (Q[1] < 0.0 ? -1.0 : 1.0);
+        r[2] = sqrt(fmax((Q[8] + 1.0) * 0.5, 0.0)) * (Q[2] < 0.0 ? -1.0 : 1.0);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && ((Q[5] > 0.0) != (r[1] * r[2] > 0.0))) r[2] = -r[2];
+        const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        if (!(n > 0.0)) return;
+        const double k = theta / n;
+        aa[0] = (float)(r[0] * k); aa[1] = (float)(r[1] * k); aa[2] = (float)(r[2] * k);
+    } else {
+        const double k = theta / (2.0 * s);
+        aa[0] = (float)(r[0] * k); aa[1] = (float)(r[1] * k); aa[2] = (float)(r[2] * k);
+    }
 }

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 #pragma unroll
             for (int c = 0; c < 3; ++c) fb.floor[row * 33 + 3 * appended + c] = pick[c];
         }
-        if (live) fb.uv_count[row] = refresh ? prm.update_vision_freq : uvc - 1;   // L234-242
+        // L228, L234-242: the refresh counter only moves while one of its two consumers is switched on
+        if (live && (prm.use_reproj_opt || prm.use_vision_updater)) fb.uv_count[row] = refresh ? prm.update_vision_freq : uvc - 1;
         fb.pend[row] = (flags & RC_ROW_UPD) ? 1 : 0;                     // L264-271 run at the start of the next frame
         int* tr = fb.trace + row * 8;
         tr[1] = ((flags & RC_ROW_VIS) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 
     // L228-242: mesh landmarks from the LOCAL pose chained from the camera-frame root
     wave_body_fk(body, s, tran, lane);
-    if (live) {
+    if (live && (prm.use_reproj_opt || prm.use_vision_updater)) {
         if (lane < 33) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

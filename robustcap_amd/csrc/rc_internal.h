@@ -144,6 +144,15 @@ void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
 struct CamConst { float Kinv[9]; float R[9]; };
 void rc_launch_camera_inputs(const float* kp, const float* acc, const float* ori, const CamConst& cam, float* j2dc, float* accc,
                              float* oric, long long n, hipStream_t s);
+void rc_launch_fk_r(const BodyConst* body, const float* Rl, float* Rg, long long n, hipStream_t s);
+void rc_launch_bone_to_joint(const BodyConst* body, const float* bone, float* joint, long long n, hipStream_t s);
+void rc_launch_joint_to_bone(const BodyConst* body, const float* joint, float* bone, long long n, hipStream_t s);
+void rc_launch_zero_pose(const BodyConst* body, const float* vt, int V, float* joint, float* vert, hipStream_t s);
+void rc_launch_rotmat_to_r6d(const float* R, float* r6d, long long n, hipStream_t s);
+void rc_launch_lerp(const float* a, const float* b, float w1, float w2, float* out, long long n, hipStream_t s);
+void rc_launch_normalize_rows(const float* x, float* out, float* norm, long long rows, int width, hipStream_t s);
+void rc_launch_angle_between(const float* R1, const float* R2, float* out, long long n, hipStream_t s);
+void rc_launch_bbox_normalise(const float* kp, float* out, long long n, hipStream_t s);
 void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t s);
 void rc_launch_R2aa(const float* R, float* aa, long long n, hipStream_t s);
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);

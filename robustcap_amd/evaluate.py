@@ -79,7 +79,6 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     mine = all_rows[a:b]
     Tmax = max(len(dataset["pose"][i]) for i, _ in all_rows)
     n = len(mine)
-    pose_all = torch.zeros(len(all_rows) if world > 1 else n, Tmax, 216)
     out_p = torch.zeros(max(n, 1), Tmax, 24, 3, 3, device=device)
     out_t = torch.zeros(max(n, 1), Tmax, 3, device=device)
     if n:
@@ -112,10 +111,10 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
                 out_p[r, :T], out_t[r, :T] = p, t
                 if smplify_info is not None:
                     smplify_info[(i, j)] = dict(runner.last_info)
-    del pose_all
     if world > 1:                                                       # the path's only collective
-        cap_p = rdist.gather_rows(out_p[:n].reshape(n, -1), len(all_rows))
-        cap_t = rdist.gather_rows(out_t[:n].reshape(n, -1), len(all_rows))
+        # explicit widths: a rank whose shard is empty (rows < world) must still reach the collective
+        cap_p = rdist.gather_rows(out_p[:n].reshape(n, Tmax * 216), len(all_rows))
+        cap_t = rdist.gather_rows(out_t[:n].reshape(n, Tmax * 3), len(all_rows))
         out_p, out_t, rows_out = cap_p.view(-1, Tmax, 24, 3, 3), cap_t.view(-1, Tmax, 3), all_rows
     else:
         rows_out = mine

@@ -142,6 +142,7 @@ class Net:
             v = np.ascontiguousarray(v, dtype=np.float32)
             _lib.check(self._ctx, self._lib.rc_load_weight(self._ctx, k.encode(), v.ctypes.data_as(C.c_void_p), v.size), "rc_load_weight")
         _lib.check(self._ctx, self._lib.rc_finalize_weights(self._ctx), "rc_finalize_weights")
+        self.__dict__["_live_on"] = False          # the library dropped its captured frame (it held the old weight pointers)
         self.__dict__["_loaded"] = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 

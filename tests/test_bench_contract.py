@@ -1,0 +1,69 @@
+"""bench.py's contract with the driver: the JSON line must come out for the driver's own arguments
+(`--gpus 1 --steps 20 --warmup 5` killed round 1's run inside cpu_baseline), whatever the side legs do."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpu_baseline_on_short_inputs(synth_assets):
+    """cpu_baseline must work on inputs shorter than its default sample (T = 5 << 1 + 96 frames)."""
+    import bench
+    m = bench.make_inputs(synth_assets["body"], 2, 5, "mixed", seed=2)
+    out = bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], m)
+    assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
+    assert "x 4 frames" in out["sample"] and "(4 frames" in out["sample"]          # clamped to T - 1
+    with pytest.raises(ValueError):
+        bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], {k: v[:, :1] if v.ndim > 2 else v for k, v in m.items()})
+
+
+def test_guarded_records_the_error_instead_of_raising():
+    import bench
+
+    def boom():
+        raise IndexError("index 25 is out of bounds")
+    out = bench.guarded(boom)
+    assert out == {"error": "IndexError: index 25 is out of bounds"}
+    assert bench.guarded(lambda: 7) == 7
+
+
+def test_pmc_traffic_is_keyed_by_batch_and_schedule():
+    import bench
+    v, src = bench.pmc_traffic(12345, "mixed")                 # no PMC pass of such a batch is committed
+    assert v is None and src is None
+    for name in os.listdir(os.path.join(ROOT, "profiles")):
+        if "pmc_traffic" in name and name.endswith(".json"):
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if "batch" in d and "conf" in d:
+                v, src = bench.pmc_traffic(int(d["batch"]), d["conf"])
+                assert v is not None and v > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong"]])
+def test_bench_runs_with_the_drivers_arguments(extra):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -> rc 0 and one JSON line with roofline + cpu_baseline."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"] + extra
+    if extra:
+        cmd.append("--no-cpu-baseline")                         # the CPU leg is covered by the first run
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "body-frames/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["bodies_total"] * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+    assert d["config"]["batch_per_gpu"] == 256 and "batch 256" in d["config"]["workload"]
+    assert d["scaling"] == ("strong" if extra else "weak")
+    roof = d["roofline"]
+    assert "error" not in roof and 0 < roof["frac"] < 1 and roof["bound"] == "mfma"
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert d["variants"]["high"]["value"] > 0
+    if not extra:
+        cpu = d["cpu_baseline"]
+        assert "error" not in cpu and cpu["value"] > 0 and cpu["kind"] == "port"

@@ -59,6 +59,12 @@ def _worker(rank, world, port, B, T, out_dir):
         assert (out is None) == (rank != 0)
         if rank == 0:
             assert out.shape == (2 * world, 5) and all(float(out[2 * q, 0]) == 10 * q + c for q in range(world))
+    # fewer rows than ranks (evaluate.run_dataset with a short row list): the empty shard still joins the collective,
+    # with the explicit trailing width run_dataset passes (reshape(0, -1) would have raised before reaching it)
+    a1, b1 = rdist.shard_range(1, rank, world)
+    empty_ok = torch.zeros(max(b1 - a1, 1), 7, 3)[:b1 - a1].reshape(b1 - a1, 21) + float(rank + 1)
+    g1 = rdist.gather_rows(empty_ok, 1)
+    assert g1.shape == (1, 21) and float(g1[0, 0]) == 1.0
     torch.save((pose, tran), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

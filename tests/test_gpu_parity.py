@@ -99,6 +99,40 @@ def test_ik_and_bone_fk(ops, pm):
     assert maxdiff(pm.bone_fk(eye)[0], ob.j_rest) <= 1e-6
 
 
+def test_model_surface_vs_reference_vectors(ops, pm, synth_assets):
+    """The rest of the ParametricModel / art.math surface SURVEY.md 8(b) lists, each on its HIP entry point against the
+    vectors the reference itself produced (oracle/capture_reference.py: fkr_out, bonefk_*, bone_rest, bbox_*, lerp_*,
+    rot2r6d_out, norm_*)."""
+    from robustcap_amd import body as B
+    assert maxdiff(pm.forward_kinematics_R(t(ops["ik_out"])), ops["fkr_out"]) <= 2e-6        # FK_R(IK_R(R)) from the reference
+    assert maxdiff(pm.forward_kinematics_R(t(ops["ik_out"])), ops["ik_in"]) <= 5e-6          # ... which is R again
+    assert maxdiff(pm.bone_vector_to_joint_position(t(ops["bonefk_in"])), ops["bonefk_out"]) <= 1e-6
+    assert maxdiff(pm.joint_position_to_bone_vector(t(ops["bonefk_out"])), ops["bonefk_in"]) <= 2e-6
+    j0, v0 = pm.get_zero_pose_joint_and_vertex()
+    body = synth_assets["body"]
+    assert maxdiff(j0, body["J"] - body["J"][:1]) == 0.0 and maxdiff(v0, body["v_template"] - body["J"][:1]) == 0.0
+    assert maxdiff(pm.joint_position_to_bone_vector(j0.view(1, 24, 3))[0], ops["bone_rest"]) <= 1e-7
+    assert pm.parent[0] is None and pm.parent[1:] == [int(p) for p in body["parent"][1:]]
+    assert maxdiff(B.normalize_keypoints(t(ops["bbox_in"])), ops["bbox_out"]) <= 1e-6
+    for k, want in zip(ops["lerp_k"], ops["lerp_out"]):
+        assert maxdiff(B.lerp(t(ops["lerp_a"]), t(ops["lerp_b"]), float(k)), want) == 0.0     # double weights, no fma
+    assert maxdiff(B.rotation_matrix_to_r6d(t(ops["ik_in"])), ops["rot2r6d_out"]) == 0.0
+    assert maxdiff(B.r6d_to_rotation_matrix(B.rotation_matrix_to_r6d(t(ops["ik_in"]))), ops["ik_in"].reshape(-1, 3, 3)) <= 2e-6
+    n, ln = B.normalize_tensor(t(ops["norm_in"]), return_norm=True)
+    ok = np.isfinite(ops["norm_out"]).all(axis=1)
+    assert maxdiff(n.cpu().numpy()[ok], ops["norm_out"][ok]) <= 2e-7 and maxdiff(ln, ops["norm_len"]) <= 1e-6
+    assert torch.isnan(n[~torch.from_numpy(ok)]).all()                                       # zero row -> NaN like the reference
+    assert n.shape == ops["norm_out"].shape and ln.shape == ops["norm_len"].shape
+    # angle_between goes through the (unpinned) Rodrigues vector: checked against the known angle of a constructed offset
+    aa = t(ops["aa_in"])
+    R = B.axis_angle_to_rotation_matrix(aa)
+    base = t(ops["ik_in"]).reshape(-1, 3, 3)[:R.shape[0]].cuda()
+    ang = B.angle_between(base, base @ R)
+    want = aa.norm(dim=1)
+    want = torch.where(want > np.pi, 2 * np.pi - want, want)
+    assert maxdiff(ang, want) <= 2e-4                                                        # float32 products near pi
+
+
 def test_body_fk_landmarks(ops, pm):
     G, J, L = pm.forward_kinematics(t(ops["fk_pose"]), tran=t(ops["fk_tran"]), calc_mesh=True)
     assert maxdiff(G, ops["fk_grot"]) <= 2e-6
@@ -359,18 +393,41 @@ def test_updater_switches_vs_oracle(vis, imu, synth_assets):
 
 
 def test_rotmat_to_axis_angle_against_scipy():
-    """rc_rotmat_to_axis_angle against scipy's Rotation.as_rotvec (an independent implementation of the log map the
-    reference takes from OpenCV, which is absent here: parity with cv2 itself stays unpinned)."""
+    """The reference calls OpenCV's cv2.Rodrigues here (absent: parity with cv2 itself stays unpinned).
+    The restatement of its steps (re-orthonormalisation, acos, the s < 1e-5 branches) is cross-checked against scipy's
+    independent log map on random rotations, angles close to 0 and to pi, exactly pi, and NON-orthonormal inputs
+    (where OpenCV first projects onto the nearest orthonormal matrix)."""
     from scipy.spatial.transform import Rotation
     from robustcap_amd import synth
     from robustcap_amd.body import rotation_matrix_to_axis_angle
     aa = synth.normal(9, 0, 3000).reshape(-1, 3).astype(np.float64)
-    aa[:100] *= 1e-4
+    aa[:100] *= 1e-4                                                        # tiny angles
     ax = aa[100:200] / np.linalg.norm(aa[100:200], axis=1, keepdims=True)
-    aa[100:200] = ax * (np.pi - 0.01 - 0.04 * synth.uniform01(9, 1, 100)[:, None])
+    aa[100:200] = ax * (np.pi - 0.01 - 0.04 * synth.uniform01(9, 1, 100)[:, None])   # 0.6 .. 2.9 degrees below pi
     n = np.linalg.norm(aa, axis=1)
-    aa[n > np.pi] *= ((np.pi - 0.05) / n[n > np.pi])[:, None]
+    aa[n > np.pi] *= ((np.pi - 0.05) / n[n > np.pi])[:, None]                # keep the principal branch
     R = Rotation.from_rotvec(aa).as_matrix().astype(np.float32)
     got = rotation_matrix_to_axis_angle(t(R)).cpu().numpy()
     want = Rotation.from_matrix(R.astype(np.float64)).as_rotvec()
-    assert np.abs(got - want).max() <= 2e-4 and np.abs(got[200:] - want[200:]).max() <= 5e-6
+    assert np.abs(got - want).max() <= 2e-4                                  # float32 matrices: the log map is ill-conditioned near pi
+    assert np.abs(got[200:] - want[200:]).max() <= 5e-6
+    from oracle import sig_mp_oracle as O                                   # SVD-based restatement of the same steps
+    assert np.abs(got - O.rotation_matrix_to_axis_angle(t(R)).numpy()).max() <= 2e-6
+    # OpenCV's s < 1e-5 band: exactly zero near the identity, sqrt-of-diagonal branch near pi (round trip within float32)
+    tiny = Rotation.from_rotvec(ax * 1e-7).as_matrix().astype(np.float32)
+    R = tiny
+    assert np.abs(rotation_matrix_to_axis_angle(t(R)).cpu().numpy()).max() == 0.0
+    for eps in (0.0, 1e-7, 1e-6):
+        R = Rotation.from_rotvec(ax * (np.pi - eps)).as_matrix().astype(np.float32)
+        got = rotation_matrix_to_axis_angle(t(R)).cpu().numpy().astype(np.float64)
+        assert np.abs(np.linalg.norm(got, axis=1) - np.pi).max() <= 2e-5
+        assert np.abs(Rotation.from_rotvec(got).as_matrix() - R).max() <= 5e-6
+    # non-orthonormal inputs: same answer as the log map of the polar factor U V^T; out-of-range / NaN -> zeros
+    noisy = (Rotation.from_rotvec(aa[200:1000]).as_matrix() + 0.05 * synth.normal(9, 5, 7200).reshape(-1, 3, 3)).astype(np.float32)
+    R = noisy
+    U, _, Vt = np.linalg.svd(noisy.astype(np.float64))
+    want = Rotation.from_matrix(U @ Vt).as_rotvec()
+    got = rotation_matrix_to_axis_angle(t(R)).cpu().numpy()
+    assert np.abs(got - want).max() <= 5e-6
+    R = np.stack([np.full((3, 3), 1000.0), np.full((3, 3), np.nan)]).astype(np.float32)
+    assert np.abs(rotation_matrix_to_axis_angle(t(R)).cpu().numpy()).max() == 0.0

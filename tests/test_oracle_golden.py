@@ -40,6 +40,19 @@ def test_assets_match_capture(golden_dir, synth_assets):
     assert sum(v.size for v in synth_assets["state_dict"].values()) == 63_424_546
 
 
+def test_fixture_files_match_their_recorded_hashes(golden_dir):
+    """Every tests/golden/*.npz carries its sha256 in meta.json (written by the capture scripts): a fixture edited or
+    regenerated without going through ``oracle/capture_*.py`` (whose ``--check`` re-runs the reference on the stored
+    inputs) fails here."""
+    import hashlib
+    want = json.load(open(os.path.join(golden_dir, "meta.json")))["sha256"]
+    have = sorted(os.path.basename(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
+    assert have == sorted(want), "fixture set and meta.json disagree"
+    for name, h in want.items():
+        with open(os.path.join(golden_dir, name), "rb") as f:
+            assert hashlib.sha256(f.read()).hexdigest() == h, name
+
+
 def test_r6d(ops):
     out = O.r6d_to_rotation_matrix(t(ops["r6d_in"]))
     assert maxdiff(out, ops["r6d_out"]) <= 1e-6
@@ -150,9 +163,10 @@ def test_batch_rows_equal_single_runs(synth_assets):
 
 
 def test_rotmat_to_axis_angle_against_scipy():
-    """The reference calls OpenCV's cv2.Rodrigues here (absent: parity unpinned). An independent
-    implementation of the same log map -- scipy's Rotation.as_rotvec -- agrees with the restatement on random
-    rotations, including angles close to 0 and close to pi."""
+    """The reference calls OpenCV's cv2.Rodrigues here (absent: parity with cv2 itself stays unpinned).
+    The restatement of its steps (re-orthonormalisation, acos, the s < 1e-5 branches) is cross-checked against scipy's
+    independent log map on random rotations, angles close to 0 and to pi, exactly pi, and NON-orthonormal inputs
+    (where OpenCV first projects onto the nearest orthonormal matrix)."""
     from scipy.spatial.transform import Rotation
     from robustcap_amd import synth
     aa = synth.normal(9, 0, 3000).reshape(-1, 3).astype(np.float64)
@@ -166,3 +180,21 @@ def test_rotmat_to_axis_angle_against_scipy():
     want = Rotation.from_matrix(R.astype(np.float64)).as_rotvec()
     assert np.abs(got - want).max() <= 2e-4                                  # float32 matrices: the log map is ill-conditioned near pi
     assert np.abs(got[200:] - want[200:]).max() <= 5e-6
+    # OpenCV's s < 1e-5 band: exactly zero near the identity, sqrt-of-diagonal branch near pi (round trip within float32)
+    tiny = Rotation.from_rotvec(ax * 1e-7).as_matrix().astype(np.float32)
+    R = tiny
+    assert np.abs(O.rotation_matrix_to_axis_angle(t(R)).numpy()).max() == 0.0
+    for eps in (0.0, 1e-7, 1e-6):
+        R = Rotation.from_rotvec(ax * (np.pi - eps)).as_matrix().astype(np.float32)
+        got = O.rotation_matrix_to_axis_angle(t(R)).numpy().astype(np.float64)
+        assert np.abs(np.linalg.norm(got, axis=1) - np.pi).max() <= 2e-5
+        assert np.abs(Rotation.from_rotvec(got).as_matrix() - R).max() <= 5e-6
+    # non-orthonormal inputs: same answer as the log map of the polar factor U V^T; out-of-range / NaN -> zeros
+    noisy = (Rotation.from_rotvec(aa[200:1000]).as_matrix() + 0.05 * synth.normal(9, 5, 7200).reshape(-1, 3, 3)).astype(np.float32)
+    R = noisy
+    U, _, Vt = np.linalg.svd(noisy.astype(np.float64))
+    want = Rotation.from_matrix(U @ Vt).as_rotvec()
+    got = O.rotation_matrix_to_axis_angle(t(R)).numpy()
+    assert np.abs(got - want).max() <= 5e-6
+    R = np.stack([np.full((3, 3), 1000.0), np.full((3, 3), np.nan)]).astype(np.float32)
+    assert np.abs(O.rotation_matrix_to_axis_angle(t(R)).numpy()).max() == 0.0
