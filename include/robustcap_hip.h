@@ -97,10 +97,32 @@ int rc_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float* oric
  * indexed [row][t] with element strides  row_stride_* (between rows) and T contiguous frames per row:
  *   j2dc + row*rs_j2d + t*99, accc + row*rs_acc + t*18, oric + row*rs_ori + t*54,
  *   pose_out + row*rs_pose + t*216, tran_out + row*rs_tran + t*3.
- * Frame 0 uses first_tran (if not NULL) and `flags`; later frames use neither. */
+ * Frame 0 uses first_tran (if not NULL) and `flags`; later frames use neither. See rc_set_sequence_mode for how the
+ * frames are scheduled (and for the one synchronisation of `stream` the default mode costs per call). */
 int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const float* accc, int64_t rs_acc,
                 const float* oric, int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out,
                 int64_t rs_pose, float* tran_out, int64_t rs_tran, void* stream);
+
+/* Sequence mode of rc_sequence (on by default). With mode = 1 every rc_sequence call of T >= 2 frames first classifies
+ * each (frame, row) on the device (the arithmetic of the per-frame prep kernel), reads the codes back -- ONE
+ * synchronisation of `stream` per call -- and plans the launches on the host:
+ *   - stretches of >= min_frames frames on which every row sees the camera (c > conf_lo), no row fires the one-shot
+ *     init_net (net/sig_mp.py:178-183) and no deferred vision-updater step is pending run on the WAVEFRONT engine: the 11
+ *     stages of a frame are skewed over consecutive ticks, one gate-GEMM launch per tick carries all 24 GEMM problems
+ *     (each on its own frame), the per-row kernels run beside it on a context-owned second stream. This is the full-sequence
+ *     form of the recurrence (the reference's own is RNN.forward over packed sequences, articulate/utils/torch/rnn.py:129-133);
+ *     outputs are bitwise those of the frame-stepped launches;
+ *   - every other frame runs the frame-stepped launches, without the three transition launches when the plan proves that
+ *     no row needs one.
+ * mode = 0: frame-stepped launches only, no pre-pass, no synchronisation. Live contexts (rc_params.live) always behave
+ * like mode 0. rc_get_sequence_stats: frames run by each engine and ticks launched since rc_create (any may be NULL).
+ * rc_plan_sequence is the planner alone on HOST data (tests): codes[T*B] (0: c <= lo, 1: mid, 2: c >= hi; frame-major),
+ * first_reach[B], pend[B] -> mode_out[T] (0 frame-stepped with transition launches, 1 without, 2 wavefront). */
+int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames);
+int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_frames, int64_t* ticks);
+int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* first_reach, const int32_t* pend, uint32_t flags,
+                     int32_t has_first_tran, int32_t use_imu_updater, int32_t use_vision_updater, int32_t min_frames,
+                     uint8_t* mode_out);
 
 /* ---- live / streaming mode (BASELINE config 5) ------------------------------------------------------------- */
 /* The live_server.py loop (live_server.py:40-48): one frame per call, HOST tensors in and out exactly like

@@ -100,6 +100,22 @@ struct rc_ctx {
     size_t ev_used = 0;
     double timed_ms = 0.0;
     long long timed_launches = 0;
+    // sequence mode (rc_sequence on all-visible stretches): skewed stage pipeline, one gate-GEMM launch per tick
+    int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (rc_set_sequence_mode)
+    int seq_min_frames = 16;             // shortest stretch worth filling the 11-stage pipeline for
+    bool ring_ready = false;
+    FrameBuffers ring[16];               // slot 0 = fb; slots 1..15 allocated on first use
+    float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
+    GemmTick* tick_tables = nullptr;     // [16] device-resident launch tables, one per (tick mod 16)
+    int tick_total_wg = 0;
+    bool tick_valid = false;
+    hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
+    hipEvent_t ev_main[8] = {}, ev_aux[8] = {};
+    signed char* scan_codes_d = nullptr; // [cap] regime code per (frame, row)
+    signed char* scan_codes_h = nullptr; // pinned
+    int* scan_state_h = nullptr;         // pinned: first_reach[B] then pend[B] (as ints)
+    size_t scan_cap = 0;
+    long long stat_wave_frames = 0, stat_stepped_frames = 0, stat_ticks = 0;
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
 };
@@ -379,6 +395,181 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
                            Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st);
 }
 
+// ====================================================================================== sequence mode (wavefront)
+// Frames on which EVERY row sees the camera (c > lo), no row fires the one-shot init_net and no deferred updater step is
+// pending have no feedback from the end of the frame into any sub-net (net/sig_mp.py:264-271 only fires at c <= lo,
+// L178-183 once per sequence). On a stretch of such frames the 11 stages of a frame
+//   0 prep | 1 linear1{rnn2,rnn4} | 2,3 LSTM l0,l1 {rnn2,rnn4} | 4 linear2{rnn2,rnn4} | 5 fuse |
+//   6 linear1{rnn6,rnn3,rnn7,rnn8} | 7,8 LSTM l0,l1 | 9 linear2 | 10 tail
+// only depend on the previous stage of the SAME frame and on their own state of the PREVIOUS frame, so tick k runs
+// stage s on frame k - s for all s at once: ONE gate-GEMM launch per tick carries all 24 GEMM problems (3,000+ tiles:
+// no launch boundary, no under-filled launch inside a frame), while the three per-row kernels run beside it on a second
+// stream. Inter-stage buffers are rings of 16 frames; the step counters stand still during a segment (parity comes from
+// step_off) and are advanced once at its end. Same tiles, same arithmetic: outputs are bitwise those of the
+// frame-stepped path.
+enum { SEQ_STEPPED_TR = 0, SEQ_STEPPED = 1, SEQ_WAVE = 2 };
+const int kRing = 16, kStages = 11;
+
+struct TickStage { int kind; int net; int stage; };     // kind: 0 linear1, 1 LSTM l0, 2 LSTM l1, 3 linear2
+const TickStage kTick[RC_TICK_PROB] = {
+    {1, N4, 2}, {2, N4, 3}, {1, N6, 7}, {2, N6, 8},                               // longest tiles first
+    {1, N2, 2}, {2, N2, 3}, {1, N3, 7}, {1, N7, 7}, {1, N8, 7}, {2, N3, 8}, {2, N7, 8}, {2, N8, 8},
+    {0, N4, 1}, {0, N2, 1}, {0, N6, 6}, {0, N3, 6}, {0, N7, 6}, {0, N8, 6},
+    {3, N4, 4}, {3, N2, 4}, {3, N6, 9}, {3, N3, 9}, {3, N7, 9}, {3, N8, 9}};
+
+int ensure_sequence_buffers(rc_ctx* ctx) {
+    if (ctx->ring_ready) return RC_OK;
+    const size_t B = (size_t)ctx->B, Bp = (size_t)ctx->Bp;
+    ctx->ring[0] = ctx->fb;
+    for (int s = 1; s < kRing; ++s) {
+        FrameBuffers f = ctx->fb;                      // state pointers are shared; the per-frame buffers get their own slot
+        int rc = RC_OK;
+#define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
+        A(f.x2, Bp * 128); A(f.x3, Bp * 256); A(f.x4, Bp * 256); A(f.x6, Bp * 256); A(f.x78, Bp * 256); A(f.xi, Bp * 128);
+        A(f.vr, B * 4); A(f.pc, B * 4); A(f.r6d, B * 144); A(f.contact, B * 2);
+        A(f.flags, B); A(f.flags2, B); A(f.regime, B); A(f.kconf, B);
+#undef A
+        if (rc) return rc;
+        ctx->ring[s] = f;
+    }
+    for (int i = 0; i < 6; ++i)
+        if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
+    if (int rc = dev_alloc(ctx, &ctx->tick_tables, (size_t)kRing)) return rc;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], hipEventDisableTiming));
+    }
+    ctx->ring_ready = true;
+    ctx->tick_valid = false;
+    return RC_OK;
+}
+
+// launch tables of the 16 tick residues: stage s of residue r works on ring slot (r - s) mod 16
+int build_tick_tables(rc_ctx* ctx) {
+    std::vector<GemmTick> tabs(kRing);
+    for (int r = 0; r < kRing; ++r) {
+        GemmTick& T = tabs[r];
+        std::memset(&T, 0, sizeof(T));
+        T.n = RC_TICK_PROB; T.B = ctx->B;
+        int base = 0;
+        for (int q = 0; q < RC_TICK_PROB; ++q) {
+            const TickStage& ts = kTick[q];
+            const int fr = ((r - ts.stage) % kRing + kRing) % kRing;        // frame residue = ring slot
+            const FrameBuffers& fb = ctx->ring[fr];
+            NetDev n = ctx->net[ts.net];
+            float* x1 = (fr & 1) ? ctx->x1_alt[ts.net] : n.x1;
+            Stage st{ts.net, 0, nullptr, 256, Out{nullptr, 0, 0, false}};
+            switch (ts.net) {
+                case N4: st.x = fb.x4; st.y = Out{fb.x6, 256, 171, true}; break;
+                case N2: st.x = fb.x2; st.ldx = 128; st.y = Out{fb.x3, 256, 72, true}; break;
+                case N6: st.x = fb.x6; st.y = Out{fb.pc, 4, 0, false}; break;
+                case N3: st.x = fb.x3; st.y = Out{fb.vr, 4, 0, false}; break;
+                case N7: st.x = fb.x78; st.y = Out{fb.r6d, 144, 0, false}; break;
+                default: st.x = fb.x78; st.y = Out{fb.contact, 2, 0, false}; break;
+            }
+            GemmProblem p = ts.kind == 0 ? lin1_problem(ctx, st) : (ts.kind == 3 ? lin2_problem(ctx, st) : lstm_problem(ctx, st, ts.kind - 1));
+            if (ts.kind == 0) p.out = x1;                                     // relu(linear1) double-buffered by frame parity
+            if (ts.kind == 1) p.seg[0].base = x1;
+            p.flags = nullptr; p.flag_bit = 0;                                // every row steps every sub-net
+            p.alt_base = nullptr; p.sel_flags = nullptr; p.sel_bit = 0;
+            p.out_flags = nullptr; p.out_bit = 0;
+            p.open_step = 0;
+            p.step_off = 1 + (fr & 1);
+            p.wg_base = base;
+            base += round_up(p.n_tiles * p.m_tiles, 8);
+            T.p[q] = p;
+        }
+        T.total_wg = base;
+        ctx->tick_total_wg = base;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->tick_tables, tabs.data(), sizeof(GemmTick) * kRing, hipMemcpyHostToDevice));
+    ctx->tick_valid = true;
+    return RC_OK;
+}
+
+// One segment [t0, t1) of a rc_sequence call in sequence mode. io_at(t) gives the FrameIO of frame t.
+template <typename IoAt>
+int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
+    if (int rc = ensure_sequence_buffers(ctx)) return rc;
+    if (!ctx->tick_valid) if (int rc = build_tick_tables(ctx)) return rc;
+    const int B = ctx->B;
+    const rc_params_dev prm = dev_params(ctx->prm);
+    hipStream_t aux = ctx->aux_stream;
+    auto in_seg = [&](int f) { return f >= t0 && f < t1; };
+    // aux stream joins: everything enqueued so far on `st` (earlier frames, weight uploads) is visible to it
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));
+    HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
+    for (int k = t0; k < t1 + kStages - 1; ++k) {
+        const int e = (k - t0) & 3, ep = (k - t0 + 3) & 3;          // event slots of this tick / the previous tick
+        // ---- per-row kernels of tick k (aux stream): after the previous tick's GEMM launch
+        if (k > t0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
+        if (in_seg(k)) rc_launch_prep(ctx->ring[k % kRing], io_at(k), prm, B, 0, aux);
+        if (in_seg(k - 5)) rc_launch_fuse(ctx->ring[(k - 5) % kRing], io_at(k - 5), prm, B, aux);
+        if (in_seg(k - 10)) rc_launch_tail(ctx->ring[(k - 10) % kRing], io_at(k - 10), prm, ctx->body, B, 0, aux);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
+        // ---- GEMM stages of tick k (main stream): after the previous tick's per-row kernels
+        unsigned active = 0;
+        for (int q = 0; q < RC_TICK_PROB; ++q)
+            if (in_seg(k - kTick[q].stage)) active |= 1u << q;
+        if (k > t0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        if (active) {
+            hipEvent_t* tev = nullptr;
+            if (ctx->timing) {
+                if (ctx->ev_used == ctx->ev_pool.size()) {
+                    hipEvent_t a, b;
+                    HIP_TRY(ctx, hipEventCreate(&a));
+                    HIP_TRY(ctx, hipEventCreate(&b));
+                    ctx->ev_pool.emplace_back(a, b);
+                }
+                auto& ev = ctx->ev_pool[ctx->ev_used++];
+                HIP_TRY(ctx, hipEventRecord(ev.first, st));
+                tev = &ev.second;
+            }
+            rc_launch_gemm_tick(ctx->tick_tables + (k % kRing), ctx->tick_total_wg, active, t0 & 1, st);
+            if (tev) HIP_TRY(ctx, hipEventRecord(*tev, st));
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
+        ctx->stat_ticks += 1;
+    }
+    // the main stream continues after the last tail; every sub-net stepped (t1 - t0) times on every row
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(t1 + kStages - 2 - t0) & 3], 0));
+    int* steps6[6];
+    for (int i = 0; i < 6; ++i) steps6[i] = ctx->net[i].steps;
+    rc_launch_advance_steps(steps6, t1 - t0, B, st);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->stat_wave_frames += t1 - t0;
+    return RC_OK;
+}
+
+// Launch plan of a rc_sequence call from the regime codes (pure host logic, exposed as rc_plan_sequence for tests).
+void plan_sequence(const signed char* codes, int B, int T, const int* first_reach, const int* pend, bool first_frame,
+                   bool has_first_tran, bool use_imu_updater, bool use_vision_updater, int min_frames, unsigned char* mode) {
+    std::vector<unsigned char> fr(B), pd(B), ok(T);
+    for (int b = 0; b < B; ++b) { fr[b] = first_reach[b] != 0; pd[b] = pend[b] != 0; }
+    for (int t = 0; t < T; ++t) {
+        const signed char* c = codes + (size_t)t * B;
+        bool all_vis = true, reach = false, pend_in = false, need_tr = false;
+        const bool ff = t == 0 && first_frame;
+        for (int b = 0; b < B; ++b) {
+            const bool vis = c[b] >= 1 || ff;                                  // rnn4 steps on the camera keypoints (L149)
+            all_vis = all_vis && c[b] >= 1;
+            if (pd[b]) { pend_in = true; if (vis) need_tr = true; }
+            if (fr[b] && c[b] == 2 && use_imu_updater) { reach = true; fr[b] = 0; }      // L178-180
+            pd[b] = (c[b] == 0 && use_vision_updater) ? 1 : 0;                           // L264 (non-live)
+        }
+        ok[t] = all_vis && !reach && !pend_in && !(t == 0 && (first_frame || has_first_tran));
+        mode[t] = need_tr ? SEQ_STEPPED_TR : SEQ_STEPPED;
+    }
+    for (int t = 0; t < T;) {
+        if (!ok[t]) { ++t; continue; }
+        int e = t;
+        while (e < T && ok[e]) ++e;
+        if (e - t >= min_frames) for (int q = t; q < e; ++q) mode[q] = SEQ_WAVE;
+        t = e;
+    }
+}
+
 int check_ready(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
     if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "weights not finalized (rc_finalize_weights)");
@@ -467,6 +658,14 @@ int rc_destroy(rc_ctx* ctx) {
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (void* p : ctx->weight_allocs) (void)hipFree(p);
     if (ctx->eager_ev) (void)hipEventDestroy(ctx->eager_ev);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int i = 0; i < 8; ++i) {
+        if (ctx->ev_main[i]) (void)hipEventDestroy(ctx->ev_main[i]);
+        if (ctx->ev_aux[i]) (void)hipEventDestroy(ctx->ev_aux[i]);
+    }
+    if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
+    if (ctx->scan_codes_h) (void)hipHostFree(ctx->scan_codes_h);
+    if (ctx->scan_state_h) (void)hipHostFree(ctx->scan_state_h);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
@@ -529,6 +728,7 @@ int rc_finalize_weights(rc_ctx* ctx) {
     for (void* p : ctx->weight_allocs) (void)hipFree(p);
     ctx->weight_allocs.clear();
     ctx->have_weights = false;
+    ctx->tick_valid = false;             // the sequence-mode launch tables hold weight pointers
     ctx->alloc_weights = true;
     const int rc = finalize_weights_impl(ctx);
     ctx->alloc_weights = false;
@@ -636,12 +836,75 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     if (int rc = check_ready(ctx)) return rc;
     ctx->live_prev_known = false;
     if (T < 0 || !j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_sequence: bad argument");
-    for (int t = 0; t < T; ++t) {
-        FrameIO io{j2dc + (int64_t)t * 99, accc + (int64_t)t * 18, oric + (int64_t)t * 54, t == 0 ? first_tran : nullptr,
-                   pose_out + (int64_t)t * 216, tran_out + (int64_t)t * 3, rs_j2d, rs_acc, rs_ori, rs_pose, rs_tran};
-        if (int rc = step_impl(ctx, io, t == 0 ? flags : 0u, (hipStream_t)stream)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto io_at = [&](int t) {
+        return FrameIO{j2dc + (int64_t)t * 99, accc + (int64_t)t * 18, oric + (int64_t)t * 54, t == 0 ? first_tran : nullptr,
+                       pose_out + (int64_t)t * 216, tran_out + (int64_t)t * 3, rs_j2d, rs_acc, rs_ori, rs_pose, rs_tran};
+    };
+    // Launch plan: with sequence mode on (and not live: the landmark refresh counter is not modelled on the host) one
+    // pre-pass classifies every (frame, row), the host reads the codes back ONCE per call (the only synchronisation of
+    // `stream` in this call) and picks, per frame, the wavefront engine, or the frame-stepped launches with or without
+    // the three transition launches.
+    std::vector<unsigned char> mode((size_t)(T > 0 ? T : 0), (unsigned char)SEQ_STEPPED_TR);
+    const int B = ctx->B;
+    if (ctx->seq_mode && !ctx->prm.live && T >= 2) {
+        const size_t need = (size_t)B * T;
+        if (need > ctx->scan_cap) {
+            if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
+            if (ctx->scan_codes_h) (void)hipHostFree(ctx->scan_codes_h);
+            ctx->scan_codes_d = nullptr; ctx->scan_codes_h = nullptr; ctx->scan_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->scan_codes_d, need));
+            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->scan_codes_h, need, hipHostMallocDefault));
+            ctx->scan_cap = need;
+        }
+        if (!ctx->scan_state_h) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->scan_state_h, (size_t)B * 2 * sizeof(int), hipHostMallocDefault));
+        rc_launch_scan_conf(j2dc, rs_j2d, B, T, ctx->prm.conf_lo, ctx->prm.conf_hi, ctx->scan_codes_d, st);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->scan_codes_h, ctx->scan_codes_d, need, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->scan_state_h, ctx->fb.first_reach, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+        std::vector<unsigned char> pend_b(B);
+        HIP_TRY(ctx, hipMemcpyAsync(pend_b.data(), ctx->fb.pend, (size_t)B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) ctx->scan_state_h[B + b] = pend_b[b];
+        plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h, ctx->scan_state_h + B, (flags & RC_FLAG_FIRST_FRAME) != 0,
+                      first_tran != nullptr, ctx->prm.use_imu_updater != 0, ctx->prm.use_vision_updater != 0, ctx->seq_min_frames,
+                      mode.data());
     }
-    return mark_eager(ctx, (hipStream_t)stream);
+    for (int t = 0; t < T;) {
+        if (mode[t] == SEQ_WAVE) {
+            int e = t;
+            while (e < T && mode[e] == SEQ_WAVE) ++e;
+            if (int rc = run_wave_segment(ctx, t, e, io_at, st)) return rc;
+            t = e;
+        } else {
+            if (int rc = step_impl(ctx, io_at(t), t == 0 ? flags : 0u, st, mode[t] == SEQ_STEPPED_TR)) return rc;
+            ctx->stat_stepped_frames += 1;
+            ++t;
+        }
+    }
+    return mark_eager(ctx, st);
+}
+
+int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames) {
+    if (!ctx || mode < 0 || mode > 1 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1, min_frames >= 1") : RC_ERR_INVALID;
+    ctx->seq_mode = mode;
+    ctx->seq_min_frames = min_frames;
+    return RC_OK;
+}
+
+int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_frames, int64_t* ticks) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (wave_frames) *wave_frames = ctx->stat_wave_frames;
+    if (stepped_frames) *stepped_frames = ctx->stat_stepped_frames;
+    if (ticks) *ticks = ctx->stat_ticks;
+    return RC_OK;
+}
+
+int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* first_reach, const int32_t* pend, uint32_t flags,
+                     int32_t has_first_tran, int32_t use_imu_updater, int32_t use_vision_updater, int32_t min_frames, uint8_t* mode_out) {
+    if (!codes || !first_reach || !pend || !mode_out || B < 1 || T < 0 || min_frames < 1) return RC_ERR_INVALID;
+    plan_sequence(reinterpret_cast<const signed char*>(codes), B, T, first_reach, pend, (flags & RC_FLAG_FIRST_FRAME) != 0,
+                  has_first_tran != 0, use_imu_updater != 0, use_vision_updater != 0, min_frames, mode_out);
+    return RC_OK;
 }
 
 int rc_live_end(rc_ctx* ctx) {

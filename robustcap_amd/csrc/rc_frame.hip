@@ -585,7 +585,42 @@ __global__ void rc_flush_flags_kernel(FrameBuffers fb, int B) {
     fb.pend[row] = 0;
 }
 
+// rc_sequence pre-pass: confidence regime of every (frame, row) -- the SAME arithmetic as rc_prep_kernel (float butterfly
+// mean, double compares) so that the host's launch plan and the device's row flags can never disagree.
+// codes[t * B + row] = 0 (c <= lo), 1 (lo < c < hi), 2 (c >= hi). Four waves per workgroup, one (row, frame) each.
+__global__ __launch_bounds__(256) void rc_scan_conf_kernel(const float* j2d, long long row_stride, int B, int T, double conf_lo,
+                                                          double conf_hi, signed char* codes) {
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= (long long)B * T) return;
+    const int t = (int)(item / B), row = (int)(item % B);
+    const float* kp = j2d + row * row_stride + (long long)t * 99;
+    const float cf = lane < 33 ? kp[3 * lane + 2] : 0.f;
+    const float c = wave_sum(cf) / 33.0f;
+    const double c64 = (double)c;
+    if (lane == 0) codes[item] = c64 >= conf_hi ? 2 : (c64 > conf_lo ? 1 : 0);
+}
+
+// end of a sequence-mode segment: every sub-net stepped n_frames times on every row (the counters stood still meanwhile)
+struct StepPtrs { int* p[6]; };
+__global__ void rc_advance_steps_kernel(StepPtrs sp, int n_frames, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * B) return;
+    sp.p[i / B][i % B] += n_frames;
+}
+
 // ================================================================================================ launchers
+void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes,
+                         hipStream_t st) {
+    const long long items = (long long)B * T;
+    if (items <= 0) return;
+    hipLaunchKernelGGL(rc_scan_conf_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, j2d, row_stride, B, T, conf_lo, conf_hi, codes);
+}
+void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t st) {
+    StepPtrs sp;
+    for (int i = 0; i < 6; ++i) sp.p[i] = steps6[i];
+    hipLaunchKernelGGL(rc_advance_steps_kernel, dim3((6 * B + 255) / 256), dim3(256), 0, st, sp, n_frames, B);
+}
 void rc_launch_flush_flags(const FrameBuffers& fb, int B, hipStream_t st) {
     hipLaunchKernelGGL(rc_flush_flags_kernel, dim3((B + 255) / 256), dim3(256), 0, st, fb, B);
 }

@@ -96,7 +96,8 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
 template <int MR, int NC, int D, bool PIPE>
-__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
+__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem,
+                                          const int step_par = 0) {   // step_par: parity of the segment's first frame (ticks)
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
 #ifdef RC_TRACE_TILES
     unsigned long long trace_t[4] = {0, 0, 0, 0};
@@ -157,7 +158,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const int row = s_rows[16 * r + i];
-        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] : 0;
+        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] + P.step_off + step_par : 0;
         const float* pp[2];
 #pragma unroll
         for (int sgi = 0; sgi < 2; ++sgi) {
@@ -267,7 +268,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
                 gsum[gq] = v + P.bias[n_tile * NT + col];
             }
             const int r2 = s_rows[rr];
-            const int dst = P.steps[r2] & 1;
+            const int dst = (P.steps[r2] + P.step_off + step_par) & 1;
             const long long ci = (long long)r2 * P.H + unit;
             const float ig = sigmoidf_(gsum[0]), fg = sigmoidf_(gsum[1]);
             const float gg = tanhf(gsum[2]), og = sigmoidf_(gsum[3]);
@@ -346,6 +347,41 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
         case 1 * 16 + 1: gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
         default: gemm_tile<2, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
     }
+}
+
+// Sequence-mode tick: the same tiles, problems read from a device-resident table (up to RC_TICK_PROB stages of the frame
+// pipeline, each on its own frame); stages without a frame at the ends of a segment are masked out.
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_tick_kernel(const GemmTick* __restrict__ T, const unsigned active,
+                                                                          const int step_par) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+    int pi = 0;
+    const int n = T->n;
+    for (int q = 1; q < n; ++q)
+        if ((int)blockIdx.x >= T->p[q].wg_base) pi = q;
+    if (!((active >> pi) & 1u)) return;
+    const GemmProblem& P = T->p[pi];
+    const int local = blockIdx.x - P.wg_base;
+    int m_tile, n_tile;
+    if ((P.n_tiles & 7) == 0) {   // XCD-aware: the row tiles of one weight slice share block-id % 8
+        const int xcd = local & 7, s = local >> 3;
+        m_tile = s % P.m_tiles;
+        n_tile = (s / P.m_tiles) * 8 + xcd;
+    } else {
+        m_tile = local % P.m_tiles;
+        n_tile = local / P.m_tiles;
+    }
+    if (n_tile >= P.n_tiles) return;
+    switch (P.mr * 16 + P.nc) {
+        case 2 * 16 + 10: gemm_tile<2, 10, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
+        case 2 * 16 + 8: gemm_tile<2, 8, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
+        case 1 * 16 + 2: gemm_tile<1, 2, 8, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
+        case 1 * 16 + 1: gemm_tile<1, 1, 8, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
+        default: gemm_tile<2, 4, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
+    }
+}
+
+void rc_launch_gemm_tick(const GemmTick* table_dev, int total_wg, unsigned active_mask, int step_par, hipStream_t s) {
+    hipLaunchKernelGGL(rc_gemm_tick_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, table_dev, active_mask, step_par);
 }
 
 // Launches whose problems all use 16-row tiles (batch <= 16: live mode, transition rows) are weight-streaming, not

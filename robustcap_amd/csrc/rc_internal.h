@@ -74,13 +74,28 @@ struct GemmProblem {
     int nc;                 // 16-column blocks per tile
     int mr;                 // 16-row blocks per tile (2 or 4); (mr, nc) must be one of the instantiated shapes
     int trace_base;         // first record slot of this launch (read by -DRC_TRACE_TILES builds only)
-    int pad_;
+    int step_off;           // added to steps[row] wherever the step parity is formed. Frame-stepped launches: 0 (linear1
+                            // has already incremented the counter). Sequence-mode ticks: 1 + (frame - first frame of the
+                            // segment), with open_step = 0: the counters stand still while stages of several frames are in
+                            // flight and are advanced once, after the segment.
 };
 
 struct GemmLaunch {
     int n;                  // problems
     int B;                  // rows in the batch
     GemmProblem p[RC_MAX_PROB];
+};
+
+// Sequence mode (rc_sequence on all-visible stretches): ONE launch per tick carries every GEMM stage of the frame pipeline,
+// each on a different frame (stage s of tick k works on frame k - s). The table lives in device memory (24 problems do not
+// fit the kernel-argument segment comfortably); `active` masks the stages that have no frame yet / any more at the ends.
+#define RC_TICK_PROB 24
+struct GemmTick {
+    int n;
+    int B;
+    int total_wg;
+    int pad_;
+    GemmProblem p[RC_TICK_PROB];
 };
 
 // ---- per-frame small kernels -------------------------------------------------------------------------------
@@ -129,6 +144,9 @@ struct rc_params_dev {
 };
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
+void rc_launch_gemm_tick(const GemmTick* table_dev, int total_wg, unsigned active_mask, int step_par, hipStream_t s);
+void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);
+void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t s);
 bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_gemm_small_kernel (16-row tiles only)
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);

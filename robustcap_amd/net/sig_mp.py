@@ -223,6 +223,17 @@ class Net:
         self.__dict__["_keep"] = (j2dc, accc, oric, ft)
         return pose, tran
 
+    def set_sequence_mode(self, enabled=True, min_frames=16):
+        """Scheduling of ``forward_sequence`` (rc_set_sequence_mode): with ``enabled`` (the default) all-visible stretches
+        of at least ``min_frames`` frames run on the wavefront engine (bitwise the same outputs, one GEMM launch per tick)."""
+        _lib.check(self._ctx, self._lib.rc_set_sequence_mode(self._ctx, int(bool(enabled)), int(min_frames)), "rc_set_sequence_mode")
+
+    def sequence_stats(self):
+        """(frames run by the wavefront engine, frames run frame-stepped, ticks launched) since construction."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self._ctx, self._lib.rc_get_sequence_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "rc_get_sequence_stats")
+        return a.value, b.value, c.value
+
     # ------------------------------------------------------------------------------------------- introspection
     def lstm_step(self, net, x, rows=None):
         """One step f(i, x) of a sub-net on the context's state (net/sig_mp.py:126-129); for component tests."""

@@ -1,0 +1,128 @@
+"""Sequence mode of rc_sequence (wavefront engine + launch planner) on the GPU.
+
+The engine runs the SAME tiles on the same operands as the frame-stepped launches, so its outputs and final states must be
+bitwise equal to them; against the reference the bar is the usual 1e-4 m / 0.1 degrees on the captured all-visible
+sequences (tests/golden/seq_allvis_*.npz) and on seq_long_mixed, whose occluded stretches force the planner to alternate
+between the two engines."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sig_mp_oracle as O
+from robustcap_amd import synth
+
+pytestmark = pytest.mark.gpu
+t = torch.from_numpy
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _net(assets, B, seq=True, min_frames=16):
+    from robustcap_amd.net.sig_mp import Net
+    n = Net(body=assets["body"], batch=B)
+    n.load_state_dict(assets["state_dict"])
+    n.set_sequence_mode(seq, min_frames)
+    return n
+
+
+def _fixture_run(assets, name, seq, min_frames=16, chunks=None):
+    s = np.load(os.path.join(GOLD, name))
+    net = _net(assets, 1, seq, min_frames)
+    net.use_flat_floor = bool(s["use_flat_floor"])
+    net.gravityc = t(s["gravityc"])
+    ft = t(s["first_tran"]).view(1, 3) if s["first_tran"].size else None
+    T = s["pose"].shape[0]
+    edges = [0, T] if chunks is None else chunks
+    P, Tr = [], []
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        p, tr = net.forward_sequence(t(s["j2dc"][None, lo:hi]), t(s["accc"][None, lo:hi]), t(s["oric"][None, lo:hi]),
+                                     first_tran=ft if lo == 0 else None, first_frame=bool(s["first_frame"]) and lo == 0)
+        P.append(p[0]), Tr.append(tr[0])
+    return s, net, torch.cat(P), torch.cat(Tr)
+
+
+def _joints(body, pose, tran):
+    return O.OracleBody(body).forward_kinematics(pose.cpu().float(), tran.cpu().float())[1]
+
+
+@pytest.mark.parametrize("name", ["seq_allvis_long.npz", "seq_allvis_ff.npz", "seq_long_mixed.npz"])
+def test_wavefront_vs_reference_and_vs_frame_stepped(name, synth_assets):
+    s, wnet, wp, wt = _fixture_run(synth_assets, name, True)
+    _, snet, sp, st = _fixture_run(synth_assets, name, False)
+    wave, stepped, ticks = wnet.sequence_stats()
+    T = s["pose"].shape[0]
+    assert wave + stepped == T and snet.sequence_stats()[0] == 0
+    if "allvis" in name:
+        assert wave >= T - 2 and ticks >= wave + 10                          # all but the sequence start ran skewed
+    else:
+        assert 0 < wave < T and stepped > 100                                # long_mixed alternates between the engines
+    assert torch.equal(wp, sp) and torch.equal(wt, st)                       # same tiles, same arithmetic
+    rp, rt = t(s["pose"]), t(s["tran"])
+    assert float((wt.cpu() - rt).abs().max()) <= 1e-4
+    assert float(O.rotation_angle_deg(wp.cpu(), rp).max()) <= 0.1
+    assert float((_joints(synth_assets["body"], wp, wt) - _joints(synth_assets["body"], rp, rt)).abs().max()) <= 1e-4
+    for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8"):
+        (hw, cw), (hs, cs) = wnet.get_state(n), snet.get_state(n)
+        assert torch.equal(hw, hs) and torch.equal(cw, cs), n                # incl. the parity the counters end on
+        assert float((hw[:, 0] - t(s["h_" + n])).abs().max()) <= 1e-4, n
+    assert wnet.get_trace()[0].tolist() == snet.get_trace()[0].tolist()
+
+
+def test_chunked_calls_and_short_segments(synth_assets):
+    """Segments of every length (odd and even starts -> both step parities), split over several rc_sequence calls."""
+    s, net, p, tr = _fixture_run(synth_assets, "seq_allvis_ff.npz", True, min_frames=3, chunks=[0, 1, 8, 9, 30, 33, 34, 77, 160])
+    _, ref, sp, st = _fixture_run(synth_assets, "seq_allvis_ff.npz", False)
+    assert torch.equal(p, sp) and torch.equal(tr, st)
+    wave, stepped, _ = net.sequence_stats()
+    assert wave > 120 and stepped >= 3                                       # T=1 chunks and the start frame stay stepped
+    for n in ("rnn2", "rnn4", "rnn8"):
+        assert torch.equal(net.get_state(n)[0], ref.get_state(n)[0])
+
+
+@pytest.mark.parametrize("B,conf", [(37, "high"), (256, "high"), (64, "mixed")])
+def test_batched_wavefront_equals_frame_stepped(B, conf, synth_assets):
+    """Ragged and full batches; 'mixed' leaves only a few all-visible stretches (the planner must find exactly those)."""
+    import bench
+    T = 96
+    m = bench.make_inputs(synth_assets["body"], B, T, conf, seed=5)
+    outs = []
+    for seq in (True, False):
+        net = _net(synth_assets, B, seq)
+        net.gravityc = t(m["gravityc"])
+        a = net.forward_sequence(t(m["j2dc"][:, :40]), t(m["accc"][:, :40]), t(m["oric"][:, :40]), first_tran=t(m["first_tran"]))
+        b = net.forward_sequence(t(m["j2dc"][:, 40:]), t(m["accc"][:, 40:]), t(m["oric"][:, 40:]))
+        torch.cuda.synchronize()
+        outs.append((torch.cat([a[0], b[0]], 1), torch.cat([a[1], b[1]], 1), net.sequence_stats(), net.get_state("rnn6")))
+    (wp, wt, wstat, wst), (sp, st, sstat, sst) = outs
+    assert torch.equal(wp, sp) and torch.equal(wt, st)
+    assert torch.equal(wst[0], sst[0]) and torch.equal(wst[1], sst[1])
+    if conf == "high":
+        assert wstat[0] == T - 1 and wstat[1] == 1                           # everything but the first_tran frame
+    else:
+        vis_all = (m["conf"] > 0.7).all(0)
+        assert wstat[0] <= int(vis_all.sum()) and wstat[0] + wstat[1] == T
+    assert sstat[0] == 0 and sstat[1] == T
+
+
+def test_sequence_mode_respects_switches_and_live(synth_assets):
+    """use_reproj_opt / no updaters run through the skewed tail as well; live contexts never use the planner."""
+    import bench
+    B, T = 8, 64
+    m = bench.make_inputs(synth_assets["body"], B, T, "high", seed=9)
+    for kw in ({"use_reproj_opt": True}, {"use_imu_updater": False, "use_vision_updater": False}, {"use_flat_floor": False}):
+        res = []
+        for seq in (True, False):
+            net = _net(synth_assets, B, seq)
+            for k, v in kw.items():
+                setattr(net, k, v)
+            net.gravityc = t(m["gravityc"])
+            res.append(net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True) + (net.sequence_stats(),))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), kw
+        assert res[0][2][0] >= T - 1 - (0 if kw.get("use_imu_updater", True) else 0) - 1
+    net = _net(synth_assets, B, True)
+    net.live = True
+    net.gravityc = t(m["gravityc"])
+    net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    assert net.sequence_stats()[0] == 0
