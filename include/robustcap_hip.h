@@ -103,6 +103,19 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                 const float* oric, int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out,
                 int64_t rs_pose, float* tran_out, int64_t rs_tran, void* stream);
 
+/* Arithmetic of the GEMM products of EVERY launch of a context (linear layers, LSTM gate GEMMs, init_net):
+ *   mode 0: v_mfma_f32_16x16x4_f32 -- fp32 operands, bitwise an fma chain per output element;
+ *   mode 1: split-bf16 products on v_mfma_f32_16x16x32_bf16 -- every fp32 operand is the exact sum of three bf16 numbers
+ *           (weights split once at rc_finalize_weights, activations on the fly) and every product the fp32-accumulated sum
+ *           of the partial products down to 2^-16 of it (what is dropped is below 2^-23 of a product, i.e. below the
+ *           rounding of the running fp32 sum); operands, accumulators, gates and state stay fp32. Same accuracy class as
+ *           mode 0 (parity with the reference: tests), 2.7x fewer MFMA cycles per product.
+ * Default: mode 1 for contexts of batch >= 32 (MFMA-bound), mode 0 below (weight-streaming-bound: 6 B instead of 4 B per
+ * weight would slow them). Within one mode a row's result does not depend on the batch, the tile shape or the engine
+ * (bitwise); between the two modes results differ by fp32 rounding noise. rc_get_gemm_mode returns the mode. */
+int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode);
+int rc_get_gemm_mode(const rc_ctx* ctx);
+
 /* Sequence mode of rc_sequence (on by default). With mode = 1 every rc_sequence call of T >= 2 frames first classifies
  * each (frame, row) on the device (the arithmetic of the per-frame prep kernel), reads the codes back -- ONE
  * synchronisation of `stream` per call -- and plans the launches on the host:
@@ -269,6 +282,19 @@ int rc_lbfgs_minimize(rc_objective_fn objective, void* user, int64_t n, double* 
 int rc_camera_inputs(const float* kp_pix, const float* imu_acc_w, const float* imu_ori_w, const float* K_host,
                      const float* Tcw_host, float* j2dc, float* accc, float* oric, float* gravity_out_host, int64_t n,
                      void* stream);
+
+/* The same preparation for ALL rows of an evaluation in one launch (evaluate.py:32-51,66-73 loops sequences, cameras and
+ * frames on the host). Row r = one (sequence, camera): kp_norm[n_rows,Tmax,33,3] = (u / image_w, v / image_h, conf) as the
+ * preprocessed dataset stores them (evaluate.py:43-44 multiplies the image size back), imu_acc_w[n_seq,Tmax,6,3] and
+ * imu_ori_w[n_seq,Tmax,6,3,3] per SEQUENCE, seq_of_row[n_rows] (which sequence a row belongs to), len[n_rows] (valid frames of
+ * the row; later frames are written as padding: zero keypoints and accelerations, identity orientations) -- all DEVICE;
+ * K[n_rows,3,3], Tcw[n_rows,4,4] HOST. Outputs j2dc[n_rows,Tmax,33,3], accc[n_rows,Tmax,6,3], oric[n_rows,Tmax,6,3,3] DEVICE,
+ * gravity_out[n_rows,3] HOST. cam_scratch: caller-owned DEVICE buffer of n_rows * 72 bytes (camera constants).
+ * Synchronises `stream` once (upload of the camera constants). */
+int rc_camera_inputs_rows(const float* kp_norm, const float* imu_acc_w, const float* imu_ori_w, const int32_t* seq_of_row,
+                          const int32_t* len, const float* K_host, const float* Tcw_host, float image_w, float image_h,
+                          int32_t n_rows, int32_t Tmax, float* j2dc, float* accc, float* oric, float* gravity_out_host,
+                          void* cam_scratch, void* stream);
 
 /* ---- state access (tests / checkpointing of a running sequence) ------------------------------------------ */
 /* Copy the (h, c) state of sub-net `net` to HOST buffers h[2,batch,H], c[2,batch,H]. Synchronises `stream`. */

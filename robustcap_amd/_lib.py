@@ -50,6 +50,8 @@ SIGNATURES = {
     "rc_reset": (_I32, [_P, _P, _P]),
     "rc_step": (_I32, [_P, _P, _P, _P, _P, _U32, _P, _P, _P]),
     "rc_sequence": (_I32, [_P, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _U32, _P, _I64, _P, _I64, _P]),
+    "rc_set_gemm_mode": (_I32, [_P, _I32]),
+    "rc_get_gemm_mode": (_I32, [_P]),
     "rc_set_sequence_mode": (_I32, [_P, _I32, _I32]),
     "rc_get_sequence_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "rc_plan_sequence": (_I32, [_P, _I32, _I32, _P, _P, _U32, _I32, _I32, _I32, _I32, _P]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "rc_lbfgs_minimize": (_I32, [OBJECTIVE_FN, _P, _I64, C.POINTER(C.c_double), C.c_double, _I32, _I32, _I32, C.c_double,
                                  C.c_double, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(C.c_double), _I64]),
     "rc_camera_inputs": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "rc_camera_inputs_rows": (_I32, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "rc_get_state": (_I32, [_P, C.c_char_p, _P, _P, _P]),
     "rc_get_trace": (_I32, [_P, _P, _P]),
     "rc_gemm_timing": (_I32, [_P, _I32]),

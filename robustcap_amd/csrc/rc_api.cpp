@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -38,12 +39,14 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Dense {       // packed dense layer
     float* W = nullptr; float* b = nullptr;
+    void* Ws = nullptr;                  // split-bf16 planes of W
     int K = 0, N = 0, Kp = 0, Np = 0;
     int mr = 2, nc = 4;                  // tile shape: 16*mr rows x 16*nc columns
 };
 struct NetDev {
     Dense lin1, lin2;
     float* Wl[2] = {nullptr, nullptr};   // LSTM layers, K' = 2H, N' = 4H (tile-interleaved gates)
+    void* Wls[2] = {nullptr, nullptr};   // their split-bf16 planes
     float* bl[2] = {nullptr, nullptr};
     float* h = nullptr;                  // [layer][parity][B][H]
     float* c = nullptr;                  // [layer][B][H]
@@ -101,14 +104,17 @@ struct rc_ctx {
     double timed_ms = 0.0;
     long long timed_launches = 0;
     // sequence mode (rc_sequence on all-visible stretches): skewed stage pipeline, one gate-GEMM launch per tick
+    bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
     int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (rc_set_sequence_mode)
     int seq_min_frames = 16;             // shortest stretch worth filling the 11-stage pipeline for
     bool ring_ready = false;
     FrameBuffers ring[16];               // slot 0 = fb; slots 1..15 allocated on first use
     float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
-    GemmTick* tick_tables = nullptr;     // [16] device-resident launch tables, one per (tick mod 16)
-    int tick_total_wg = 0;
+    std::vector<GemmProblem> tick_prob;  // [16][RC_TICK_PROB] GEMM problems per (tick mod 16), assembled into launches per tick
+    int tile6[2] = {0, 0}, tile378[2] = {0, 0}, tile2[2] = {0, 0}, tile4[2] = {0, 0};   // LSTM tile shapes of full-batch stages (0 = pick_tile)
     bool tick_valid = false;
+    bool seq_lin1_main = true;
+    bool seq_two_streams = true;         // tuning: per-row kernels + linear2 on the second stream (else everything on the caller's)          // tuning: linear1 problems ride in the last wide launch instead of the second stream
     hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
     hipEvent_t ev_main[8] = {}, ev_aux[8] = {};
     signed char* scan_codes_d = nullptr; // [cap] regime code per (frame, row)
@@ -169,6 +175,52 @@ std::vector<float> pack_weights(int Np, int Kp, F getW) {
     return out;
 }
 
+// The same matrix as three bf16 planes for the split-bf16 products (rc_gemm.hip: mma_kblock). fp32 w = hi + mid + lo
+// exactly (truncation split, 8 + 8 + 8 significant bits). Layout [cb][kb][plane][lane][8]: for 16-column block cb and
+// 32-wide k-block kb, lane l = kq*16 + j holds, of column cb*16 + j, the eight k = 32 kb + {4 kq .. 4 kq + 3} and
+// 32 kb + 16 + {4 kq .. 4 kq + 3} -- the k a lane of the A operand finds in its two rc_pk float4 of that k-block.
+template <typename F>
+std::vector<uint16_t> pack_weights_split(int Np, int Kp, F getW) {
+    std::vector<uint16_t> out((size_t)Np * Kp * 3);
+    const int Qs = Kp / 32;
+    for (int cb = 0; cb < Np / 16; ++cb)
+        for (int kb = 0; kb < Qs; ++kb)
+            for (int l = 0; l < 64; ++l) {
+                const int kq = l >> 4, j = l & 15;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 32 * kb + (e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4));
+                    const float w = getW(cb * 16 + j, k);
+                    uint32_t u;
+                    std::memcpy(&u, &w, 4);
+                    const uint32_t uh = u & 0xffff0000u;
+                    float fh;
+                    std::memcpy(&fh, &uh, 4);
+                    const float r1 = w - fh;
+                    uint32_t u1;
+                    std::memcpy(&u1, &r1, 4);
+                    const uint32_t um = u1 & 0xffff0000u;
+                    float fm;
+                    std::memcpy(&fm, &um, 4);
+                    const float r2 = r1 - fm;
+                    uint32_t u2;
+                    std::memcpy(&u2, &r2, 4);
+                    const size_t base = (((size_t)cb * Qs + kb) * 3) * 512 + (size_t)l * 8 + e;
+                    out[base] = (uint16_t)(uh >> 16);
+                    out[base + 512] = (uint16_t)(um >> 16);
+                    out[base + 1024] = (uint16_t)(u2 >> 16);
+                }
+            }
+    return out;
+}
+
+int upload16(rc_ctx* ctx, void** dst, const std::vector<uint16_t>& v) {
+    uint16_t* q = nullptr;
+    if (int rc = dev_alloc(ctx, &q, v.size(), false)) return rc;
+    HIP_TRY(ctx, hipMemcpy(q, v.data(), v.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *dst = q;
+    return RC_OK;
+}
+
 int upload(rc_ctx* ctx, float** dst, const std::vector<float>& v) {
     if (int rc = dev_alloc(ctx, dst, v.size(), false)) return rc;
     HIP_TRY(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -183,6 +235,7 @@ int make_dense(rc_ctx* ctx, Dense& d, const std::vector<float>& W, const std::ve
     std::vector<float> bp(d.Np, 0.0f);
     for (int n = 0; n < N; ++n) bp[n] = b[n];
     if (int rc = upload(ctx, &d.W, pack_weights(d.Np, d.Kp, get))) return rc;
+    if (int rc = upload16(ctx, &d.Ws, pack_weights_split(d.Np, d.Kp, get))) return rc;
     return upload(ctx, &d.b, bp);
 }
 
@@ -212,7 +265,7 @@ GemmProblem dense_problem(const rc_ctx* ctx, const Dense& d, GemmSeg a, Out out,
     a.K = d.Kp;
     p.seg[0] = a;
     p.seg[1] = seg(a.base, a.ld, 0);
-    p.W = d.W; p.bias = d.b; p.out = out.p; p.ldo = out.ld; p.N = d.N; p.out_col0 = out.col0; p.out_packed = out.packed ? 1 : 0;
+    p.W = d.W; p.Ws = d.Ws; p.bias = d.b; p.out = out.p; p.ldo = out.ld; p.N = d.N; p.out_col0 = out.col0; p.out_packed = out.packed ? 1 : 0;
     p.steps = steps; p.flags = flags; p.flag_bit = flag_bit;
     p.epi = relu ? RC_EPI_RELU : RC_EPI_DENSE;
     p.open_step = open_step ? 1 : 0;
@@ -237,6 +290,17 @@ struct Stage {                 // which rows of which net, reading which (rc_pk)
 
 // LSTM tile shape (16*mr rows x 4*nc units) for a stage expected to touch `rows` rows: wide tiles when the row tiles
 // alone fill the chip, narrow ones (more column tiles, each streaming a slice of the weights) when few rows are active.
+// "4x8"-style tuning knob from the environment (A/B runs of tile shapes without a rebuild); false if unset / malformed
+bool tile_env(const char* name, int* mr, int* nc) {
+    const char* v = std::getenv(name);
+    int a = 0, b = 0;
+    if (!v || std::sscanf(v, "%dx%d", &a, &b) != 2) return false;
+    const int code = a * 16 + b;
+    for (int ok : {2 * 16 + 4, 4 * 16 + 4, 8 * 16 + 4, 2 * 16 + 8, 4 * 16 + 8, 2 * 16 + 10, 4 * 16 + 5})
+        if (code == ok) { *mr = a; *nc = b; return true; }
+    return false;
+}
+
 void pick_tile(int H, int rows, int* mr, int* nc) {
     if (rows >= 128) { *mr = 2; *nc = H == 1280 ? RC_NC1280 : (H == 1024 ? 8 : 4); return; }
     if (rows > 16) { *mr = 2; *nc = rows >= 64 ? 4 : 2; if (*nc == 2) { *mr = 1; } return; }
@@ -261,12 +325,22 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     if (layer == 0) p.seg[0] = seg(n.x1, n.H, n.H);
     else p.seg[0] = seg(n.h, n.H, n.H, RC_PAR_DST, BH);                     // h of layer 0, just written
     p.seg[1] = seg(n.h + layer * 2 * BH, n.H, n.H, RC_PAR_SRC, BH);         // own h, previous step
-    p.W = n.Wl[layer]; p.bias = n.bl[layer];
+    p.W = n.Wl[layer]; p.Ws = n.Wls[layer]; p.bias = n.bl[layer];
     p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = s.flags ? s.flags : c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
     int mr, nc;
     pick_tile(n.H, s.rows_hint < 0 ? c->B : s.rows_hint, &mr, &nc);
+    if (s.rows_hint < 0 && c->B >= 128) {
+        // Second stage of a frame {rnn6, rnn3, rnn7, rnn8}: 64-row tiles. 128 CUs run the 128 rnn6 tiles (64 x 128) while
+        // the other 128 run the 3 x 128 tiles (64 x 64) of the H = 512 nets in three rounds of a third of that length each,
+        // instead of one round of 32 x 128 tiles followed by three rounds of 32 x 64 tiles: half as many tile prologues /
+        // reductions / epilogues, fewer operand bytes per MFMA, and the launch still ends level.
+        if (s.net == N6 && c->tile6[0]) { mr = c->tile6[0]; nc = c->tile6[1]; }
+        if ((s.net == N3 || s.net == N7 || s.net == N8) && c->tile378[0]) { mr = c->tile378[0]; nc = c->tile378[1]; }
+        if (s.net == N2 && c->tile2[0]) { mr = c->tile2[0]; nc = c->tile2[1]; }
+        if (s.net == N4 && c->tile4[0]) { mr = c->tile4[0]; nc = c->tile4[1]; }
+    }
     const int rows = s.rows_hint < 0 ? c->B : (s.rows_hint < c->B ? s.rows_hint : c->B);
     p.n_tiles = n.H / (4 * nc); p.m_tiles = (rows + 16 * mr - 1) / (16 * mr); p.Kp = 2 * n.H; p.nc = nc; p.mr = mr;
     return p;
@@ -284,6 +358,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     if (ps.empty()) return RC_OK;
     GemmLaunch L{};
     L.B = ctx->B;
+    L.split = ctx->gemm_split ? 1 : 0;
     // XCD-aligned problems first so that (block id % 8) is the XCD for them
     std::vector<GemmProblem> ordered;
     for (auto& p : ps) if ((p.n_tiles & 7) == 0) ordered.push_back(p);
@@ -402,20 +477,32 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
 //   0 prep | 1 linear1{rnn2,rnn4} | 2,3 LSTM l0,l1 {rnn2,rnn4} | 4 linear2{rnn2,rnn4} | 5 fuse |
 //   6 linear1{rnn6,rnn3,rnn7,rnn8} | 7,8 LSTM l0,l1 | 9 linear2 | 10 tail
 // only depend on the previous stage of the SAME frame and on their own state of the PREVIOUS frame, so tick k runs
-// stage s on frame k - s for all s at once: ONE gate-GEMM launch per tick carries all 24 GEMM problems (3,000+ tiles:
-// no launch boundary, no under-filled launch inside a frame), while the three per-row kernels run beside it on a second
-// stream. Inter-stage buffers are rings of 16 frames; the step counters stand still during a segment (parity comes from
-// step_off) and are advanced once at its end. Same tiles, same arithmetic: outputs are bitwise those of the
-// frame-stepped path.
+// stage s on frame k - s for all s at once. What the skew buys is the freedom to group the 12 LSTM layer-steps of a tick by
+// TILE DURATION instead of by data dependence: four launches on the caller's stream,
+//   {rnn4 l0, l1}   {rnn6 l0, l1}   {rnn2 l0, l1, rnn3 l0, l1}   {rnn7 l0, l1, rnn8 l0, l1},
+// each a whole number of rounds of equal tiles at batch 256 (the frame-stepped stages mix 58 us and 14 us tiles and end on
+// a partly filled round), and -- every row being active -- 64-row tiles for the H = 512 nets (half as many tiles, so half
+// the per-tile prologue / reduction / epilogue time, which is 20 % of a 32 x 64 tile). The weight-streaming launches
+// (linear1, linear2: 16-row tiles on the small-tile kernel, 4 workgroups per CU) and the three per-row kernels run beside them
+// on a context-owned second stream; the two streams hand over once per tick. Inter-stage buffers are rings of 16 frames;
+// the step counters stand still during a segment (parity comes from step_off) and are advanced once at its end.
+// Every output element is the same chain of fp32 operations as in the frame-stepped launches (the K split and the
+// accumulation order do not depend on the tile shape): outputs and states are bitwise equal.
 enum { SEQ_STEPPED_TR = 0, SEQ_STEPPED = 1, SEQ_WAVE = 2 };
 const int kRing = 16, kStages = 11;
 
-struct TickStage { int kind; int net; int stage; };     // kind: 0 linear1, 1 LSTM l0, 2 LSTM l1, 3 linear2
+struct TickStage { int kind; int net; int stage; int group; };   // kind: 0 linear1, 1 LSTM l0, 2 LSTM l1, 3 linear2
+// groups 0-3: caller's stream (wide tiles); 4 (linear1) and 5 (linear2): second stream (16-row tiles, small-tile kernel)
 const TickStage kTick[RC_TICK_PROB] = {
-    {1, N4, 2}, {2, N4, 3}, {1, N6, 7}, {2, N6, 8},                               // longest tiles first
-    {1, N2, 2}, {2, N2, 3}, {1, N3, 7}, {1, N7, 7}, {1, N8, 7}, {2, N3, 8}, {2, N7, 8}, {2, N8, 8},
-    {0, N4, 1}, {0, N2, 1}, {0, N6, 6}, {0, N3, 6}, {0, N7, 6}, {0, N8, 6},
-    {3, N4, 4}, {3, N2, 4}, {3, N6, 9}, {3, N3, 9}, {3, N7, 9}, {3, N8, 9}};
+    {1, N4, 2, 0}, {2, N4, 3, 0}, {1, N6, 7, 1}, {2, N6, 8, 1},
+    {1, N2, 2, 2}, {2, N2, 3, 2}, {1, N3, 7, 2}, {2, N3, 8, 2}, {1, N7, 7, 3}, {2, N7, 8, 3}, {1, N8, 7, 3}, {2, N8, 8, 3},
+    {0, N4, 1, 4}, {0, N2, 1, 4}, {0, N6, 6, 4}, {0, N3, 6, 4}, {0, N7, 6, 4}, {0, N8, 6, 4},
+    {3, N4, 4, 5}, {3, N2, 4, 5}, {3, N6, 9, 5}, {3, N3, 9, 5}, {3, N7, 9, 5}, {3, N8, 9, 5}};
+
+int tune_env(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
 
 int ensure_sequence_buffers(rc_ctx* ctx) {
     if (ctx->ring_ready) return RC_OK;
@@ -434,7 +521,6 @@ int ensure_sequence_buffers(rc_ctx* ctx) {
     }
     for (int i = 0; i < 6; ++i)
         if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
-    if (int rc = dev_alloc(ctx, &ctx->tick_tables, (size_t)kRing)) return rc;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], hipEventDisableTiming));
@@ -445,19 +531,23 @@ int ensure_sequence_buffers(rc_ctx* ctx) {
     return RC_OK;
 }
 
-// launch tables of the 16 tick residues: stage s of residue r works on ring slot (r - s) mod 16
-int build_tick_tables(rc_ctx* ctx) {
-    std::vector<GemmTick> tabs(kRing);
+// GEMM problems of the 16 tick residues: the problem of stage s at residue r works on ring slot (r - s) mod 16.
+// Tile shapes (batch >= 128; smaller batches keep pick_tile's choice): rnn4 / rnn6 as in the frame-stepped launches,
+// H = 512 nets 64 x 64 (4 x 4 blocks): 128 workgroups per layer-step, four layer-steps per launch = two full rounds.
+int build_tick_problems(rc_ctx* ctx) {
+    int t4[2] = {2, 10}, t6[2] = {2, 8}, t5[2] = {4, 4};
+    tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
+    tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
+    tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
+    ctx->seq_lin1_main = tune_env("RC_SEQ_LIN1_MAIN", 1) != 0;
+    ctx->seq_two_streams = tune_env("RC_SEQ_STREAMS", 2) == 2;
+    ctx->tick_prob.assign((size_t)kRing * RC_TICK_PROB, GemmProblem{});
     for (int r = 0; r < kRing; ++r) {
-        GemmTick& T = tabs[r];
-        std::memset(&T, 0, sizeof(T));
-        T.n = RC_TICK_PROB; T.B = ctx->B;
-        int base = 0;
         for (int q = 0; q < RC_TICK_PROB; ++q) {
             const TickStage& ts = kTick[q];
             const int fr = ((r - ts.stage) % kRing + kRing) % kRing;        // frame residue = ring slot
             const FrameBuffers& fb = ctx->ring[fr];
-            NetDev n = ctx->net[ts.net];
+            const NetDev& n = ctx->net[ts.net];
             float* x1 = (fr & 1) ? ctx->x1_alt[ts.net] : n.x1;
             Stage st{ts.net, 0, nullptr, 256, Out{nullptr, 0, 0, false}};
             switch (ts.net) {
@@ -469,21 +559,27 @@ int build_tick_tables(rc_ctx* ctx) {
                 default: st.x = fb.x78; st.y = Out{fb.contact, 2, 0, false}; break;
             }
             GemmProblem p = ts.kind == 0 ? lin1_problem(ctx, st) : (ts.kind == 3 ? lin2_problem(ctx, st) : lstm_problem(ctx, st, ts.kind - 1));
-            if (ts.kind == 0) p.out = x1;                                     // relu(linear1) double-buffered by frame parity
+            if (ts.kind == 0) {
+                p.out = x1;                                                   // relu(linear1) double-buffered by frame parity
+                if (!ctx->seq_lin1_main) {                                    // 16 x 32 tiles: side kernel, beside the wide launches
+                    p.mr = 1; p.nc = 2;
+                    p.n_tiles = n.lin1.Np / 32; p.m_tiles = (ctx->B + 15) / 16;
+                }
+            }
             if (ts.kind == 1) p.seg[0].base = x1;
+            if ((ts.kind == 1 || ts.kind == 2) && ctx->B >= 128) {
+                const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
+                const int mr = t[0], nc = t[1];
+                p.mr = mr; p.nc = nc;
+                p.n_tiles = n.H / (4 * nc); p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr);
+            }
             p.flags = nullptr; p.flag_bit = 0;                                // every row steps every sub-net
             p.alt_base = nullptr; p.sel_flags = nullptr; p.sel_bit = 0;
             p.out_flags = nullptr; p.out_bit = 0;
             p.open_step = 0;
-            p.step_off = 1 + (fr & 1);
-            p.wg_base = base;
-            base += round_up(p.n_tiles * p.m_tiles, 8);
-            T.p[q] = p;
+            ctx->tick_prob[(size_t)r * RC_TICK_PROB + q] = p;
         }
-        T.total_wg = base;
-        ctx->tick_total_wg = base;
     }
-    HIP_TRY(ctx, hipMemcpy(ctx->tick_tables, tabs.data(), sizeof(GemmTick) * kRing, hipMemcpyHostToDevice));
     ctx->tick_valid = true;
     return RC_OK;
 }
@@ -492,48 +588,47 @@ int build_tick_tables(rc_ctx* ctx) {
 template <typename IoAt>
 int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
     if (int rc = ensure_sequence_buffers(ctx)) return rc;
-    if (!ctx->tick_valid) if (int rc = build_tick_tables(ctx)) return rc;
+    if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
     const int B = ctx->B;
     const rc_params_dev prm = dev_params(ctx->prm);
-    hipStream_t aux = ctx->aux_stream;
+    const bool two = ctx->seq_two_streams;
+    hipStream_t aux = two ? ctx->aux_stream : st;
     auto in_seg = [&](int f) { return f >= t0 && f < t1; };
-    // aux stream joins: everything enqueued so far on `st` (earlier frames, weight uploads) is visible to it
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));
-    HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
+    auto group = [&](int k, int g, hipStream_t s) -> int {                  // launch the active problems of group g at tick k
+        std::vector<GemmProblem> ps;
+        for (int q = 0; q < RC_TICK_PROB; ++q) {
+            const int f = k - kTick[q].stage;
+            const int gq = (kTick[q].group == 4 && ctx->seq_lin1_main) ? 3 : kTick[q].group;
+            if (gq != g || !in_seg(f)) continue;
+            GemmProblem p = ctx->tick_prob[(size_t)(k % kRing) * RC_TICK_PROB + q];
+            p.step_off = 1 + (f - t0);                                        // steps[row] stands still during the segment
+            ps.push_back(p);
+        }
+        return launch_problems(ctx, ps, nullptr, s);
+    };
+    if (two) {   // the second stream joins: everything enqueued so far on `st` (earlier frames, weight uploads) is visible to it
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
+    }
     for (int k = t0; k < t1 + kStages - 1; ++k) {
         const int e = (k - t0) & 3, ep = (k - t0 + 3) & 3;          // event slots of this tick / the previous tick
-        // ---- per-row kernels of tick k (aux stream): after the previous tick's GEMM launch
-        if (k > t0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
+        // ---- per-row kernels and the weight-streaming GEMMs of tick k (second stream: after the previous tick's wide launches)
+        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
         if (in_seg(k)) rc_launch_prep(ctx->ring[k % kRing], io_at(k), prm, B, 0, aux);
+        if (int rc = group(k, 4, aux)) return rc;
         if (in_seg(k - 5)) rc_launch_fuse(ctx->ring[(k - 5) % kRing], io_at(k - 5), prm, B, aux);
+        if (int rc = group(k, 5, aux)) return rc;
         if (in_seg(k - 10)) rc_launch_tail(ctx->ring[(k - 10) % kRing], io_at(k - 10), prm, ctx->body, B, 0, aux);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
-        // ---- GEMM stages of tick k (main stream): after the previous tick's per-row kernels
-        unsigned active = 0;
-        for (int q = 0; q < RC_TICK_PROB; ++q)
-            if (in_seg(k - kTick[q].stage)) active |= 1u << q;
-        if (k > t0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-        if (active) {
-            hipEvent_t* tev = nullptr;
-            if (ctx->timing) {
-                if (ctx->ev_used == ctx->ev_pool.size()) {
-                    hipEvent_t a, b;
-                    HIP_TRY(ctx, hipEventCreate(&a));
-                    HIP_TRY(ctx, hipEventCreate(&b));
-                    ctx->ev_pool.emplace_back(a, b);
-                }
-                auto& ev = ctx->ev_pool[ctx->ev_used++];
-                HIP_TRY(ctx, hipEventRecord(ev.first, st));
-                tev = &ev.second;
-            }
-            rc_launch_gemm_tick(ctx->tick_tables + (k % kRing), ctx->tick_total_wg, active, t0 & 1, st);
-            if (tev) HIP_TRY(ctx, hipEventRecord(*tev, st));
-        }
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
+        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
+        // ---- the LSTM layer-steps of tick k (caller's stream: after the previous tick's second-stream work)
+        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        for (int g = 0; g < 4; ++g)
+            if (int rc = group(k, g, st)) return rc;
+        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
         ctx->stat_ticks += 1;
     }
-    // the main stream continues after the last tail; every sub-net stepped (t1 - t0) times on every row
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(t1 + kStages - 2 - t0) & 3], 0));
+    // the caller's stream continues after the last tail; every sub-net stepped (t1 - t0) times on every row
+    if (two) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(t1 + kStages - 2 - t0) & 3], 0));
     int* steps6[6];
     for (int i = 0; i < 6; ++i) steps6[i] = ctx->net[i].steps;
     rc_launch_advance_steps(steps6, t1 - t0, B, st);
@@ -614,6 +709,11 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     (void)hipGetDevice(&ctx->dev);
     if (hipEventCreateWithFlags(&ctx->eager_ev, hipEventDisableTiming) != hipSuccess) ctx->eager_ev = nullptr;
     rc_default_params(live, &ctx->prm);
+    ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= 32 ? 1 : 0) != 0;
+    tile_env("RC_TILE_RNN6", &ctx->tile6[0], &ctx->tile6[1]);
+    tile_env("RC_TILE_S2H512", &ctx->tile378[0], &ctx->tile378[1]);
+    tile_env("RC_TILE_RNN2", &ctx->tile2[0], &ctx->tile2[1]);
+    tile_env("RC_TILE_RNN4", &ctx->tile4[0], &ctx->tile4[1]);
     const size_t B = (size_t)batch, Bp = (size_t)ctx->Bp;
     int rc = RC_OK;
     FrameBuffers& fb = ctx->fb;
@@ -762,6 +862,7 @@ static int finalize_weights_impl(rc_ctx* ctx) {
             std::vector<float> bp(4 * H);
             for (size_t np = 0; np < 4 * H; ++np) bp[np] = (*bi)[orig((int)np)] + (*bh)[orig((int)np)];
             if (int rc = upload(ctx, &n.Wl[l], pack_weights(4 * s.H, 2 * s.H, get))) return rc;
+            if (int rc = upload16(ctx, &n.Wls[l], pack_weights_split(4 * s.H, 2 * s.H, get))) return rc;
             if (int rc = upload(ctx, &n.bl[l], bp)) return rc;
         }
     }
@@ -883,6 +984,14 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     }
     return mark_eager(ctx, st);
 }
+
+int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < 0 || mode > 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_gemm_mode: 0 (fp32 MFMA) or 1 (split-bf16 products)") : RC_ERR_INVALID;
+    if ((mode != 0) != ctx->gemm_split) rc_live_end(ctx);      // a captured frame has the kernel choice baked in
+    ctx->gemm_split = mode != 0;
+    return RC_OK;
+}
+int rc_get_gemm_mode(const rc_ctx* ctx) { return ctx ? (ctx->gemm_split ? 1 : 0) : RC_ERR_INVALID; }
 
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames) {
     if (!ctx || mode < 0 || mode > 1 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1, min_frames >= 1") : RC_ERR_INVALID;
@@ -1235,24 +1344,50 @@ int rc_lstm_step(rc_ctx* ctx, const char* net, const float* x, const uint8_t* ro
     return mark_eager(ctx, st);
 }
 
+namespace {
+// K^-1 by the adjugate in double (the reference uses torch's float32 LU inverse, evaluate.py:34,70), R_cw, gravity
+bool camera_constants(const float* K, const float* Tcw, CamConst* cam, float* g_out) {
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (det == 0.0) return false;
+    const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                           (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                           (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    for (int q = 0; q < 9; ++q) cam->Kinv[q] = (float)inv[q];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) cam->R[3 * r + q] = Tcw[4 * r + q];
+    for (int r = 0; r < 3; ++r) g_out[r] = -cam->R[3 * r + 1];            // R_cw [0, -1, 0], evaluate.py:73
+    return true;
+}
+}  // namespace
+
 int rc_camera_inputs(const float* kp, const float* acc, const float* ori, const float* K, const float* Tcw, float* j2dc,
                      float* accc, float* oric, float* g_out, int64_t n, void* stream) {
     if (!K || !Tcw || !g_out || n < 0) return RC_ERR_INVALID;
     CamConst cam;
-    // K^-1 by the adjugate in double (the reference uses torch's float32 LU inverse, evaluate.py:34,70)
-    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
-    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-    if (det == 0.0) return RC_ERR_INVALID;
-    const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
-                           (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
-                           (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
-    for (int q = 0; q < 9; ++q) cam.Kinv[q] = (float)inv[q];
-    for (int r = 0; r < 3; ++r)
-        for (int q = 0; q < 3; ++q) cam.R[3 * r + q] = Tcw[4 * r + q];
-    for (int r = 0; r < 3; ++r) g_out[r] = -cam.R[3 * r + 1];            // R_cw [0, -1, 0], evaluate.py:73
+    if (!camera_constants(K, Tcw, &cam, g_out)) return RC_ERR_INVALID;
     if (n == 0) return RC_OK;
     if (!kp || !acc || !ori || !j2dc || !accc || !oric) return RC_ERR_INVALID;
     rc_launch_camera_inputs(kp, acc, ori, cam, j2dc, accc, oric, n, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
+}
+
+int rc_camera_inputs_rows(const float* kp_norm, const float* imu_acc_w, const float* imu_ori_w, const int32_t* seq_of_row,
+                          const int32_t* len, const float* K_host, const float* Tcw_host, float image_w, float image_h,
+                          int32_t n_rows, int32_t Tmax, float* j2dc, float* accc, float* oric, float* gravity_out_host,
+                          void* cam_scratch, void* stream) {
+    if (n_rows < 0 || Tmax < 0 || !K_host || !Tcw_host || !gravity_out_host || !cam_scratch) return RC_ERR_INVALID;
+    if (n_rows == 0 || Tmax == 0) return RC_OK;
+    if (!kp_norm || !imu_acc_w || !imu_ori_w || !seq_of_row || !len || !j2dc || !accc || !oric) return RC_ERR_INVALID;
+    std::vector<CamConst> cams((size_t)n_rows);
+    for (int r = 0; r < n_rows; ++r)
+        if (!camera_constants(K_host + 9 * (size_t)r, Tcw_host + 16 * (size_t)r, &cams[r], gravity_out_host + 3 * (size_t)r)) return RC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    // cam_scratch: DEVICE buffer of n_rows * 72 bytes owned by the caller (the library allocates nothing here)
+    if (hipMemcpyAsync(cam_scratch, cams.data(), cams.size() * sizeof(CamConst), hipMemcpyHostToDevice, st) != hipSuccess) return RC_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return RC_ERR_HIP;        // `cams` is a stack-lifetime staging buffer
+    rc_launch_camera_inputs_rows(kp_norm, imu_acc_w, imu_ori_w, seq_of_row, len, (const CamConst*)cam_scratch, image_w, image_h, n_rows,
+                                 Tmax, j2dc, accc, oric, st);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_ERR_HIP;
 }
 

@@ -505,6 +505,36 @@ __global__ void rc_camera_inputs_kernel(const float* kp, const float* acc, const
     }
 }
 
+// The same preparation for EVERY (sequence, camera) row of an evaluation in one launch (evaluate.py:32-51,66-73 loops rows
+// and frames on the host): row r reads the pixel keypoints of its camera, the IMU data of its sequence seq_of_row[r] (shared
+// by that sequence's cameras) and its own camera constants cams[r]; frames t >= len[r] of the [n_rows, Tmax] layout are
+// padding (zero keypoints / accelerations, identity orientations) so that the batched net call sees well-formed rotations.
+__global__ __launch_bounds__(128) void rc_camera_inputs_rows_kernel(const float* kp, const float* acc, const float* ori,
+                                                                    const int* seq_of_row, const int* len, const CamConst* cams,
+                                                                    float sx, float sy, int Tmax, float* j2dc, float* accc, float* oric) {
+    const long long r = blockIdx.y, f = blockIdx.x;
+    const int t = threadIdx.x;
+    const long long o = r * Tmax + f, in = (long long)seq_of_row[r] * Tmax + f;
+    const bool pad = f >= len[r];
+    const CamConst& cam = cams[r];
+    if (t < 33) {
+        const float* k = kp + (o * 33 + t) * 3;
+        float* d = j2dc + (o * 33 + t) * 3;
+        const float u = pad ? 0.f : k[0] * sx, v = pad ? 0.f : k[1] * sy;           // evaluate.py:43-44: pixels from the image-size normalisation
+        d[0] = pad ? 0.f : (cam.Kinv[0] * u + cam.Kinv[1] * v) + cam.Kinv[2];
+        d[1] = pad ? 0.f : (cam.Kinv[3] * u + cam.Kinv[4] * v) + cam.Kinv[5];
+        d[2] = pad ? 0.f : k[2];
+    } else if (t < 33 + 18) {
+        const int e = t - 33, i = e / 3, q = e % 3;
+        const float* a = acc + (in * 6 + i) * 3;
+        accc[o * 18 + e] = pad ? 0.f : (cam.R[3 * q] * a[0] + cam.R[3 * q + 1] * a[1]) + cam.R[3 * q + 2] * a[2];
+    } else if (t < 33 + 18 + 54) {
+        const int e = t - 51, i = e / 9, q = (e % 9) / 3, c = e % 3;
+        const float* m = ori + (in * 6 + i) * 9;
+        oric[o * 54 + e] = pad ? (q == c ? 1.f : 0.f) : (cam.R[3 * q] * m[c] + cam.R[3 * q + 1] * m[3 + c]) + cam.R[3 * q + 2] * m[6 + c];
+    }
+}
+
 // Full-mesh linear-blend skinning (articulate/model.py:235-241): one workgroup per frame; wave 0 chains the 24 joint
 // transforms into LDS, then all 256 threads sweep the V vertices (blend the 3x4 transforms, then apply). HBM-bound
 // sweep: 12 B out per vertex; v_template (83 KB) and the [V,24] weights (661 KB) stay in L2 across frames.
@@ -655,6 +685,13 @@ void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t st) {
 void rc_launch_camera_inputs(const float* kp, const float* acc, const float* ori, const CamConst& cam, float* j2dc, float* accc,
                              float* oric, long long n, hipStream_t st) {
     hipLaunchKernelGGL(rc_camera_inputs_kernel, dim3((unsigned)n), dim3(128), 0, st, kp, acc, ori, cam, j2dc, accc, oric, n);
+}
+void rc_launch_camera_inputs_rows(const float* kp, const float* acc, const float* ori, const int* seq_of_row, const int* len,
+                                  const CamConst* cams, float sx, float sy, int n_rows, int Tmax, float* j2dc, float* accc,
+                                  float* oric, hipStream_t st) {
+    if (n_rows <= 0 || Tmax <= 0) return;
+    hipLaunchKernelGGL(rc_camera_inputs_rows_kernel, dim3((unsigned)Tmax, (unsigned)n_rows), dim3(128), 0, st, kp, acc, ori, seq_of_row,
+                       len, cams, sx, sy, Tmax, j2dc, accc, oric);
 }
 void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t st) {
     hipLaunchKernelGGL(rc_aa2R_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, aa, R, n);

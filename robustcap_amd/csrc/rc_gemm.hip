@@ -38,12 +38,22 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #ifndef LDS_PAD
 #define LDS_PAD 16            // floats added to a partial-sum row: epilogue rows land on different banks
 #endif
+#define RC_LDS_HEAD 192       // ints in front of the partial sums: active rows of the tile [128], per-wave counts [4]
 
 #ifndef RC_ABLATE
 #define RC_ABLATE 0           // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
 #endif
 
+#ifndef RC_FAST_GATES
+#define RC_FAST_GATES 0       // 1: gate non-linearities on v_exp_f32 / v_rcp_f32 (A/B builds; see DESIGN.md for the parity cost)
+#endif
+#if RC_FAST_GATES
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x)); }
+#else
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#endif
 
 template <int MR, int NC>
 struct Frag {                 // one chunk (16 k): a float4 per lane for each of the MR row blocks and NC column blocks
@@ -80,6 +90,81 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
     }
 }
 
+// ---- split-bf16 products (GemmLaunch.split) -----------------------------------------------------------------------------
+// An fp32 value is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 significant bits, truncation split: hi = top 16 bits of
+// a, mid = top 16 bits of a - hi, lo = a - hi - mid), and a bf16 x bf16 product is exact in fp32. The gate GEMM then runs on
+// v_mfma_f32_16x16x32_bf16 (17 cycles per 16x16x32 block against 8 x 32 cycles of v_mfma_f32_16x16x4_f32) as RC_SPLIT_PRODUCTS
+// partial products per block pair with fp32 accumulation: 6 keep every term down to 2^-16 of the product (hi.hi, hi.mid,
+// mid.hi, mid.mid, hi.lo, lo.hi; what is dropped is <= 2^-23 of a product, below the fp32 rounding of the running sum that
+// the fp32 instruction makes as well), 9 keep all of them (the products are then exact; only the order of the fp32
+// additions differs from an fma chain). Weights are split once on the host (three bf16 planes, 6 B per weight), activations
+// on the fly (they stay fp32 everywhere else). One k-block = 32 k = two 16-k chunks of the rc_pk layout: lane (kq, i) holds
+// k = 32 kb + {4 kq .. 4 kq + 3} and 32 kb + 16 + {4 kq .. 4 kq + 3} -- the same 8 k for the A and the B operand.
+#ifndef RC_SPLIT_PRODUCTS
+#define RC_SPLIT_PRODUCTS 6
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MR, int NC>
+struct FragS {                // one k-block (32 k): fp32 activations (two float4 per row block), three weight planes per column block
+    f32x4 a0[MR], a1[MR];
+    u32x4 b[NC][3];
+};
+
+template <int MR, int NC>
+__device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const u32x4* pb,
+                                            long long bstride) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
+        f.a1[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff + 256);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+}
+
+// a = hi + mid + lo exactly; each output packs 8 bf16 (element e in the low / high half of dword e / 2)
+__device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
+    float a[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    unsigned ua[8], um[8], ul[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ua[e] = __float_as_uint(a[e]);
+        const float r1 = a[e] - __uint_as_float(ua[e] & 0xffff0000u);
+        um[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(um[e] & 0xffff0000u);
+        ul[e] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {   // bytes {hi[3], hi[2], lo[3], lo[2]} of the pair = the two truncated bf16
+        h[d] = __builtin_amdgcn_perm(ua[2 * d + 1], ua[2 * d], 0x07060302u);
+        m[d] = __builtin_amdgcn_perm(um[2 * d + 1], um[2 * d], 0x07060302u);
+        l[d] = __builtin_amdgcn_perm(ul[2 * d + 1], ul[2 * d], 0x07060302u);
+    }
+}
+
+template <int MR, int NC>
+__device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[MR][NC]) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        u32x4 uh, um, ul;
+        split3(f.a0[r], f.a1[r], uh, um, ul);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, uh), am = __builtin_bit_cast(bf16x8, um), al = __builtin_bit_cast(bf16x8, ul);
+        // small terms first; consecutive MFMAs go to different accumulators (NC of them between two uses of one)
+#define RC_PROD(AV, PL)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                                        \
+        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AV, __builtin_bit_cast(bf16x8, f.b[j][PL]), acc[r][j], 0, 0, 0);
+#if RC_SPLIT_PRODUCTS == 9
+        RC_PROD(al, 2) RC_PROD(am, 2) RC_PROD(al, 1)
+#endif
+        RC_PROD(al, 0) RC_PROD(ah, 2) RC_PROD(am, 1) RC_PROD(am, 0) RC_PROD(ah, 1) RC_PROD(ah, 0)
+#undef RC_PROD
+    }
+}
+
 // One workgroup = one (16*MR)-row x (16*NC)-column tile, K split over the RC_NW waves. Tile shapes are chosen so that
 // every LSTM layer of every net is exactly 256 workgroups at batch 256 (one per CU), with as few operand bytes per
 // MFMA as the register file allows -- measured on MI355X, a CU delivers only ~256 B of operands per 64 MFMA cycles
@@ -95,10 +180,9 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int MR, int NC, int D, bool PIPE>
-__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem,
-                                          const int step_par = 0) {   // step_par: parity of the segment's first frame (ticks)
-    constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + LDS_PAD;
+template <int MR, int NC, int D, bool PIPE, bool SPLIT = false>
+__device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
+    constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + (MR >= 8 ? 4 : LDS_PAD);   // 128-row tiles: 140 KB with pad 4
 #ifdef RC_TRACE_TILES
     unsigned long long trace_t[4] = {0, 0, 0, 0};
     bool traced = false;
@@ -107,9 +191,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
   // column tile and still cover any number of rows (a full grid of row tiles would mostly be workgroups that scan the
   // flags and exit: 9,216 of them per launch at batch 256 with 16-row tiles).
   for (int m_tile = m_tile0;; m_tile += P.m_tiles) {
-    int* s_rows = reinterpret_cast<int*>(s_mem);                   // [MT <= 64]
-    int* s_cnt = s_rows + 64;                                       // [RC_NW] (+ padding to 128 ints)
-    float* s_part = s_mem + 128;                                    // [RC_NW][MT][LD]
+    int* s_rows = reinterpret_cast<int*>(s_mem);                   // [MT <= 128]
+    int* s_cnt = s_rows + 128;                                      // [RC_NW] (+ padding to RC_LDS_HEAD ints)
+    float* s_part = s_mem + RC_LDS_HEAD;                            // [RC_NW][MT][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     TRACE_T(0);
@@ -120,7 +204,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         nrows = min(MT, B - lo);
         if (nrows <= 0) return;
         __syncthreads();                                            // previous row tile done with s_rows / s_part
-        if (tid < MT) s_rows[tid] = lo + min(tid, nrows - 1);
+        if (tid < MT) s_rows[tid] = lo + min(tid, nrows - 1);       // MT <= 128 < 256 threads
         __syncthreads();
     } else {
         int total = 0;
@@ -158,7 +242,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const int row = s_rows[16 * r + i];
-        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] + P.step_off + step_par : 0;
+        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] + P.step_off : 0;
         const float* pp[2];
 #pragma unroll
         for (int sgi = 0; sgi < 2; ++sgi) {
@@ -197,7 +281,33 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     // vmcnt(0) in front of the MFMAs); prefetch indices past the end are clamped (a redundant, valid load) and only
     // the remainder (< D chunks, already loaded) is predicated. D = 2 for the wide tiles (their 64-80 MFMAs per chunk
     // cover the latency), D = 8 for the 16-row tiles whose 4-8 MFMAs per chunk do not.
-    if constexpr (D == 2) {             // wide tiles: two named buffers (the array form below schedules worse here)
+    if constexpr (SPLIT) {              // split-bf16 products: k-blocks of 32, two named buffers for every tile shape
+        const int Qs = P.Kp / 32, Qws = Qs / RC_NW;                 // k-blocks per wave (K' % 128 == 0 -> >= 1)
+        const long long bs = (long long)Qs * 192;                   // uint4 between consecutive 16-column blocks (3 planes x 64 lanes)
+        const u32x4* pbs = reinterpret_cast<const u32x4*>(P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * 192 + lane;
+        const int kb0 = wave * Qws * 32;
+#define LOADS(F, QI)                                                                                                \
+    do {                                                                                                            \
+        const int k_ = kb0 + (QI) * 32;                                                                             \
+        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)(QI) * 192, bs);              \
+        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)(QI) * 192, bs);               \
+    } while (0)
+        FragS<MR, NC> fa = {}, fb = {};
+        int q = 0;
+        LOADS(fa, 0);
+        for (; q + 2 <= Qws; q += 2) {  // prefetch indices past the end are clamped: a redundant, valid load, no branch
+            LOADS(fb, min(q + 1, Qws - 1));
+            SB();
+            mma_kblock<MR, NC>(fa, acc);
+            SB();
+            LOADS(fa, min(q + 2, Qws - 1));
+            SB();
+            mma_kblock<MR, NC>(fb, acc);
+            SB();
+        }
+        if (q < Qws) mma_kblock<MR, NC>(fa, acc);
+#undef LOADS
+    } else if constexpr (D == 2) {      // wide tiles: two named buffers (the array form below schedules worse here)
         Frag<MR, NC> fa = {}, fb = {};
         int q = 0;
         LOADC(fa, 0);
@@ -268,13 +378,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
                 gsum[gq] = v + P.bias[n_tile * NT + col];
             }
             const int r2 = s_rows[rr];
-            const int dst = (P.steps[r2] + P.step_off + step_par) & 1;
+            const int dst = (P.steps[r2] + P.step_off) & 1;
             const long long ci = (long long)r2 * P.H + unit;
             const float ig = sigmoidf_(gsum[0]), fg = sigmoidf_(gsum[1]);
-            const float gg = tanhf(gsum[2]), og = sigmoidf_(gsum[3]);
+            const float gg = tanhf_(gsum[2]), og = sigmoidf_(gsum[3]);
             const float cn = fg * P.cstate[ci] + ig * gg;
             P.cstate[ci] = cn;
-            P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf(cn);
+            P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf_(cn);
         }
     } else {
         for (int item = tid; item < MT * NT; item += RC_NW * 64) {
@@ -308,7 +418,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 }
 
 #ifndef RC_LDS_FLOATS
-#define RC_LDS_FLOATS (128 + RC_NW * 64 * (16 * 5 + LDS_PAD))   // 98 KB = the 4 x 5 tile; 2 x 10 needs 90 KB
+#define RC_LDS_FLOATS (RC_LDS_HEAD + RC_NW * 64 * (16 * 8 + LDS_PAD))   // 148 KB = the 4 x 8 tile (8 x 4: 140 KB, 4 x 5: 97 KB, 2 x 10: 91 KB)
 #endif
 
 #ifndef RC_WPS
@@ -333,68 +443,56 @@ __device__ __forceinline__ bool locate_tile(const GemmLaunch& L, int& pi, int& m
     return n_tile < P.n_tiles;
 }
 
-__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmLaunch L) {
-    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+template <bool SPLIT>
+__device__ __forceinline__ void wide_tiles(const GemmLaunch& L, float* s_mem) {
     int pi, m_tile, n_tile;
     if (!locate_tile(L, pi, m_tile, n_tile)) return;
     const GemmProblem& P = L.p[pi];
     switch (P.mr * 16 + P.nc) {
-        case 4 * 16 + 5: gemm_tile<4, 5, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 4 * 16 + 4: gemm_tile<4, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 2 * 16 + 10: gemm_tile<2, 10, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 2 * 16 + 8: gemm_tile<2, 8, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 1 * 16 + 2: gemm_tile<1, 2, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        case 1 * 16 + 1: gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem); break;
-        default: gemm_tile<2, 4, 2, true>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 8 * 16 + 4: gemm_tile<8, 4, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 8: gemm_tile<4, 8, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 5: gemm_tile<4, 5, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 4 * 16 + 4: gemm_tile<4, 4, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 10: gemm_tile<2, 10, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 2 * 16 + 8: gemm_tile<2, 8, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 2: gemm_tile<1, 2, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 1: gemm_tile<1, 1, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        default: gemm_tile<2, 4, 2, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
     }
 }
 
-// Sequence-mode tick: the same tiles, problems read from a device-resident table (up to RC_TICK_PROB stages of the frame
-// pipeline, each on its own frame); stages without a frame at the ends of a segment are masked out.
-__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_tick_kernel(const GemmTick* __restrict__ T, const unsigned active,
-                                                                          const int step_par) {
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
-    int pi = 0;
-    const int n = T->n;
-    for (int q = 1; q < n; ++q)
-        if ((int)blockIdx.x >= T->p[q].wg_base) pi = q;
-    if (!((active >> pi) & 1u)) return;
-    const GemmProblem& P = T->p[pi];
-    const int local = blockIdx.x - P.wg_base;
-    int m_tile, n_tile;
-    if ((P.n_tiles & 7) == 0) {   // XCD-aware: the row tiles of one weight slice share block-id % 8
-        const int xcd = local & 7, s = local >> 3;
-        m_tile = s % P.m_tiles;
-        n_tile = (s / P.m_tiles) * 8 + xcd;
-    } else {
-        m_tile = local % P.m_tiles;
-        n_tile = local / P.m_tiles;
-    }
-    if (n_tile >= P.n_tiles) return;
-    switch (P.mr * 16 + P.nc) {
-        case 2 * 16 + 10: gemm_tile<2, 10, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
-        case 2 * 16 + 8: gemm_tile<2, 8, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
-        case 1 * 16 + 2: gemm_tile<1, 2, 8, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
-        case 1 * 16 + 1: gemm_tile<1, 1, 8, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
-        default: gemm_tile<2, 4, 2, true>(P, T->B, m_tile, n_tile, s_mem, step_par); break;
-    }
+    wide_tiles<false>(L, s_mem);
 }
-
-void rc_launch_gemm_tick(const GemmTick* table_dev, int total_wg, unsigned active_mask, int step_par, hipStream_t s) {
-    hipLaunchKernelGGL(rc_gemm_tick_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, table_dev, active_mask, step_par);
+// the same tiles with split-bf16 products (GemmLaunch.split; see mma_kblock)
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_split_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+    wide_tiles<true>(L, s_mem);
 }
 
 // Launches whose problems all use 16-row tiles (batch <= 16: live mode, transition rows) are weight-streaming, not
 // MFMA-bound: their own kernel with a 12 KB LDS footprint and a register budget for 4 waves per SIMD keeps four
 // workgroups -- 4 x 32 KB of weight loads in flight -- on every CU instead of one.
-#define RC_SMALL_LDS_FLOATS (128 + RC_NW * 16 * (16 * 2 + LDS_PAD))
-__global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const GemmLaunch L) {
-    __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
+// (Tried and dropped for sequence mode: running such launches on a second stream BESIDE a wide-tile launch. Four of these
+// workgroups fill a CU's register file and lock the wide tiles' 300-register waves out; a variant with its LDS padded to
+// 60 KB, so that only one fits beside a wide-tile workgroup, still stretched a 116 us rnn4 launch to 150-220 us.)
+#define RC_SMALL_LDS_FLOATS (RC_LDS_HEAD + RC_NW * 16 * (16 * 2 + LDS_PAD))
+template <bool SPLIT>
+__device__ __forceinline__ void small_tiles(const GemmLaunch& L, float* s_mem) {
     int pi, m_tile, n_tile;
     if (!locate_tile(L, pi, m_tile, n_tile)) return;
     const GemmProblem& P = L.p[pi];
-    if (P.nc == 2) gemm_tile<1, 2, 4, true>(P, L.B, m_tile, n_tile, s_mem);
-    else gemm_tile<1, 1, 8, true>(P, L.B, m_tile, n_tile, s_mem);
+    if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem);
+    else gemm_tile<1, 1, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem);
+}
+__global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
+    small_tiles<false>(L, s_mem);
+}
+__global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_split_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
+    small_tiles<true>(L, s_mem);
 }
 
 bool rc_gemm_is_small(const GemmLaunch& L) {
@@ -404,6 +502,12 @@ bool rc_gemm_is_small(const GemmLaunch& L) {
 }
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
-    if (rc_gemm_is_small(L)) hipLaunchKernelGGL(rc_gemm_small_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
-    else hipLaunchKernelGGL(rc_gemm_kernel, dim3(total_wg), dim3(RC_NW * 64), 0, s, L);
+    const dim3 g(total_wg), b(RC_NW * 64);
+    if (rc_gemm_is_small(L)) {
+        if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
+        else hipLaunchKernelGGL(rc_gemm_small_kernel, g, b, 0, s, L);
+    } else {
+        if (L.split) hipLaunchKernelGGL(rc_gemm_split_kernel, g, b, 0, s, L);
+        else hipLaunchKernelGGL(rc_gemm_kernel, g, b, 0, s, L);
+    }
 }

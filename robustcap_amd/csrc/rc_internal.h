@@ -14,7 +14,7 @@
 #endif
 #define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
 #define RC_KALIGN 128     // padded K granularity (>= 2 * RC_KC * RC_NW: an even number of chunks per wave)
-#define RC_MAX_PROB 6     // problems fused in one launch
+#define RC_MAX_PROB 12    // problems fused in one launch (GemmLaunch travels as a kernel argument: 12 x 224 B)
 
 // Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
 // wave's A load is one contiguous 1 KiB piece, exactly like the packed weights: for 16-row block row / 16 and
@@ -54,6 +54,7 @@ struct GemmSeg {
 struct GemmProblem {
     GemmSeg seg[2];         // A = [seg0 | seg1] along K
     const float* W;         // packed weights, see pack_weights() in rc_api.cpp
+    const void* Ws;         // the same weights as three bf16 planes (split-bf16 products), see pack_weights_split()
     const float* bias;      // [n_tiles * 64] in packed column order
     float* out;             // dense: out[row * ldo + col0 + n], or rc_pk(row, col0 + n, ldo) if out_packed
     float* hstate;          // lstm: h[parity][row][H]
@@ -75,7 +76,7 @@ struct GemmProblem {
     int mr;                 // 16-row blocks per tile (2 or 4); (mr, nc) must be one of the instantiated shapes
     int trace_base;         // first record slot of this launch (read by -DRC_TRACE_TILES builds only)
     int step_off;           // added to steps[row] wherever the step parity is formed. Frame-stepped launches: 0 (linear1
-                            // has already incremented the counter). Sequence-mode ticks: 1 + (frame - first frame of the
+                            // has already incremented the counter). Sequence mode: 1 + (frame - first frame of the
                             // segment), with open_step = 0: the counters stand still while stages of several frames are in
                             // flight and are advanced once, after the segment.
 };
@@ -83,20 +84,12 @@ struct GemmProblem {
 struct GemmLaunch {
     int n;                  // problems
     int B;                  // rows in the batch
+    int split;              // 1: products as split-bf16 partial products on the bf16 MFMA (rc_gemm.hip: mma_kblock), W -> Ws
+    int pad_;
     GemmProblem p[RC_MAX_PROB];
 };
 
-// Sequence mode (rc_sequence on all-visible stretches): ONE launch per tick carries every GEMM stage of the frame pipeline,
-// each on a different frame (stage s of tick k works on frame k - s). The table lives in device memory (24 problems do not
-// fit the kernel-argument segment comfortably); `active` masks the stages that have no frame yet / any more at the ends.
-#define RC_TICK_PROB 24
-struct GemmTick {
-    int n;
-    int B;
-    int total_wg;
-    int pad_;
-    GemmProblem p[RC_TICK_PROB];
-};
+#define RC_TICK_PROB 24   // GEMM problems of one sequence-mode tick (6 sub-nets x {linear1, LSTM l0, LSTM l1, linear2})
 
 // ---- per-frame small kernels -------------------------------------------------------------------------------
 struct BodyConst {          // device copy of the body constants the path needs
@@ -144,7 +137,6 @@ struct rc_params_dev {
 };
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
-void rc_launch_gemm_tick(const GemmTick* table_dev, int total_wg, unsigned active_mask, int step_par, hipStream_t s);
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);
 void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t s);
 bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_gemm_small_kernel (16-row tiles only)
@@ -171,6 +163,9 @@ void rc_launch_lerp(const float* a, const float* b, float w1, float w2, float* o
 void rc_launch_normalize_rows(const float* x, float* out, float* norm, long long rows, int width, hipStream_t s);
 void rc_launch_angle_between(const float* R1, const float* R2, float* out, long long n, hipStream_t s);
 void rc_launch_bbox_normalise(const float* kp, float* out, long long n, hipStream_t s);
+void rc_launch_camera_inputs_rows(const float* kp, const float* acc, const float* ori, const int* seq_of_row, const int* len,
+                                  const CamConst* cams, float sx, float sy, int n_rows, int Tmax, float* j2dc, float* accc,
+                                  float* oric, hipStream_t s);
 void rc_launch_aa2R(const float* aa, float* R, long long n, hipStream_t s);
 void rc_launch_R2aa(const float* R, float* aa, long long n, hipStream_t s);
 void rc_launch_ik(const BodyConst* body, const float* Rg, float* Rl, long long n, hipStream_t s);

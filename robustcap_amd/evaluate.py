@@ -63,14 +63,68 @@ def labels(dataset, i, j, device="cuda"):
     return pose, tran
 
 
+def camera_inputs_rows(dataset, rows, Tmax, image_size=(1920, 1080), device="cuda"):
+    """evaluate.py:38-51 + 70-73 for ALL the given (sequence, camera) rows in ONE kernel launch (rc_camera_inputs_rows):
+    the dataset arrays are stacked on the host (padded to Tmax), uploaded once, and every row's frames are prepared on the
+    device -- no per-row launches, copies or synchronisation. Returns device tensors j2dc [n,Tmax,33,3], accc [n,Tmax,6,3],
+    oric [n,Tmax,6,3,3] (padding frames: zero keypoints / accelerations, identity orientations) and host gravity [n,3]."""
+    dev = torch.device(device)
+    n = len(rows)
+    seqs = sorted({i for i, _ in rows})
+    slot = {i: k for k, i in enumerate(seqs)}
+    kp = np.zeros((n, Tmax, 33, 3), np.float32)
+    acc = np.zeros((len(seqs), Tmax, 6, 3), np.float32)
+    ori = np.zeros((len(seqs), Tmax, 6, 3, 3), np.float32)
+    for i in seqs:
+        T = len(dataset["pose"][i])
+        acc[slot[i], :T] = np.asarray(dataset["imu_acc"][i], np.float32)
+        ori[slot[i], :T] = np.asarray(dataset["imu_ori"][i], np.float32)
+    K = np.zeros((n, 3, 3), np.float32)
+    Tcw = np.zeros((n, 4, 4), np.float32)
+    lens = np.zeros(n, np.int32)
+    for r, (i, j) in enumerate(rows):
+        T = len(dataset["pose"][i])
+        kp[r, :T] = np.asarray(dataset["joint2d_mp"][i][j], np.float32)
+        K[r], Tcw[r], lens[r] = np.asarray(dataset["cam_K"][i][j], np.float32), np.asarray(dataset["cam_T"][i][j], np.float32), T
+    seq_of_row = np.asarray([slot[i] for i, _ in rows], np.int32)
+    up = lambda a: torch.from_numpy(a).to(dev)
+    kp_d, acc_d, ori_d, sor_d, len_d = up(kp), up(acc), up(ori), up(seq_of_row), up(lens)
+    j2dc = torch.empty(n, Tmax, 33, 3, device=dev)
+    accc = torch.empty(n, Tmax, 6, 3, device=dev)
+    oric = torch.empty(n, Tmax, 6, 3, 3, device=dev)
+    grav = np.zeros((n, 3), np.float32)
+    scratch = torch.empty(n * 18, device=dev)                                   # 72 bytes of camera constants per row
+    lib = _lib.load()
+    rc = lib.rc_camera_inputs_rows(_lib.ptr(kp_d), _lib.ptr(acc_d), _lib.ptr(ori_d), _lib.ptr(sor_d), _lib.ptr(len_d),
+                                   K.ctypes.data_as(C.c_void_p), Tcw.ctypes.data_as(C.c_void_p), float(image_size[0]), float(image_size[1]),
+                                   n, Tmax, _lib.ptr(j2dc), _lib.ptr(accc), _lib.ptr(oric), grav.ctypes.data_as(C.c_void_p),
+                                   _lib.ptr(scratch), _lib.stream_ptr())
+    _lib.check(None, rc, "rc_camera_inputs_rows")
+    torch.cuda.current_stream().synchronize()                                   # inputs of the launch stay alive until it ran
+    return j2dc, accc, oric, torch.from_numpy(grav)
+
+
+def first_translations(dataset, rows):
+    """label translation of frame 0 of every row in its camera frame: T_cw [tran; 1] (evaluate.py:46-49,77) -- the same
+    float32 expression as ``labels`` (so a row of the batched run equals that row run alone, bit for bit), without the pose."""
+    ft = torch.zeros(len(rows), 3)
+    for r, (i, j) in enumerate(rows):
+        Tcw = torch.as_tensor(dataset["cam_T"][i][j], dtype=torch.float32)
+        ft[r] = (torch.as_tensor(dataset["tran"][i], dtype=torch.float32) @ Tcw[:3, :3].T + Tcw[:3, 3])[0]
+    return ft
+
+
 def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda",
-                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080)):
+                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080), smplify_workers=4):
     """Run every (sequence, camera) row of ``dataset`` (or the given subset) through the net; rows are sharded over
     the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU.
 
+    Input preparation is one kernel launch for all rows (``camera_inputs_rows``), the net one ``forward_sequence`` call.
     run_smplify=True refines every row with the smplify optimiser exactly where evaluate.py:86-90 does: after the
     net, on the pixel keypoints and the camera-frame IMU orientations of that row, lr=0.001, and -- like the reference
-    -- takes the optimised pose and translation whether or not ``update`` says they improved. ``gmm`` is the pose
+    -- takes the optimised pose and translation whether or not ``update`` says they improved. Rows are independent
+    optimisation problems (the reference runs them one after another): ``smplify_workers`` host threads each drive their
+    own optimiser context and HIP stream, so the line searches of several rows overlap on the device. ``gmm`` is the pose
     prior (dict means/covars/weights); ``smplify_info`` (a dict) receives the per-row optimiser records."""
     all_rows = rows_of(dataset) if rows is None else list(rows)
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
@@ -82,35 +136,15 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     out_p = torch.zeros(max(n, 1), Tmax, 24, 3, 3, device=device)
     out_t = torch.zeros(max(n, 1), Tmax, 3, device=device)
     if n:
-        j2d = torch.zeros(n, Tmax, 33, 3, device=device)
-        acc = torch.zeros(n, Tmax, 6, 3, device=device)
-        ori = torch.eye(3, device=device).repeat(n, Tmax, 6, 1, 1)      # padding frames: identity orientations
-        grav, ft = torch.zeros(n, 3), torch.zeros(n, 3)
-        for r, (i, j) in enumerate(mine):
-            T = len(dataset["pose"][i])
-            k, ac, orc, g = camera_inputs(dataset["joint2d_mp"][i][j], dataset["imu_acc"][i], dataset["imu_ori"][i],
-                                          dataset["cam_K"][i][j], dataset["cam_T"][i][j], image_size=image_size, device=device)
-            j2d[r, :T], acc[r, :T], ori[r, :T], grav[r] = k, ac, orc, g
-            ft[r] = labels(dataset, i, j, device)[1][0]                    # first_tran = label translation of frame 0
+        j2d, acc, ori, grav = camera_inputs_rows(dataset, mine, Tmax, image_size=image_size, device=device)
+        ft = first_translations(dataset, mine)
         net = Net(body=body, batch=n, device=device)
         net.load_state_dict(state_dict)
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)
         if run_smplify:
-            from .smplify import TemporalSMPLify
-            runner = TemporalSMPLify(body=body, gmm=gmm, device=device)
-            if not runner.has_prior:
-                raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")
-            for r, (i, j) in enumerate(mine):
-                T = len(dataset["pose"][i])
-                kp_pix = torch.as_tensor(dataset["joint2d_mp"][i][j], dtype=torch.float32).clone()
-                kp_pix[..., 0] *= image_size[0]                              # the pixels evaluate.py:43-44 builds, :87 passes on
-                kp_pix[..., 1] *= image_size[1]
-                p, t, _ = runner.run(out_p[r, :T], out_t[r, :T], kp_pix, ori[r, :T], dataset["cam_K"][i][j], lr=0.001)
-                out_p[r, :T], out_t[r, :T] = p, t
-                if smplify_info is not None:
-                    smplify_info[(i, j)] = dict(runner.last_info)
+            _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, smplify_workers)
     if world > 1:                                                       # the path's only collective
         # explicit widths: a rank whose shard is empty (rows < world) must still reach the collective
         cap_p = rdist.gather_rows(out_p[:n].reshape(n, Tmax * 216), len(all_rows))
@@ -118,11 +152,50 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
         out_p, out_t, rows_out = cap_p.view(-1, Tmax, 24, 3, 3), cap_t.view(-1, Tmax, 3), all_rows
     else:
         rows_out = mine
+    out_p, out_t = out_p.cpu(), out_t.cpu()                             # one D2H for everything
     res = {}
     for r, (i, j) in enumerate(rows_out):
         T = len(dataset["pose"][i])
-        res[(i, j)] = (out_p[r, :T].cpu(), out_t[r, :T].cpu())
+        res[(i, j)] = (out_p[r, :T], out_t[r, :T])
     return res
+
+
+def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, workers):
+    """smplify over the rows of this rank (evaluate.py:86-90), ``workers`` rows in flight: each host thread owns a
+    TemporalSMPLify context and a HIP stream; the C call releases the GIL, so the threads' line searches interleave."""
+    import threading
+    from .smplify import TemporalSMPLify
+    torch.cuda.synchronize()
+    workers = max(1, min(int(workers), len(mine)))
+    runners = [TemporalSMPLify(body=body, gmm=gmm, device=device) for _ in range(workers)]
+    if not runners[0].has_prior:
+        raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")
+    scale = torch.tensor([float(image_size[0]), float(image_size[1]), 1.0])
+    errors = []
+
+    def work(w):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                for r in range(w, len(mine), workers):
+                    i, j = mine[r]
+                    T = len(dataset["pose"][i])
+                    kp_pix = torch.as_tensor(dataset["joint2d_mp"][i][j], dtype=torch.float32) * scale   # evaluate.py:43-44 -> :87
+                    p, t, _ = runners[w].run(out_p[r, :T], out_t[r, :T], kp_pix, ori[r, :T], dataset["cam_K"][i][j], lr=0.001)
+                    out_p[r, :T], out_t[r, :T] = p, t
+                    if smplify_info is not None:
+                        smplify_info[(i, j)] = dict(runners[w].last_info)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001 - re-raised on the calling thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    torch.cuda.synchronize()
 
 
 def joint_errors(model, pose_p, tran_p, pose_t, tran_t):

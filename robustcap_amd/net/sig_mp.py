@@ -223,6 +223,17 @@ class Net:
         self.__dict__["_keep"] = (j2dc, accc, oric, ft)
         return pose, tran
 
+    def set_gemm_mode(self, split):
+        """Product arithmetic of every GEMM of this context (rc_set_gemm_mode): False = fp32 MFMA (fma chains), True =
+        split-bf16 partial products with fp32 accumulation (default for batch >= 32). Results are bitwise reproducible
+        across batch sizes and shards WITHIN one mode."""
+        _lib.check(self._ctx, self._lib.rc_set_gemm_mode(self._ctx, int(bool(split))), "rc_set_gemm_mode")
+        self.__dict__["_live_on"] = False
+
+    @property
+    def gemm_mode(self):
+        return int(self._lib.rc_get_gemm_mode(self._ctx))
+
     def set_sequence_mode(self, enabled=True, min_frames=16):
         """Scheduling of ``forward_sequence`` (rc_set_sequence_mode): with ``enabled`` (the default) all-visible stretches
         of at least ``min_frames`` frames run on the wavefront engine (bitwise the same outputs, one GEMM launch per tick)."""

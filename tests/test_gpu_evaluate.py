@@ -25,6 +25,25 @@ def test_camera_inputs_match_reference_formulas(synth_assets):
     assert float((g - Tcw[:3, :3] @ torch.tensor([0.0, -1.0, 0.0])).abs().max()) <= 1e-7      # evaluate.py:73
 
 
+def test_batched_camera_inputs_equal_the_per_row_kernel(synth_assets):
+    """rc_camera_inputs_rows (all rows, one launch, padded to Tmax) == rc_camera_inputs row by row, bit for bit."""
+    from robustcap_amd import synth
+    from robustcap_amd import evaluate as ev
+    ds = synth.make_dataset(7, 3, 24, synth_assets["body"], n_cam=3)
+    for k in ("pose", "tran", "imu_ori", "imu_acc"):
+        ds[k][2] = ds[k][2][:17]                                                     # ragged
+    ds["joint2d_mp"][2] = ds["joint2d_mp"][2][:, :17]
+    rows = [(0, 0), (2, 1), (1, 2), (2, 2), (0, 1)]                                  # any order, any subset
+    j2d, acc, ori, grav = ev.camera_inputs_rows(ds, rows, 24)
+    for r, (i, j) in enumerate(rows):
+        k, a, o, g = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])
+        T = k.shape[0]
+        assert torch.equal(j2d[r, :T], k) and torch.equal(acc[r, :T], a) and torch.equal(ori[r, :T], o) and torch.equal(grav[r], g)
+        assert float(j2d[r, T:].abs().sum()) == 0.0 and float(acc[r, T:].abs().sum()) == 0.0
+        if T < 24:
+            assert torch.equal(ori[r, T:], torch.eye(3, device=ori.device).expand(24 - T, 6, 3, 3))
+
+
 def test_run_dataset_rows_equal_direct_runs_and_metrics(synth_assets):
     from robustcap_amd import synth
     from robustcap_amd import evaluate as ev
@@ -58,6 +77,27 @@ def test_run_dataset_rows_equal_direct_runs_and_metrics(synth_assets):
     assert e["mpjpe_smpl24_m"] > 0.05 and e["pa_mpjpe_smpl24_m"] < 1e-5           # Procrustes removes it
     per_row, mean = ev.evaluate(ds, sd, body)
     assert len(per_row) == 4 and np.isfinite(list(mean.values())).all()
+
+
+def test_run_dataset_with_smplify_rows_in_parallel(synth_assets):
+    """evaluate.py:86-90 over all rows: several rows' optimisers in flight (own context + stream per host thread) give the
+    same result as one after another, and every row was optimised."""
+    from robustcap_amd import synth
+    from robustcap_amd import evaluate as ev
+    body, sd, gmm = synth_assets["body"], synth_assets["state_dict"], synth.make_gmm(3)
+    ds = synth.make_dataset(8, 2, 48, body, n_cam=3, conf="high")
+    out = []
+    for workers in (1, 3):
+        info = {}
+        res = ev.run_dataset(ds, sd, body, run_smplify=True, gmm=gmm, smplify_info=info, smplify_workers=workers)
+        assert len(info) == 6 and all(v["n_eval"] >= 1 for v in info.values())
+        out.append((res, info))
+    for key in out[0][0]:
+        assert torch.equal(out[0][0][key][0], out[1][0][key][0]) and torch.equal(out[0][0][key][1], out[1][0][key][1]), key
+        assert out[0][1][key]["n_eval"] == out[1][1][key]["n_eval"]
+    plain = ev.run_dataset(ds, sd, body)
+    changed = [float((plain[k][1] - out[0][0][k][1]).abs().max()) for k in plain if out[0][1][k]["status"] == 1]
+    assert changed and max(changed) > 0.0                                          # the optimiser moved the optimised rows
 
 
 def test_full_mesh_and_cal_mpjpe(synth_assets):

@@ -150,13 +150,17 @@ def test_reprojection_residual(ops, pm):
 
 
 # --------------------------------------------------------------------------------------------- sub-net steps
+@pytest.mark.parametrize("split", [False, True], ids=["fp32mfma", "splitbf16"])
 @pytest.mark.parametrize("name", ["rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8"])
-def test_lstm_step_vs_torch(name, synth_assets):
-    """f(i, x) of one sub-net for 5 steps incl. a masked step, vs torch.nn.LSTM on the CPU (oracle module)."""
+def test_lstm_step_vs_torch(name, split, synth_assets):
+    """f(i, x) of one sub-net for 5 steps incl. a masked step, vs torch.nn.LSTM on the CPU (oracle module), in both product
+    arithmetics of the gate GEMM (rc_set_gemm_mode): fp32 MFMA and split-bf16 partial products."""
     from robustcap_amd import config as C, synth
     B = 37                                                      # ragged: not a multiple of the 32-row tile
     nin = {n: i for n, i, _, _ in C.NETS}[name]
     net = make_net(synth_assets, batch=B)
+    net.set_gemm_mode(split)
+    assert net.gemm_mode == int(split)
     ora = make_oracle(synth_assets, batch=B)
     for step in range(5):
         x = t(synth.normal(50 + step, 1, B * nin).reshape(B, nin))
@@ -183,13 +187,16 @@ def joint_positions(body, pose, tran):
     return ob.forward_kinematics(pose.reshape(-1, 24, 3, 3), tran.reshape(-1, 3))[1]
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32mfma", "splitbf16"])
 @pytest.mark.parametrize("path", SEQS, ids=[os.path.basename(p)[4:-4] for p in SEQS])
-def test_sequence_vs_reference_capture(path, synth_assets):
-    """forward_online (batch 1, frame by frame, like evaluate.py) against the REFERENCE's own outputs."""
+def test_sequence_vs_reference_capture(path, split, synth_assets):
+    """forward_online (batch 1, frame by frame, like evaluate.py) against the REFERENCE's own outputs, in both product
+    arithmetics of the GEMMs (batch-1 contexts default to the fp32 MFMA, batch >= 32 to the split-bf16 products)."""
     from oracle import sig_mp_oracle as O
     s = np.load(path)
     live = str(s["live"])
     net = make_net(synth_assets, 1, live_ctor=(live == "pre"))
+    net.set_gemm_mode(split)
     if live == "post":
         net.live = True
     net.use_flat_floor = bool(s["use_flat_floor"])

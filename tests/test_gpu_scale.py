@@ -15,6 +15,7 @@ def _net(assets, B):
     from robustcap_amd.net.sig_mp import Net
     n = Net(body=assets["body"], batch=B)
     n.load_state_dict(assets["state_dict"])
+    assert n.gemm_mode == (1 if B >= 32 else 0)           # split-bf16 products from batch 32 up
     return n
 
 
@@ -70,6 +71,7 @@ def test_config2_rows_equal_single_sequence_runs_and_oracle(cfg2, synth_assets):
     Tc = 96
     for b in (0, 77, 255):
         one = _net(synth_assets, 1)
+        one.set_gemm_mode(True)                           # the arithmetic of the 256-row context (batch-1 contexts default to fp32 MFMA)
         p1, t1 = _run(one, m, rows=slice(b, b + 1), T=Tc)
         assert torch.equal(p1[0], pose[b, :Tc]) and torch.equal(t1[0], tran[b, :Tc])    # row b == that sequence alone
     rows = [3, 200]
@@ -99,3 +101,34 @@ def test_config4_occluded_batch_1024(synth_assets):
     half = _net(synth_assets, 512)
     ph, th = _run(half, m, rows=slice(512, 1024), first_tran=False)
     assert torch.equal(ph, pose[512:]) and torch.equal(th, tran[512:])
+
+
+def test_strong_split_over_two_ranks_equals_one_rank():
+    """bench.py --scaling strong / dist.shard_range: 2 ranks (sharing this box's one GPU, gloo collective) run their row
+    blocks of ONE 37-body batch (19 + 18 rows), rank 0 gathers -- bitwise the 1-rank result; and the bench itself runs
+    in that mode under the launcher the driver uses."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return str(s.getsockname()[1])
+    env = dict(os.environ, RC_DIST_SHARE_DEVICE="1", RC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    r = subprocess.run(base + ["--master-port", port(), os.path.join(root, "tools", "strong_split_check.py"), "37", "40"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["bitwise_equal"] and d["world"] == 2 and d["blocks"] == [[0, 19], [19, 37]]
+    r = subprocess.run(base + ["--master-port", port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+                               "--scaling", "strong", "--batch", "37", "--no-variants"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_total"] == 37 and d["config"]["batch_per_gpu"] == 19
+    assert d["value"] > 0 and d["cpu_baseline"] is None

@@ -57,7 +57,7 @@ def test_wavefront_vs_reference_and_vs_frame_stepped(name, synth_assets):
     if "allvis" in name:
         assert wave >= T - 2 and ticks >= wave + 10                          # all but the sequence start ran skewed
     else:
-        assert 0 < wave < T and stepped > 100                                # long_mixed alternates between the engines
+        assert 0 < wave < T and stepped > 20                                 # long_mixed alternates between the engines
     assert torch.equal(wp, sp) and torch.equal(wt, st)                       # same tiles, same arithmetic
     rp, rt = t(s["pose"]), t(s["tran"])
     assert float((wt.cpu() - rt).abs().max()) <= 1e-4
