@@ -36,6 +36,9 @@ from robustcap_amd import dist as rdist  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA (16x16x4 / 32x32x2), dense
+PRODUCTS_SPLIT = ("fp32 operands split exactly into 3 bf16 terms each; every product = 6 partial products on "
+                  "v_mfma_f32_16x16x32_bf16 (all terms >= 2^-16 of the product), fp32 accumulation, fp32 gates / state")
+PRODUCTS_FP32 = "v_mfma_f32_16x16x4_f32 (fp32 operands, an fma chain per output element)"
 CPU_FRAMES_BATCHED = 16                # cpu_baseline sample: B x 16 frames batched + 96 frames batch-1 (~10-30 s)
 CPU_FRAMES_SINGLE = 96
 
@@ -115,7 +118,7 @@ def guarded(fn, *a, **k):
 class Workload:
     """One confidence schedule: inputs resident on the device, a context of this rank's rows, timed/instrumented runs."""
 
-    def __init__(self, sd, body, conf, B, W, K, rank, world, seed_base=2):
+    def __init__(self, sd, body, conf, B, W, K, rank, world, seed_base=2, split=None):
         from robustcap_amd.net.sig_mp import Net
         self.conf, self.B, self.W, self.K, self.rank, self.world = conf, B, W, K, rank, world
         self.m = make_inputs(body, B, W + K, conf, seed=seed_base + rank)
@@ -125,6 +128,9 @@ class Workload:
         self.ft = torch.from_numpy(self.m["first_tran"]).to(dev)
         self.net = Net(body=body, batch=B)
         self.net.load_state_dict(sd)
+        if split is not None:
+            self.net.set_gemm_mode(split)
+        self.split = bool(self.net.gemm_mode)
         self.net.gravityc = torch.from_numpy(self.m["gravityc"])
 
     def run(self, lo, hi, first):
@@ -197,7 +203,8 @@ class Workload:
         ach = flop_per_launch / avg_s / 1e12
         path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
         traffic, src = pmc_traffic(B, self.conf)
-        return {"bound": "mfma", "kernel": "rc_gemm_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+        return {"bound": "mfma", "kernel": "rc_gemm_split_kernel" if self.split else "rc_gemm_kernel", "achieved": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": (f"fabric-side L2 miss bytes per gate-GEMM launch, rocprofv3 PMC pass of this batch/schedule "
                                  f"(profiles/{src})" if src else
@@ -205,8 +212,12 @@ class Workload:
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches, "launches_per_step": round(launches / K, 2),
                 "flop_per_launch": flop_per_launch,
                 "path_achieved": round(path, 2), "path_frac": round(path / PEAK_FP32_MFMA_TFLOPS, 4),
-                "note": "frac: rc_gemm_kernel alone (its algorithmic FLOPs / its HIP-event time); path_frac: whole frame incl. "
-                        "the weight-streaming 16-row launches and the per-frame logic kernels"}
+                "products": PRODUCTS_SPLIT if self.split else PRODUCTS_FP32,
+                "note": "frac: the wide-tile gate-GEMM kernel alone (its algorithmic fp32 FLOPs / its HIP-event time) against the "
+                        "dense fp32-input MFMA peak, the peak of the type the path computes in; path_frac: whole frame incl. the "
+                        "weight-streaming 16-row launches and the per-frame logic kernels. With split-bf16 products the kernel "
+                        "issues 6 bf16 MFMAs per 16x16x32 block (2.7x fewer MFMA cycles than the fp32-input instruction): the "
+                        "fp32 MFMA roof no longer binds it, operand delivery L2 -> CU does (DESIGN.md section 3.1)"}
 
 
 def main():
@@ -244,14 +255,20 @@ def main():
     roof = guarded(main_w.roofline, dt, bodies_total) if rank == 0 else None
 
     variants = None
-    if not args.no_variants and args.conf != "high":
+    if not args.no_variants:
+        def variant(conf, split, what):
+            w = guarded(Workload, sd, body, conf, B, W, K, rank, world, 2, split)
+            dtv = w if isinstance(w, dict) else guarded(w.timed, strong_total)
+            return dtv if isinstance(dtv, dict) else {"value": round(bodies_total * K / dtv, 1), "ms_per_step": round(dtv / K * 1e3, 4),
+                                                      "workload": what}
         del main_w.j2d, main_w.acc, main_w.ori
-        hi_w = Workload(sd, body, "high", B, W, K, rank, world)
-        dt_hi = guarded(hi_w.timed, strong_total)
-        if rank == 0:
-            variants = {"high": dt_hi if isinstance(dt_hi, dict) else {
-                "value": round(bodies_total * K / dt_hi, 1), "ms_per_step": round(dt_hi / K * 1e3, 4),
-                "workload": "SURVEY.md 8(d) config 2a: every frame visible (c >= 0.8), same batch and frame count"}}
+        v = {}
+        if args.conf != "high":
+            v["high"] = variant("high", None, "SURVEY.md 8(d) config 2a: every frame visible (c >= 0.8), same batch and frame count")
+        if main_w.split:
+            v["fp32_mfma"] = variant(args.conf, False, "the main workload with the products on the fp32-input MFMA instead of the "
+                                                      "split-bf16 partial products (rc_set_gemm_mode 0): bitwise fma chains")
+        variants = v if rank == 0 else None
 
     if rank == 0:
         cpu = None
@@ -263,6 +280,7 @@ def main():
             "metric": "body-frames/sec (sig_mp fwd + FK) at batch 256", "value": round(value, 1), "unit": "body-frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "products": PRODUCTS_SPLIT if main_w.split else PRODUCTS_FP32,
             "config": {"workload": f"synthetic 60 fps, 6 IMU + 33 keypoints, batch {B} x {K} frames per GPU "
                                    f"({bodies_total} bodies in total, {args.scaling} scaling), "
                                    f"confidence schedule '{args.conf}', seeded random weights (63.4 M params)",

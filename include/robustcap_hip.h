@@ -173,6 +173,14 @@ int rc_normalize_rows(const float* x, float* out, float* norm, int64_t rows, int
 /* Keypoint normalisation of forward_online (net/sig_mp.py:150-152 with get_bbox_scale L277-284): kp[n,33,3] -> out[n,33,3]
  * (xy / max(bbox width, height), rows != 23 relative to row 23, confidence copied). */
 int rc_bbox_normalise(const float* kp, float* out, int64_t n, void* stream);
+/* Shape blendshapes of ParametricModel.get_zero_pose_joint_and_vertex(shape) (articulate/model.py:88-91), before its root
+ * alignment: verts_out[V,3] = tensordot(beta, shapedirs) + v_template, joints_out[24,3] = J_regressor . verts_out. All
+ * pointers HOST (v_template[V,3], shapedirs[V,3,10], J_regressor[24,V] dense, beta[10]); computed on the device,
+ * synchronous. The caller hands the shaped joints / landmark vertices to rc_set_body (and the vertices to rc_set_mesh):
+ * every entry point of the context then works on the shaped body, which is how forward_kinematics(shape=...) and
+ * smplify_runner(shape=...) are served (one shape per context, as TemporalSMPLify holds one per sequence). */
+int rc_shape_body(rc_ctx* ctx, const float* v_template, const float* shapedirs, const float* J_regressor, const float* beta,
+                  int32_t V, float* verts_out, float* joints_out);
 /* ParametricModel.forward_kinematics_R (articulate/math/spatial.py:170-194): Rl[n,24,3,3] local -> Rg[n,24,3,3] global. */
 int rc_fk_r(rc_ctx* ctx, const float* Rlocal, float* Rglobal, int64_t n, void* stream);
 /* ParametricModel.bone_vector_to_joint_position / joint_position_to_bone_vector (spatial.py:126-167): [n,24,3] both. */
@@ -248,6 +256,12 @@ int rc_smplify_set_prior(rc_ctx* ctx, const float* means_host, const float* prec
  * Synchronises `stream`. */
 int rc_smplify_loss_grad(rc_ctx* ctx, const float* x, const float* kp, const float* ref3d, const float* imu_aa,
                          const float* K_host, int64_t T, double* loss_host, float* grad, void* stream);
+
+/* With shape=..., the reference keeps the preserved 3D landmarks of the INITIAL prediction on the MEAN-shape body
+ * (temporal_smplify.py:112 calls forward_kinematics without shape) while everything else uses the shaped body. A context
+ * holds one body, so the caller computes those landmarks on a mean-shape model and hands them over: ref3d DEVICE [T,33,3],
+ * used by the NEXT rc_smplify_run instead of the landmarks of the context's own body (then forgotten); NULL cancels. */
+int rc_smplify_set_ref3d(rc_ctx* ctx, const float* ref3d);
 
 typedef struct rc_smplify_info {
     int32_t status;          /* 0: rejected by the pre-check (run.py:27-29), 1: optimised */

@@ -58,10 +58,10 @@ def _write_body_pickle(path, body):
     kin = np.stack([np.where(body["parent"] < 0, 2 ** 32 - 1, body["parent"]).astype(np.int64),
                     np.arange(24, dtype=np.int64)])
     data = {
-        "J_regressor": scipy.sparse.csc_matrix(np.zeros((24, V))),
+        "J_regressor": scipy.sparse.csc_matrix(np.asarray(body.get("J_regressor", np.zeros((24, V))), np.float64)),
         "weights": body["weights"].astype(np.float64),
         "posedirs": np.zeros((V, 3, 207), np.float32),
-        "shapedirs": np.zeros((V, 3, 10), np.float32),
+        "shapedirs": np.asarray(body.get("shapedirs", np.zeros((V, 3, 10))), np.float32),
         "v_template": body["v_template"].astype(np.float64),
         "J": body["J"].astype(np.float64),
         "f": np.zeros((1, 3), np.int64),
@@ -125,6 +125,13 @@ def capture_ops(art, sig_mp, body):
     g["fk_j33"] = torch.stack([sig_mp.sync_mp3d(vert[i], joint[i]) for i in range(N)]).numpy()
     import utils as ref_utils
     assert torch.equal(ref_utils.sync_mp3d_from_smpl(vert, joint), t(g["fk_j33"]))
+    # the same with shape blendshapes (model.py:88-92, 228-229): one beta for all frames, as TemporalSMPLify(shape=...) passes it
+    beta = (2.0 * synth.uniform01(14, 9, 10) - 1.0).astype(np.float32)
+    js, vs = bm.get_zero_pose_joint_and_vertex(t(beta.copy()).view(1, 10))
+    grot_s, joint_s, vert_s = bm.forward_kinematics(t(pose.copy()), shape=t(beta.copy()).view(1, 10).expand(N, 10), tran=t(tran.copy()), calc_mesh=True)
+    g["shape_beta"], g["shape_j0"], g["shape_v0_extra"] = beta, js[0].numpy(), vs[0][extra].numpy()
+    g["shape_joint"], g["shape_vert_extra"] = joint_s.numpy(), vert_s[:, extra].numpy()
+    g["shape_j33"] = torch.stack([sig_mp.sync_mp3d(vert_s[i], joint_s[i]) for i in range(N)]).numpy()
     # bbox normalisation (sig_mp.py:150-152 with get_bbox_scale L277-284)
     kp = (synth.uniform01(15, 0, N * 99)).reshape(N, 33, 3).astype(np.float32)
     kp[..., :2] = kp[..., :2] - 0.5

@@ -104,6 +104,18 @@ def main():
     loss_h.backward()
     g.update(evh_loss=np.float64(loss_h.item()), evh_grad_pose=bph.grad.numpy().copy(), evh_grad_tran=tnh.grad.numpy().copy(),
              evh_residual=fit_h.get_fitting_loss(pose_h.detach(), tnh.detach(), kp.clone()).numpy())
+    # the same evaluation on a SHAPED body (temporal_smplify.py:84-86,158-159): every landmark of the closure and of the
+    # residual uses shape=beta, while the preserved 3D landmarks ref3d stay those of the mean shape (temporal_smplify.py:112)
+    beta = t((2.0 * synth.uniform01(14, 9, 10) - 1.0).astype(np.float32))
+    fit_s = ts.TemporalSMPLify(cam_k=K, imu_ori=t(m["oric"][0]), step_size=1e-3, batch_size=T, shape=beta.view(1, 10).expand(T, 10))
+    bps, tns = bp.detach().clone().requires_grad_(True), tn.detach().clone().requires_grad_(True)
+    pose_s = ts.batch_rodrigues(bps.view(-1, 3)).view(T, 24, 3, 3)
+    gps, js, vs = ts.body_model.forward_kinematics(pose=pose_s, tran=tns, calc_mesh=True, shape=fit_s.shape)
+    mjs = ref_utils.sync_mp3d_from_smpl(vs, js)
+    loss_s = losses.temporal_body_fitting_loss(bps, mjs, kp[:, :, :2], conf, fit_s.pose_prior, fit_s.cam_k, ref3d, fit_s.imu_ori, gps[:, [ts.joint_mask]])
+    loss_s.backward()
+    g.update(evs_beta=beta.numpy(), evs_loss=np.float64(loss_s.item()), evs_grad_pose=bps.grad.numpy().copy(), evs_grad_tran=tns.grad.numpy().copy(),
+             evs_residual=fit_s.get_fitting_loss(pose_s.detach(), tns.detach(), kp.clone()).numpy())
     prior = fit.pose_prior(bp.detach()[:, 3:], None)
     g["ev_prior"] = prior.numpy()
     print("closure: loss %.6g |g_pose| %.4g |g_tran| %.4g" % (loss.item(), bp.grad.abs().max(), tn.grad.abs().max()))

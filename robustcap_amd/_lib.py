@@ -66,6 +66,7 @@ SIGNATURES = {
     "rc_lerp": (_I32, [_P, _P, C.c_double, _P, _I64, _P]),
     "rc_normalize_rows": (_I32, [_P, _P, _P, _I64, _I32, _P]),
     "rc_bbox_normalise": (_I32, [_P, _P, _I64, _P]),
+    "rc_shape_body": (_I32, [_P, _P, _P, _P, _P, _I32, _P, _P]),
     "rc_fk_r": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_bone_to_joint": (_I32, [_P, _P, _P, _I64, _P]),
     "rc_joint_to_bone": (_I32, [_P, _P, _P, _I64, _P]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "rc_set_ignored_landmarks": (_I32, [_P, _P, _I32]),
     "rc_reproj_residual": (_I32, [_P, _P, _P, _P, _P, _F, _P, _I64, _P]),
     "rc_smplify_set_prior": (_I32, [_P, _P, _P, _P]),
+    "rc_smplify_set_ref3d": (_I32, [_P, _P]),
     "rc_smplify_loss_grad": (_I32, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_double), _P, _P]),
     "rc_smplify_run": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _F, _I32, _F, _P, _P, _P, C.POINTER(RcSmplifyInfo), _P]),
     "rc_lbfgs_minimize": (_I32, [OBJECTIVE_FN, _P, _I64, C.POINTER(C.c_double), C.c_double, _I32, _I32, _I32, C.c_double,

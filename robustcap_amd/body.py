@@ -22,8 +22,13 @@ def load_smpl_pickle(path):
         data = pickle.load(f, encoding="latin1")
     parent = np.asarray(data["kintree_table"][0]).astype(np.int64).copy()
     parent[0] = -1
-    return {"J": np.asarray(data["J"], np.float32), "v_template": np.asarray(data["v_template"], np.float32),
+    body = {"J": np.asarray(data["J"], np.float32), "v_template": np.asarray(data["v_template"], np.float32),
             "weights": np.asarray(data["weights"], np.float32), "parent": parent}
+    if "shapedirs" in data and "J_regressor" in data:                      # only needed for shape=... (model.py:33-35)
+        jr = data["J_regressor"]
+        body["J_regressor"] = np.asarray(jr.toarray() if hasattr(jr, "toarray") else jr, np.float32)
+        body["shapedirs"] = np.asarray(data["shapedirs"], np.float32)[:, :, :10]
+    return body
 
 
 def body_arrays(body):
@@ -34,6 +39,28 @@ def body_arrays(body):
     return (np.ascontiguousarray(parent), np.ascontiguousarray(body["J"], dtype=np.float32),
             np.ascontiguousarray(np.asarray(body["weights"], np.float32)[ids]),
             np.ascontiguousarray(np.asarray(body["v_template"], np.float32)[ids]))
+
+
+def shaped_body(ctx, body, shape):
+    """The body dict with the shape blendshapes applied: v = shapedirs . beta + v_template, J = J_regressor . v
+    (articulate/model.py:88-91; the root alignment happens in rc_set_body like for the mean shape). ``shape``: 10 betas, or
+    [n,10] with identical rows (one shape per context). Computed on the device (rc_shape_body)."""
+    beta = torch.as_tensor(shape, dtype=torch.float32).detach().cpu().reshape(-1, 10)
+    if not bool((beta == beta[:1]).all()):
+        raise NotImplementedError("one shape per model / sequence: the rows of `shape` must be identical")
+    if "shapedirs" not in body or "J_regressor" not in body:
+        raise ValueError("this body has no shapedirs / J_regressor (needed for shape=...)")
+    vt = np.ascontiguousarray(body["v_template"], dtype=np.float32)
+    sd = np.ascontiguousarray(np.asarray(body["shapedirs"], np.float32)[:, :, :10])
+    jr = np.ascontiguousarray(body["J_regressor"], dtype=np.float32)
+    b = np.ascontiguousarray(beta[0].numpy())
+    V = vt.shape[0]
+    v, j = np.empty((V, 3), np.float32), np.empty((24, 3), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(ctx, _lib.load().rc_shape_body(ctx, p(vt), p(sd), p(jr), p(b), V, p(v), p(j)), "rc_shape_body")
+    out = dict(body)
+    out["v_template"], out["J"] = v, j
+    return out
 
 
 def set_body(ctx, body):
@@ -55,6 +82,8 @@ class ParametricModel:
         if use_pose_blendshape:
             raise NotImplementedError("pose blendshapes are off on the sig_mp path (model.py:237, default False)")
         self._body = body if body is not None else load_smpl_pickle(official_model_file)
+        self._mean_body = self._body
+        self._shape_key = None
         self.parent = [None] + [int(p) for p in self._body["parent"][1:]]
         self.device = torch.device(device)
         self._lib = _lib.load()
@@ -66,6 +95,19 @@ class ParametricModel:
         if getattr(self, "_ctx", None):
             self._lib.rc_destroy(self._ctx)
             self._ctx = None
+
+    def set_shape(self, shape=None):
+        """Switch the model to the body of these shape parameters (None = mean shape): every method then works on it.
+        The reference passes ``shape`` per call (model.py:209-229); here it is a state of the context (rc_set_body)."""
+        key = None if shape is None else torch.as_tensor(shape, dtype=torch.float32).detach().cpu().reshape(-1, 10)[0].numpy().tobytes()
+        if key == self._shape_key:
+            return
+        self._body = self._mean_body if shape is None else shaped_body(self._ctx, self._mean_body, shape)
+        set_body(self._ctx, self._body)
+        self._shape_key = key
+        if self.__dict__.get("_mesh_set"):
+            self._mesh_set = False
+            self._ensure_mesh()
 
     def inverse_kinematics_R(self, R_global):
         Rg = _f32c(R_global, self.device).view(-1, 24, 3, 3)
@@ -96,8 +138,7 @@ class ParametricModel:
 
     def get_zero_pose_joint_and_vertex(self, shape=None):
         """articulate/model.py:78-93 for the mean shape: (joints [24,3], vertices [V,3]), root joint at the origin."""
-        if shape is not None:
-            raise NotImplementedError("shape=None (mean shape) on this path, model.py:86-87")
+        self.set_shape(shape)
         self._ensure_mesh()
         j = torch.empty(24, 3, device=self.device)
         v = torch.empty(self._V, 3, device=self.device)
@@ -114,8 +155,7 @@ class ParametricModel:
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
         """(global rotations, joints[, landmarks]). With ``calc_mesh`` the third output is the 33-landmark set
         ``sync_mp3d(vert, joint)`` -- the only part of the 6890-vertex mesh the path consumes."""
-        if shape is not None:
-            raise NotImplementedError("shape=None (mean shape) on this path, model.py:86-87")
+        self.set_shape(shape)                                           # one shape for all frames (model.py:228)
         pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
         n = pose.shape[0]
         tran = torch.zeros(n, 3, device=self.device) if tran is None else _f32c(tran, self.device).view(n, 3)

@@ -354,11 +354,11 @@ GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     return p;
 }
 
-int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st) {
+int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st, bool fp32 = false) {
     if (ps.empty()) return RC_OK;
     GemmLaunch L{};
     L.B = ctx->B;
-    L.split = ctx->gemm_split ? 1 : 0;
+    L.split = (ctx->gemm_split && !fp32) ? 1 : 0;
     // XCD-aligned problems first so that (block id % 8) is the XCD for them
     std::vector<GemmProblem> ordered;
     for (auto& p : ps) if ((p.n_tiles & 7) == 0) ordered.push_back(p);
@@ -392,7 +392,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     return RC_OK;
 }
 
-int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const std::vector<GemmProblem>* extra, hipStream_t st) {
+int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const std::vector<GemmProblem>* extra, hipStream_t st, bool fp32 = false) {
     for (int phase = 0; phase < (with_lin2 ? 4 : 3); ++phase) {
         std::vector<GemmProblem> ps;
         for (const Stage& s : nets) {
@@ -401,7 +401,7 @@ int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const
             else ps.push_back(lstm_problem(ctx, s, phase - 1));
         }
         if (extra && phase < (int)extra->size()) ps.push_back((*extra)[phase]);
-        if (int rc = launch_problems(ctx, ps, nullptr, st)) return rc;
+        if (int rc = launch_problems(ctx, ps, nullptr, st, fp32)) return rc;
     }
     return RC_OK;
 }
@@ -430,7 +430,10 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
         Stage t6{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         Stage t4{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         t6.rows_hint = t4.rows_hint = 8;  // regime changes: a handful of rows per frame -> narrow tiles
-        if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st)) return rc;
+        // Weight-streaming launches: always on the fp32 weights (4 B instead of the 6 B of the three bf16 planes). Which
+        // rows take this launch depends on each row's own regime history only, so a row's result stays independent of the
+        // batch it runs in.
+        if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st, true)) return rc;
     }
     // inertial pose branch (L144) + visual pose branch (L153); rnn4 also takes the rows whose deferred updater
     // step is still pending and that do not step on camera keypoints this frame (they read x4l)
@@ -467,7 +470,7 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
     const FrameBuffers& fb = ctx->fb;
     rc_launch_flush_flags(fb, ctx->B, st);
     return run_stage(ctx, {Stage{N6, (int)RC_ROW2_FLUSH, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2},
-                           Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st);
+                           Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st, true);
 }
 
 // ====================================================================================== sequence mode (wavefront)
@@ -535,7 +538,7 @@ int ensure_sequence_buffers(rc_ctx* ctx) {
 // Tile shapes (batch >= 128; smaller batches keep pick_tile's choice): rnn4 / rnn6 as in the frame-stepped launches,
 // H = 512 nets 64 x 64 (4 x 4 blocks): 128 workgroups per layer-step, four layer-steps per launch = two full rounds.
 int build_tick_problems(rc_ctx* ctx) {
-    int t4[2] = {2, 10}, t6[2] = {2, 8}, t5[2] = {4, 4};
+    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 4};
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
@@ -710,6 +713,13 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     if (hipEventCreateWithFlags(&ctx->eager_ev, hipEventDisableTiming) != hipSuccess) ctx->eager_ev = nullptr;
     rc_default_params(live, &ctx->prm);
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= 32 ? 1 : 0) != 0;
+    // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
+    // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
+    // only lengthens the launch). 64-row tiles halve the weight bytes a CU pulls per product -- with the MFMA time cut 2.7x
+    // the K loop is operand-bound -- and the number of tile prologues / reductions / epilogues.
+    ctx->tile4[0] = 4; ctx->tile4[1] = 5;
+    ctx->tile6[0] = 4; ctx->tile6[1] = 8;
+    ctx->tile378[0] = 4; ctx->tile378[1] = 4;
     tile_env("RC_TILE_RNN6", &ctx->tile6[0], &ctx->tile6[1]);
     tile_env("RC_TILE_S2H512", &ctx->tile378[0], &ctx->tile378[1]);
     tile_env("RC_TILE_RNN2", &ctx->tile2[0], &ctx->tile2[1]);
@@ -1199,6 +1209,30 @@ int rc_zero_pose(rc_ctx* ctx, float* joint, float* vert, void* stream) {
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
 }
+int rc_shape_body(rc_ctx* ctx, const float* v_template, const float* shapedirs, const float* J_regressor, const float* beta,
+                  int32_t V, float* verts_out, float* joints_out) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (!v_template || !shapedirs || !J_regressor || !beta || !verts_out || !joints_out || V < 1)
+        return fail(ctx, RC_ERR_INVALID, "rc_shape_body: bad argument");
+    const size_t n = (size_t)V;
+    float *vt = nullptr, *sd = nullptr, *jr = nullptr, *bt = nullptr, *v = nullptr, *j = nullptr;
+    int rc = RC_OK;
+    auto up = [&](float** d, const float* h, size_t count) {
+        if (rc) return;
+        if (hipMalloc((void**)d, count * sizeof(float)) != hipSuccess || (h && hipMemcpy(*d, h, count * sizeof(float), hipMemcpyHostToDevice) != hipSuccess))
+            rc = fail(ctx, RC_ERR_HIP, "rc_shape_body: device buffer");
+    };
+    up(&vt, v_template, n * 3); up(&sd, shapedirs, n * 30); up(&jr, J_regressor, n * 24); up(&bt, beta, 10);
+    up(&v, nullptr, n * 3); up(&j, nullptr, 72);
+    if (!rc) {
+        rc_launch_shape_body(vt, sd, bt, jr, V, v, j, nullptr);
+        if (hipMemcpy(verts_out, v, n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(joints_out, j, 72 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, RC_ERR_HIP, "rc_shape_body: read back");
+    }
+    for (float* q : {vt, sd, jr, bt, v, j}) if (q) (void)hipFree(q);
+    return rc;
+}
 int rc_ik_r(rc_ctx* ctx, const float* Rg, float* Rl, int64_t n, void* stream) {
     if (!ctx || !ctx->have_body) return ctx ? fail(ctx, RC_ERR_STATE, "rc_ik_r: body not set") : RC_ERR_INVALID;
     rc_launch_ik(ctx->body, Rg, Rl, n, (hipStream_t)stream);
@@ -1220,8 +1254,11 @@ int rc_body_fk(rc_ctx* ctx, const float* pose, const float* tran, float* grot, f
 }
 int rc_set_mesh(rc_ctx* ctx, const float* vt, const float* w, int32_t V) {
     if (!ctx || !vt || !w || V <= 0) return RC_ERR_INVALID;
-    if (int rc = dev_alloc(ctx, &ctx->mesh_vt, (size_t)V * 3, false)) return rc;
-    if (int rc = dev_alloc(ctx, &ctx->mesh_w, (size_t)V * 24, false)) return rc;
+    if (ctx->mesh_V != V) {                                 // a second call with the same V (shape change) reuses the buffers
+        if (int rc = dev_alloc(ctx, &ctx->mesh_vt, (size_t)V * 3, false)) return rc;
+        if (int rc = dev_alloc(ctx, &ctx->mesh_w, (size_t)V * 24, false)) return rc;
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());                    // nothing in flight may still read the old mesh
     HIP_TRY(ctx, hipMemcpy(ctx->mesh_vt, vt, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->mesh_w, w, (size_t)V * 24 * sizeof(float), hipMemcpyHostToDevice));
     ctx->mesh_V = V;

@@ -154,6 +154,7 @@ void rc_launch_r6d(const float* r6d, float* R, long long n, hipStream_t s);
 struct CamConst { float Kinv[9]; float R[9]; };
 void rc_launch_camera_inputs(const float* kp, const float* acc, const float* ori, const CamConst& cam, float* j2dc, float* accc,
                              float* oric, long long n, hipStream_t s);
+void rc_launch_shape_body(const float* vt, const float* sd, const float* beta, const float* Jr, int V, float* v, float* j, hipStream_t s);
 void rc_launch_fk_r(const BodyConst* body, const float* Rl, float* Rg, long long n, hipStream_t s);
 void rc_launch_bone_to_joint(const BodyConst* body, const float* bone, float* joint, long long n, hipStream_t s);
 void rc_launch_joint_to_bone(const BodyConst* body, const float* joint, float* bone, long long n, hipStream_t s);

@@ -113,7 +113,35 @@ __global__ __launch_bounds__(64) void rc_bbox_normalise_kernel(const float* kp, 
     if (lane < 33) { out[(b * 33 + lane) * 3] = xn; out[(b * 33 + lane) * 3 + 1] = yn; out[(b * 33 + lane) * 3 + 2] = cf; }
 }
 
+// get_zero_pose_joint_and_vertex(shape) before the root alignment (articulate/model.py:88-91):
+//   v = tensordot(shape, shapedirs) + v_template  (one thread per vertex coordinate, 10 blend directions)
+//   j = J_regressor . v                           (one workgroup per (joint, coordinate), reduced over the V vertices)
+__global__ void rc_shape_vertices_kernel(const float* __restrict__ vt, const float* __restrict__ sd, const float* __restrict__ beta,
+                                         int V, float* v) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * V) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < 10; ++b) acc += beta[b] * sd[(long long)idx * 10 + b];
+    v[idx] = acc + vt[idx];
+}
+__global__ __launch_bounds__(256) void rc_shape_joints_kernel(const float* __restrict__ Jr, const float* __restrict__ v, int V, float* j) {
+    __shared__ float part[4];
+    const int joint = blockIdx.x / 3, c = blockIdx.x % 3;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < V; k += 256) acc += Jr[(long long)joint * V + k] * v[3 * k + c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) j[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 static inline unsigned blocks_of(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+void rc_launch_shape_body(const float* vt, const float* sd, const float* beta, const float* Jr, int V, float* v, float* j, hipStream_t st) {
+    hipLaunchKernelGGL(rc_shape_vertices_kernel, dim3(blocks_of(3ll * V, 256)), dim3(256), 0, st, vt, sd, beta, V, v);
+    hipLaunchKernelGGL(rc_shape_joints_kernel, dim3(72), dim3(256), 0, st, Jr, v, V, j);
+}
 
 void rc_launch_fk_r(const BodyConst* body, const float* Rl, float* Rg, long long n, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(rc_fk_r_kernel, dim3((unsigned)n), dim3(64), 0, st, body, Rl, Rg);

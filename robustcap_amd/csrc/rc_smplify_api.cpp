@@ -26,6 +26,7 @@ struct SmplifyState {
     float *h_x = nullptr, *h_grad = nullptr, *h_terms = nullptr, *h_res = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double device_ms = 0.0;
+    const float* ref3d_override = nullptr;                            // rc_smplify_set_ref3d: caller-owned [T,33,3], next run only
 };
 
 namespace {
@@ -138,6 +139,14 @@ int rc_smplify_set_prior(rc_ctx* ctx, const float* means, const float* prec, con
     return RC_OK;
 }
 
+int rc_smplify_set_ref3d(rc_ctx* ctx, const float* ref3d) {
+    if (!ctx) return RC_ERR_INVALID;
+    SmplifyState* s = nullptr;
+    if (int rc = state_of(ctx, &s)) return rc;
+    s->ref3d_override = ref3d;
+    return RC_OK;
+}
+
 int rc_smplify_loss_grad(rc_ctx* ctx, const float* x, const float* kp, const float* ref3d, const float* imu_aa, const float* K,
                          int64_t T, double* loss, float* grad, void* stream) {
     if (!ctx) return RC_ERR_INVALID;
@@ -202,7 +211,12 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
     rc_launch_R2aa(pose, s->x, T * 24, st);                                            // body_pose = axis-angle of the prediction
     SM_TRY(ctx, hipMemcpyAsync(s->x + T * 72, tran, (size_t)T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     rc_launch_R2aa(imu_ori, s->imu_aa, T * 6, st);
-    rc_launch_body_fk(body, pose, tran, nullptr, s->joint, s->ref3d, T, st);          // preserved 3D landmarks
+    if (s->ref3d_override) {                                                           // see rc_smplify_set_ref3d
+        SM_TRY(ctx, hipMemcpyAsync(s->ref3d, s->ref3d_override, (size_t)T * 99 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        s->ref3d_override = nullptr;
+    } else {
+        rc_launch_body_fk(body, pose, tran, nullptr, s->joint, s->ref3d, T, st);      // preserved 3D landmarks
+    }
     SM_TRY(ctx, hipMemcpyAsync(s->h_x, s->x, (size_t)T * 75 * sizeof(float), hipMemcpyDeviceToHost, st));
     SM_TRY(ctx, hipStreamSynchronize(st));
 

@@ -44,8 +44,14 @@ def prior_arrays(gmm):
 class TemporalSMPLify:
     """Device-side optimiser state: body constants, pose prior, work buffers (reused across sequences)."""
 
-    def __init__(self, body=None, smpl_file=None, gmm=None, gmm_file=None, device="cuda", use_head=False):
+    def __init__(self, body=None, smpl_file=None, gmm=None, gmm_file=None, device="cuda", use_head=False, shape=None):
+        """``shape`` (10 betas, or [T,10] with identical rows; temporal_smplify.py:84-86): the body every closure evaluation,
+        residual and landmark of this optimiser uses (``set_shape`` switches it later, None = mean shape)."""
         self.model = _body.ParametricModel(smpl_file, device=device, body=body)
+        self._shaped, self._mean_model = False, None
+        if shape is not None:
+            self.model.set_shape(shape)
+            self._shaped = True
         self.device = self.model.device
         self._lib, self._ctx = self.model._lib, self.model._ctx
         self.has_prior = False
@@ -54,6 +60,10 @@ class TemporalSMPLify:
         if gmm is not None or gmm_file is not None:
             self.set_prior(gmm if gmm is not None else load_gmm_pickle(gmm_file))
         self.last_info = None
+
+    def set_shape(self, shape=None):
+        self.model.set_shape(shape)
+        self._shaped = shape is not None
 
     def set_use_head(self, use_head):
         """temporal_smplify.py:92-94: the landmarks whose confidence is zeroed -- face + feet tips {1..9, 31, 32}, or only
@@ -101,6 +111,13 @@ class TemporalSMPLify:
         pose_out, tran_out = torch.empty_like(pose), torch.empty_like(tran)
         update = np.zeros(T, dtype=np.uint8)
         info = _lib.RcSmplifyInfo()
+        ref3d = None
+        if self._shaped:     # reference quirk: the preserved 3D landmarks come from the MEAN-shape body (temporal_smplify.py:112)
+            if self._mean_model is None:
+                self._mean_model = _body.ParametricModel(device=dev, body=self.model._mean_body)
+            ref3d = self._mean_model.forward_kinematics(pose, tran=tran, calc_mesh=True)[2].contiguous()
+            torch.cuda.current_stream().synchronize()
+            _lib.check(self._ctx, self._lib.rc_smplify_set_ref3d(self._ctx, _lib.ptr(ref3d)), "rc_smplify_set_ref3d")
         rc = self._lib.rc_smplify_run(self._ctx, _lib.ptr(pose), _lib.ptr(tran), _lib.ptr(kp), _lib.ptr(ori), K.ctypes.data_as(C.c_void_p),
                                       T, C.c_float(lr), int(max_iter), C.c_float(loss_threshold), _lib.ptr(pose_out), _lib.ptr(tran_out),
                                       update.ctypes.data_as(C.c_void_p), C.byref(info), _lib.stream_ptr())
@@ -120,12 +137,16 @@ def smplify_runner(pred_pose, pred_tran, j2dc, imu_ori, batch_size, cam_k, lr=1.
     cam_k [3,3]. Returns (pose [T,24,3,3] cpu, tran [T,3] cpu, update) with update None if the sequence failed the
     pre-check. ``runner`` (a TemporalSMPLify with the prior set) is reused across calls; otherwise ``body`` and
     ``gmm`` build one."""
-    if shape is not None:
-        raise NotImplementedError("shape= is outside the built path (mean shape only, articulate/model.py:86-87)")
-    if not use_lbfgs or opt_steps != 1:
-        raise NotImplementedError("the reference only runs use_lbfgs=True, opt_steps=1 (evaluate.py:89)")
+    if not use_lbfgs:
+        # The reference's own Adam branch cannot run: temporal_smplify.py:171-175 hands the [T,72] axis-angle parameters to
+        # forward_kinematics as if they were rotation matrices (view(T,-1,3,3) -> 8 "joints") and torch.cat raises
+        # "Sizes of tensors must match" (verified on the imported reference, DESIGN.md section 8). Nothing to be equal to.
+        raise NotImplementedError("use_lbfgs=False raises inside the reference itself (temporal_smplify.py:171-175); only L-BFGS is built")
+    if opt_steps != 1:
+        raise NotImplementedError("the reference only runs opt_steps=1 (evaluate.py:89)")
     runner = runner or TemporalSMPLify(body=body, gmm=gmm)
     runner.set_use_head(use_head)
+    runner.set_shape(shape)                                       # temporal_smplify.py:84-86,158-159: None = mean shape
     if not runner.has_prior:
         raise _lib.RobustcapLibraryError("smplify_runner needs the GMM pose prior (gmm= or TemporalSMPLify.set_prior)")
     T = int(batch_size)

@@ -122,7 +122,16 @@ def make_body(seed=1, num_vertex=6890):
     np.add.at(w, (idx, gp), rest[:, 1].astype(np.float32))
     np.add.at(w, (idx, other), rest[:, 2].astype(np.float32))
     w = (w / w.sum(1, keepdims=True)).astype(np.float32)
-    return {"J": J, "v_template": v.astype(np.float32), "weights": w, "parent": parent}
+    # shape blendshapes and joint regressor (articulate/model.py:33-35, used only with shape=...): seeded directions of a
+    # few centimetres per unit beta; every regressor row is a convex combination of 24 seeded vertices. (Like the official
+    # model, J is what the model file stores; with shape=None the regressor is never applied, model.py:86.)
+    sd = (0.015 * normal(seed, 8, V * 30)).reshape(V, 3, 10).astype(np.float32)
+    Jr = np.zeros((24, V), np.float32)
+    for j in range(24):
+        ids = (uniform01(seed, 20 + j, 24).astype(np.float64) * V).astype(np.int64) % V
+        ww = uniform01(seed, 60 + j, 24).astype(np.float64) + 0.1
+        np.add.at(Jr[j], ids, (ww / ww.sum()).astype(np.float32))
+    return {"J": J, "v_template": v.astype(np.float32), "weights": w, "parent": parent, "shapedirs": sd, "J_regressor": Jr}
 
 
 # ------------------------------------------------------------------------------------------------------ motion

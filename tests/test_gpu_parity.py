@@ -133,6 +133,27 @@ def test_model_surface_vs_reference_vectors(ops, pm, synth_assets):
     assert maxdiff(ang, want) <= 2e-4                                                        # float32 products near pi
 
 
+def test_shaped_body_vs_reference_vectors(ops, synth_assets):
+    """forward_kinematics(shape=...) / get_zero_pose_joint_and_vertex(shape) (articulate/model.py:88-92, 209-241): shape
+    blendshapes + joint regressor on the device (rc_shape_body), then the ordinary kernels on the shaped constants."""
+    from robustcap_amd.body import ParametricModel
+    model = ParametricModel(body=synth_assets["body"])
+    beta = t(ops["shape_beta"])
+    j0, v0 = model.get_zero_pose_joint_and_vertex(beta)
+    ids = [int(i) for i in ops["fk_vert_extra_ids"]]
+    assert maxdiff(j0, ops["shape_j0"]) <= 1e-6 and maxdiff(v0[ids], ops["shape_v0_extra"]) <= 1e-6
+    N = ops["fk_pose"].shape[0]
+    G, J, L = model.forward_kinematics(t(ops["fk_pose"]), shape=beta.view(1, 10).expand(N, 10), tran=t(ops["fk_tran"]), calc_mesh=True)
+    assert maxdiff(J, ops["shape_joint"]) <= 2e-6 and maxdiff(L, ops["shape_j33"]) <= 2e-6
+    assert maxdiff(model.forward_mesh(t(ops["fk_pose"]), t(ops["fk_tran"]))[:, ids], ops["shape_vert_extra"]) <= 2e-6
+    assert maxdiff(J, ops["fk_joint"]) > 1e-3                                              # the shape really moved the joints
+    G0, J0, L0 = model.forward_kinematics(t(ops["fk_pose"]), tran=t(ops["fk_tran"]), calc_mesh=True)   # shape=None: mean body again
+    assert maxdiff(J0, ops["fk_joint"]) <= 2e-6 and maxdiff(L0, ops["fk_j33"]) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        two = torch.stack([beta, beta + 0.1])
+        model.forward_kinematics(t(ops["fk_pose"][:2]), shape=two)
+
+
 def test_body_fk_landmarks(ops, pm):
     G, J, L = pm.forward_kinematics(t(ops["fk_pose"]), tran=t(ops["fk_tran"]), calc_mesh=True)
     assert maxdiff(G, ops["fk_grot"]) <= 2e-6

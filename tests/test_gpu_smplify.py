@@ -60,6 +60,32 @@ def test_use_head_variant_matches_reference_capture(g, synth_assets):
     assert abs(loss0 - float(g["ev_loss"])) <= 1e-5 * abs(float(g["ev_loss"]))
 
 
+def test_shape_variant_matches_reference_capture(g, synth_assets):
+    """shape=... (temporal_smplify.py:84-86,158-159,211-216): closure loss / gradient and the residual on the shaped body
+    against the reference's own autograd; ref3d stays the mean-shape landmarks the reference preserves (L112)."""
+    from robustcap_amd.smplify import TemporalSMPLify
+    beta = t(g["evs_beta"])
+    r = TemporalSMPLify(body=synth_assets["body"], gmm=synth.make_gmm(3), shape=beta)
+    loss, gp, gt = r.loss_and_grad(t(g["ev_pose"]), t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_ref3d"]), _imu_aa(t(g["ev_imu_ori"])), t(g["ev_K"]))
+    assert abs(loss - float(g["evs_loss"])) <= 1e-5 * abs(float(g["evs_loss"]))
+    gs = max(np.abs(g["evs_grad_pose"]).max(), np.abs(g["evs_grad_tran"]).max())
+    assert float((gp.cpu() - t(g["evs_grad_pose"])).abs().max()) <= 1e-4 * gs
+    assert float((gt.cpu() - t(g["evs_grad_tran"])).abs().max()) <= 1e-4 * gs
+    assert abs(float(g["evs_loss"]) - float(g["ev_loss"])) > 1e-3 * abs(float(g["ev_loss"]))        # the shape matters
+    pose = S.batch_rodrigues(t(g["ev_pose"]).view(-1, 3)).view(-1, 24, 3, 3)
+    res = r.get_fitting_loss(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_K"]))
+    assert float((res.cpu() - t(g["evs_residual"])).abs().max()) <= 1e-4 * float(g["evs_residual"].max())
+    # the runner with shape=: optimises on the shaped body, keeps the mean-shape preserved landmarks; back to None afterwards
+    from robustcap_amd.smplify import smplify_runner
+    T = int(g["ev_T"])
+    p1, t1, u1 = smplify_runner(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_imu_ori"]), T, t(g["ev_K"]), lr=0.001, shape=beta.view(1, 10).expand(T, 10),
+                                runner=r)
+    p0, t0, u0 = smplify_runner(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_imu_ori"]), T, t(g["ev_K"]), lr=0.001, runner=r)
+    assert u1 is not None and u0 is not None and float((t1 - t0).abs().max()) > 1e-6
+    with pytest.raises(NotImplementedError):
+        smplify_runner(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_imu_ori"]), T, t(g["ev_K"]), use_lbfgs=False, runner=r)
+
+
 @pytest.mark.parametrize("T,seed", [(1, 5), (2, 6), (37, 7)])
 def test_closure_matches_oracle(T, seed, synth_assets, runner):
     """Seeded poses away from the capture, including T=1 (no temporal terms) and a ragged length."""
