@@ -13,6 +13,7 @@
 #include "../../include/robustcap_hip.h"
 #include "rc_internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -417,13 +418,14 @@ rc_params_dev dev_params(const rc_params& p) {
     return d;
 }
 
-int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bool with_tr = true) {
+int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bool with_tr = true, bool skip_prep = false,
+              const FrameIO* next_io = nullptr) {   // skip_prep / next_io: the previous / this frame's tail runs the next prep
     const int B = ctx->B;
     const FrameBuffers& fb = ctx->fb;
     const rc_params_dev prm = dev_params(ctx->prm);
     const int first = (flags & RC_FLAG_FIRST_FRAME) ? 1 : 0;
 
-    rc_launch_prep(fb, io, prm, B, first, st);
+    if (!skip_prep) rc_launch_prep(fb, io, prm, B, first, st);
     // deferred vision updater of the previous frame (L264-271) for rows that step again now: rnn6 then rnn4 in the
     // reference, independent nets here. State-only, linear2 skipped; usually no row qualifies and the tiles exit.
     if (ctx->prm.use_vision_updater && with_tr) {
@@ -459,7 +461,7 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
                            true, &init, st)) return rc;
     // tail: fusion logic + landmarks; rows in the occluded regime get their updater inputs (x6l, x4l) and a
     // pending mark -- the two sub-net steps themselves run at the start of the next frame (or in rc_get_state)
-    rc_launch_tail(fb, io, prm, ctx->body, B, first, st);
+    rc_launch_tail(fb, io, prm, ctx->body, B, first, st, next_io);
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
 }
@@ -862,9 +864,10 @@ static int finalize_weights_impl(rc_ctx* ctx) {
             const auto *wi = need("rnn.weight_ih_l" + sl, 4 * H * H), *wh = need("rnn.weight_hh_l" + sl, 4 * H * H);
             const auto *bi = need("rnn.bias_ih_l" + sl, 4 * H), *bh = need("rnn.bias_hh_l" + sl, 4 * H);
             if (!wi || !wh || !bi || !bh) return fail(ctx, RC_ERR_STATE, "rc_finalize_weights: missing LSTM weights of " + p);
-            // 16-column block cb = 4 hidden units x [i | f | g | o]: column n' <-> torch row g*H + 4*cb + u (gate order
-            // i,f,g,o). Independent of the tile width, so few-row stages can run narrow tiles on the same weights.
-            auto orig = [&](int np) { const int cb = np / 16, g = (np % 16) / 4, u = np % 4; return (size_t)g * H + 4 * cb + u; };
+            // 16-column block cb = hidden units 4 cb .. 4 cb + 3, each with its gates (i, f, g, o) in four consecutive
+            // columns: column n' <-> torch row g*H + 4*cb + u (torch gate order i,f,g,o). Independent of the tile width,
+            // so few-row stages can run narrow tiles on the same weights; the epilogue reads a unit's gates as one float4.
+            auto orig = [&](int np) { const int cb = np / 16, u = (np % 16) / 4, g = np % 4; return (size_t)g * H + 4 * cb + u; };
             auto get = [&](int np, int k) -> float {
                 const size_t r = orig(np);
                 return k < (int)H ? (*wi)[r * H + k] : (*wh)[r * H + (k - H)];
@@ -980,6 +983,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                       first_tran != nullptr, ctx->prm.use_imu_updater != 0, ctx->prm.use_vision_updater != 0, ctx->seq_min_frames,
                       mode.data());
     }
+    bool prep_done = false;                 // the previous frame's tail kernel already ran this frame's prep
     for (int t = 0; t < T;) {
         if (mode[t] == SEQ_WAVE) {
             int e = t;
@@ -987,7 +991,12 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
             if (int rc = run_wave_segment(ctx, t, e, io_at, st)) return rc;
             t = e;
         } else {
-            if (int rc = step_impl(ctx, io_at(t), t == 0 ? flags : 0u, st, mode[t] == SEQ_STEPPED_TR)) return rc;
+            // consecutive frame-stepped frames: tail(t) and prep(t + 1) are back to back on the stream and per row, so
+            // one wave does both (one launch boundary and the prep kernel's start-up latency less per frame)
+            const bool chain = t + 1 < T && mode[t + 1] != SEQ_WAVE;
+            const FrameIO next = chain ? io_at(t + 1) : FrameIO{};
+            if (int rc = step_impl(ctx, io_at(t), t == 0 ? flags : 0u, st, mode[t] == SEQ_STEPPED_TR, prep_done, chain ? &next : nullptr)) return rc;
+            prep_done = chain;
             ctx->stat_stepped_frames += 1;
             ++t;
         }
@@ -1125,6 +1134,17 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
     } else {
         HIP_TRY(ctx, hipGraphLaunch(need_tr ? ctx->live_exec : ctx->live_exec_notr, st));
+    }
+    // A frame is ~100 us of GPU work: poll for its completion instead of sleeping on the stream (the blocking wait's wake-up
+    // costs a sizeable fraction of that); after ~2 ms fall back to the blocking call.
+    {
+        const auto t_spin = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+        }
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(ctx, RC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        (void)hipGetLastError();
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));

@@ -22,8 +22,11 @@
 #include "rc_device.h"
 
 // =========================================================================================== prep (L138-152)
-__global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+// One wave, one body. pend_in / uv_count: the row's pending-updater mark and landmark refresh counter as they stand BEFORE this
+// frame (read from the state by rc_prep_kernel, handed over in registers when the previous frame's tail runs this in the same
+// wave -- rc_tail_kernel with a next frame).
+__device__ __forceinline__ void prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
+                                          const int lane, const int first_frame, const int pend_in, const int uv_count) {
     const float* kp = io.j2d + row * io.s_j2d;
     const float* acc = io.acc + row * io.s_acc;
     const float* ori = io.ori + row * io.s_ori;
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
     const float c = wave_sum(cf) / 33.0f;                                 // L138
     const double c64 = (double)c;                                         // python-double compares
     const bool gt_lo = c64 > prm.conf_lo, is_hi = c64 >= prm.conf_hi;
-    const bool refresh = !prm.live || fb.uv_count[row] == 0;
+    const bool refresh = !prm.live || uv_count == 0;
     float xn, yn;
     bbox_normalise(x, y, lane, xn, yn);                                   // L150-152
     float Rcr[9];
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
         if (!gt_lo && refresh && prm.use_vision_updater) f |= RC_ROW_UPD; // L264
         fb.flags[row] = (unsigned char)f;
         // deferred updater steps of the previous frame (see RC_ROW2_*)
-        const bool pend = fb.pend[row] != 0;
+        const bool pend = pend_in != 0;
         unsigned f2 = 0;
         if (pend && vis) f2 |= RC_ROW2_TR;
         if (vis || pend) f2 |= RC_ROW2_M4;
@@ -84,6 +87,11 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
         fb.x4[rc_pk(row, k, LD_X4)] = xn; fb.x4[rc_pk(row, k + 1, LD_X4)] = yn; fb.x4[rc_pk(row, k + 2, LD_X4)] = cf;
         fb.x6[rc_pk(row, k, LD_X6)] = x; fb.x6[rc_pk(row, k + 1, LD_X6)] = y; fb.x6[rc_pk(row, k + 2, LD_X6)] = cf;
     }
+}
+
+__global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
+    const int row = blockIdx.x;
+    prep_body(fb, io, prm, row, threadIdx.x, first_frame, fb.pend[row], fb.uv_count[row]);
 }
 
 // =================================================================================== fuse (L154-167, L178-180)
@@ -131,8 +139,11 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
 }
 
 // ============================================================================================ tail (L173-273)
+// has_next: the same wave goes on with the prep of the NEXT frame of its row (io_next) -- in a frame-stepped sequence the two
+// kernels are back to back on the stream anyway, and the row's state they share travels in registers.
 __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
-                                                     const BodyConst* __restrict__ body_g, int B, int first_frame) {
+                                                     const BodyConst* __restrict__ body_g, int B, int first_frame, FrameIO io_next,
+                                                     int has_next) {
     __shared__ WaveScratch s;
     __shared__ BodyConst s_body;
     const int row = blockIdx.x, lane = threadIdx.x;
@@ -262,6 +273,8 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     const bool live = prm.live != 0;
     const int uvc = fb.uv_count[row];
     const bool refresh = !live || uvc == 0;
+    const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
+    const int pend_next = (flags & RC_ROW_UPD) ? 1 : 0;
     __syncthreads();   // all lanes have read the per-row state; lane 0 may now overwrite it
     if (lane == 0) {                                                       // L227, L273
 #pragma unroll
@@ -276,8 +289,8 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             for (int c = 0; c < 3; ++c) fb.floor[row * 33 + 3 * appended + c] = pick[c];
         }
         // L228, L234-242: the refresh counter only moves while one of its two consumers is switched on
-        if (live && (prm.use_reproj_opt || prm.use_vision_updater)) fb.uv_count[row] = refresh ? prm.update_vision_freq : uvc - 1;
-        fb.pend[row] = (flags & RC_ROW_UPD) ? 1 : 0;                     // L264-271 run at the start of the next frame
+        if (live && (prm.use_reproj_opt || prm.use_vision_updater)) fb.uv_count[row] = uvc_next;
+        fb.pend[row] = pend_next;                                         // L264-271 run at the start of the next frame
         int* tr = fb.trace + row * 8;
         tr[1] = ((flags & RC_ROW_VIS) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
         tr[2] = (first_frame ? 1 : 0) + ((flags & RC_ROW_PC) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
@@ -363,6 +376,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             fb.c2[fb.c2_layer_stride + row * 512 + e] = src[1536 + e];
         }
     }
+    if (has_next) prep_body(fb, io_next, prm, row, lane, 0, pend_next, uvc_next);
 }
 
 // ================================================================================================== reset
@@ -665,8 +679,8 @@ void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
     hipLaunchKernelGGL(rc_fuse_kernel, dim3((B * 24 + 255) / 256), dim3(256), 0, st, fb, io, prm, B);
 }
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
-                    int first_frame, hipStream_t st) {
-    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame);
+                    int first_frame, hipStream_t st, const FrameIO* io_next) {
+    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0);
 }
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t st) {

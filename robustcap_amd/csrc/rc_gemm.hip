@@ -45,7 +45,8 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #endif
 
 #ifndef RC_FAST_GATES
-#define RC_FAST_GATES 0       // 1: gate non-linearities on v_exp_f32 / v_rcp_f32 (A/B builds; see DESIGN.md for the parity cost)
+#define RC_FAST_GATES 1       // gate non-linearities on v_exp_f32 / v_rcp_f32 (0: libm expf / tanhf, A/B builds): measured +3.6 %
+                              // frame rate with parity margins unchanged (profiles/r02_parity_margins.json)
 #endif
 #if RC_FAST_GATES
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
@@ -362,26 +363,22 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
-        // item -> (row rr, unit u); every 16-column block holds 4 hidden units x [i | f | g | o] (4 columns each), so
-        // the weight packing does not depend on the tile width and the host picks NC per launch
+        // item -> (row rr, unit u); every 16-column block holds 4 hidden units x (i, f, g, o) -- the four gates of a unit
+        // in four consecutive columns -- so the weight packing does not depend on the tile width (the host picks NC per
+        // launch) and an item reads each wave's partial sums, and the bias, as ONE 16-byte access
         for (int item = tid; item < MT * UT; item += RC_NW * 64) {
             const int rr = item / UT, u = item - rr * UT;
             if (rr >= nrows) continue;
             const int unit = n_tile * UT + u;
-            float gsum[4];
+            f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + 4 * u]);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int col = 16 * (u >> 2) + 4 * gq + (u & 3);
-                float v = s_part[rr * LD + col];
-#pragma unroll
-                for (int w = 1; w < RC_NW; ++w) v += s_part[(w * MT + rr) * LD + col];
-                gsum[gq] = v + P.bias[n_tile * NT + col];
-            }
+            for (int w = 1; w < RC_NW; ++w) g4 += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + 4 * u]);
+            g4 += *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * u]);
             const int r2 = s_rows[rr];
             const int dst = (P.steps[r2] + P.step_off) & 1;
             const long long ci = (long long)r2 * P.H + unit;
-            const float ig = sigmoidf_(gsum[0]), fg = sigmoidf_(gsum[1]);
-            const float gg = tanhf_(gsum[2]), og = sigmoidf_(gsum[3]);
+            const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]);
+            const float gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
             const float cn = fg * P.cstate[ci] + ig * gg;
             P.cstate[ci] = cn;
             P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf_(cn);

@@ -143,7 +143,7 @@ bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_g
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
-                    int first_frame, hipStream_t s);
+                    int first_frame, hipStream_t s, const FrameIO* io_next = nullptr);   // io_next: also the next frame's prep
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
 

@@ -105,6 +105,10 @@ class Net:
 
     def _sync_gravity(self):
         g = self.gravityc                                                   # instance attr, else the class attr
+        seen = self.__dict__.get("_gravity_seen")                           # same tensor object, not modified in place since
+        if seen is not None and seen[0] is g and isinstance(g, torch.Tensor) and seen[1] == g._version:
+            return
+        self.__dict__["_gravity_seen"] = (g, g._version) if isinstance(g, torch.Tensor) else None
         g = torch.as_tensor(g, dtype=torch.float32).detach().cpu().reshape(-1, 3)
         key = g.numpy().tobytes()
         if key == self._gravity_key:
@@ -196,12 +200,15 @@ class Net:
             torch.cuda.synchronize()
             _lib.check(self._ctx, self._lib.rc_live_begin(self._ctx), "rc_live_begin")
             self.__dict__["_live_on"] = True
-        host = lambda t, shape: torch.as_tensor(t, dtype=torch.float32).cpu().reshape(shape).contiguous()
-        j2dc, accc, oric = host(j2dc, (B, 33, 3)), host(accc, (B, 6, 3)), host(oric, (B, 6, 3, 3))
-        ft = None if first_tran is None else host(first_tran, (B, 3))
+        def host(x, n):       # CPU float32 contiguous tensors (what live callers hand over) pass through untouched
+            if isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.device.type == "cpu" and x.is_contiguous() and x.numel() == n:
+                return x
+            return torch.as_tensor(x, dtype=torch.float32).cpu().reshape(n).contiguous()
+        j2dc, accc, oric = host(j2dc, B * 99), host(accc, B * 18), host(oric, B * 54)
+        ft = None if first_tran is None else host(first_tran, B * 3)
         pose, tran = torch.empty(B, 24, 3, 3), torch.empty(B, 3)
-        rc = self._lib.rc_live_step(self._ctx, _lib.ptr(j2dc), _lib.ptr(accc), _lib.ptr(oric), _lib.ptr(ft),
-                                    _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, _lib.ptr(pose), _lib.ptr(tran))
+        rc = self._lib.rc_live_step(self._ctx, j2dc.data_ptr(), accc.data_ptr(), oric.data_ptr(), None if ft is None else ft.data_ptr(),
+                                    _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, pose.data_ptr(), tran.data_ptr())
         _lib.check(self._ctx, rc, "rc_live_step")
         return pose, tran
 
