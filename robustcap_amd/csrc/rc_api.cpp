@@ -93,6 +93,7 @@ struct rc_ctx {
     float *live_in_d = nullptr, *live_out_d = nullptr, *live_ft_d = nullptr;
     float *live_in_io = nullptr, *live_out_io = nullptr;    // what the frame kernels read / write (device copy or mapped host memory)
     bool live_zero_copy = false;
+    bool live_eager = false;
     hipGraph_t live_graph_notr = nullptr;                   // the same frame without the transition launches
     hipGraphExec_t live_exec_notr = nullptr;
     std::vector<unsigned char> live_maybe_pend;             // host-side, conservative: row may carry a deferred updater step
@@ -715,6 +716,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     if (hipEventCreateWithFlags(&ctx->eager_ev, hipEventDisableTiming) != hipSuccess) ctx->eager_ev = nullptr;
     rc_default_params(live, &ctx->prm);
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= 32 ? 1 : 0) != 0;
+    ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
     // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
     // only lengthens the launch). 64-row tiles halve the weight bytes a CU pulls per product -- with the MFMA time cut 2.7x
@@ -1131,6 +1133,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, first_tran ? ctx->live_ft_d : nullptr,
                    ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
         if (int rc = step_impl(ctx, io, flags, st)) return rc;
+        if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
+    } else if (ctx->live_eager) {                                // tuning (RC_LIVE_EAGER=1): the 11-14 launches enqueued directly
+        FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, nullptr,
+                   ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
+        if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
+        if (int rc = step_impl(ctx, io, 0u, st, need_tr)) return rc;
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
     } else {
         HIP_TRY(ctx, hipGraphLaunch(need_tr ? ctx->live_exec : ctx->live_exec_notr, st));

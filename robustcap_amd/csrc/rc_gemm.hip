@@ -104,6 +104,9 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 #ifndef RC_SPLIT_PRODUCTS
 #define RC_SPLIT_PRODUCTS 6
 #endif
+#ifndef RC_ABL_SPLIT
+#define RC_ABL_SPLIT 0        // timing-only probe builds (wrong results): 1 = weight loads hit one k-block only (L1-resident),
+#endif                        // 2 = no operand split (raw bits), 3 = both, 4 = activations loaded from one k-block only
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -116,6 +119,9 @@ struct FragS {                // one k-block (32 k): fp32 activations (two float
 template <int MR, int NC>
 __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const u32x4* pb,
                                             long long bstride) {
+#if RC_ABL_SPLIT == 4
+    aoff = 0;
+#endif
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
@@ -152,7 +158,11 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         u32x4 uh, um, ul;
+#if RC_ABL_SPLIT & 2
+        uh = __builtin_bit_cast(u32x4, f.a0[r]); um = __builtin_bit_cast(u32x4, f.a1[r]); ul = uh;
+#else
         split3(f.a0[r], f.a1[r], uh, um, ul);
+#endif
         const bf16x8 ah = __builtin_bit_cast(bf16x8, uh), am = __builtin_bit_cast(bf16x8, um), al = __builtin_bit_cast(bf16x8, ul);
         // small terms first; consecutive MFMAs go to different accumulators (NC of them between two uses of one)
 #define RC_PROD(AV, PL)                                                                                                  \
@@ -181,7 +191,7 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int MR, int NC, int D, bool PIPE, bool SPLIT = false>
+template <int MR, int NC, int D, bool PIPE, bool SPLIT = false, bool DEEPOK = true>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + (MR >= 8 ? 4 : LDS_PAD);   // 128-row tiles: 140 KB with pad 4
 #ifdef RC_TRACE_TILES
@@ -290,23 +300,49 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define LOADS(F, QI)                                                                                                \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)(QI) * 192, bs);              \
-        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)(QI) * 192, bs);               \
+        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * 192, bs);              \
+        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * 192, bs);               \
     } while (0)
-        FragS<MR, NC> fa = {}, fb = {};
+        // With the MFMA time cut 2.7x the K loop is bound by what a wave keeps in flight (one k-block = 23 KiB for a 64 x 80
+        // tile; 4 waves x 23 KiB / ~2 us of L2 / fabric latency = the 47 GB/s per CU the two-buffer loop was measured at):
+        // tile shapes whose registers allow it run THREE k-block buffers (two blocks in flight behind every MFMA block).
+        constexpr bool DEEP = DEEPOK && MR >= 2 && (MR * 8 + NC * 12) * 3 + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
         int q = 0;
-        LOADS(fa, 0);
-        for (; q + 2 <= Qws; q += 2) {  // prefetch indices past the end are clamped: a redundant, valid load, no branch
-            LOADS(fb, min(q + 1, Qws - 1));
-            SB();
-            mma_kblock<MR, NC>(fa, acc);
-            SB();
-            LOADS(fa, min(q + 2, Qws - 1));
-            SB();
-            mma_kblock<MR, NC>(fb, acc);
-            SB();
+        if constexpr (DEEP) {
+            FragS<MR, NC> fa = {}, fb = {}, fc = {};
+            LOADS(fa, 0);
+            LOADS(fb, min(1, Qws - 1));
+            for (; q + 3 <= Qws; q += 3) {  // prefetch indices past the end are clamped: a redundant, valid load, no branch
+                LOADS(fc, min(q + 2, Qws - 1));
+                SB();
+                mma_kblock<MR, NC>(fa, acc);
+                SB();
+                LOADS(fa, min(q + 3, Qws - 1));
+                SB();
+                mma_kblock<MR, NC>(fb, acc);
+                SB();
+                LOADS(fb, min(q + 4, Qws - 1));
+                SB();
+                mma_kblock<MR, NC>(fc, acc);
+                SB();
+            }
+            if (q < Qws) mma_kblock<MR, NC>(fa, acc);
+            if (q + 1 < Qws) mma_kblock<MR, NC>(fb, acc);
+        } else {
+            FragS<MR, NC> fa = {}, fb = {};
+            LOADS(fa, 0);
+            for (; q + 2 <= Qws; q += 2) {
+                LOADS(fb, min(q + 1, Qws - 1));
+                SB();
+                mma_kblock<MR, NC>(fa, acc);
+                SB();
+                LOADS(fa, min(q + 2, Qws - 1));
+                SB();
+                mma_kblock<MR, NC>(fb, acc);
+                SB();
+            }
+            if (q < Qws) mma_kblock<MR, NC>(fa, acc);
         }
-        if (q < Qws) mma_kblock<MR, NC>(fa, acc);
 #undef LOADS
     } else if constexpr (D == 2) {      // wide tiles: two named buffers (the array form below schedules worse here)
         Frag<MR, NC> fa = {}, fb = {};
@@ -468,6 +504,30 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_split_kernel(const
     wide_tiles<true>(L, s_mem);
 }
 
+// Launches whose tiles are all at most 32 x 64 (the linear1 launches; LSTM stages of batches below 128) do not need the
+// 148 KB of the wide kernel: with 41 KB of LDS and a register budget for two waves per SIMD three of these workgroups
+// share a CU, so the 328 short tiles of a linear1 launch no longer take two rounds of 256.
+#define RC_MID_LDS_FLOATS (RC_LDS_HEAD + RC_NW * 32 * (16 * 4 + LDS_PAD))
+template <bool SPLIT>
+__device__ __forceinline__ void mid_tiles(const GemmLaunch& L, float* s_mem) {
+    int pi, m_tile, n_tile;
+    if (!locate_tile(L, pi, m_tile, n_tile)) return;
+    const GemmProblem& P = L.p[pi];
+    switch (P.mr * 16 + P.nc) {
+        case 1 * 16 + 2: gemm_tile<1, 2, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        case 1 * 16 + 1: gemm_tile<1, 1, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem); break;
+        default: gemm_tile<2, 4, 2, true, SPLIT, false>(P, L.B, m_tile, n_tile, s_mem); break;   // two buffers: 256-register budget
+    }
+}
+__global__ __launch_bounds__(RC_NW * 64, 2) void rc_gemm_mid_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_MID_LDS_FLOATS];
+    mid_tiles<false>(L, s_mem);
+}
+__global__ __launch_bounds__(RC_NW * 64, 2) void rc_gemm_mid_split_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_MID_LDS_FLOATS];
+    mid_tiles<true>(L, s_mem);
+}
+
 // Launches whose problems all use 16-row tiles (batch <= 16: live mode, transition rows) are weight-streaming, not
 // MFMA-bound: their own kernel with a 12 KB LDS footprint and a register budget for 4 waves per SIMD keeps four
 // workgroups -- 4 x 32 KB of weight loads in flight -- on every CU instead of one.
@@ -498,11 +558,20 @@ bool rc_gemm_is_small(const GemmLaunch& L) {
     return small;
 }
 
+bool rc_gemm_is_mid(const GemmLaunch& L) {
+    bool mid = true;
+    for (int q = 0; q < L.n; ++q) mid = mid && L.p[q].mr <= 2 && L.p[q].nc <= 4 && !(L.p[q].mr == 2 && L.p[q].nc < 4);
+    return mid;
+}
+
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
     const dim3 g(total_wg), b(RC_NW * 64);
     if (rc_gemm_is_small(L)) {
         if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
         else hipLaunchKernelGGL(rc_gemm_small_kernel, g, b, 0, s, L);
+    } else if (rc_gemm_is_mid(L)) {
+        if (L.split) hipLaunchKernelGGL(rc_gemm_mid_split_kernel, g, b, 0, s, L);
+        else hipLaunchKernelGGL(rc_gemm_mid_kernel, g, b, 0, s, L);
     } else {
         if (L.split) hipLaunchKernelGGL(rc_gemm_split_kernel, g, b, 0, s, L);
         else hipLaunchKernelGGL(rc_gemm_kernel, g, b, 0, s, L);

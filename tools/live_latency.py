@@ -27,17 +27,39 @@ def run(net, m, n):
     return lat[50:] * 1e6
 
 
+def run_c(net, m, n):
+    """The library call alone (rc_live_step through ctypes on preallocated host tensors): what a C caller of the ABI sees."""
+    import ctypes as C
+    from robustcap_amd import _lib
+    t = torch.from_numpy
+    T = m["j2dc"].shape[1]
+    ins = [(t(m["j2dc"][0, k]).contiguous(), t(m["accc"][0, k]).contiguous(), t(m["oric"][0, k]).contiguous()) for k in range(T)]
+    pose, tran = torch.empty(1, 24, 3, 3), torch.empty(1, 3)
+    net.forward_online(*ins[0], first_frame=True)                       # captures the frame
+    fn, ctx = net._lib.rc_live_step, net._ctx
+    pp, pt = C.c_void_p(pose.data_ptr()), C.c_void_p(tran.data_ptr())
+    ptrs = [(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr())) for a, b, c in ins]
+    lat = np.empty(n)
+    for i in range(n):
+        a, b, c = ptrs[1 + i % (T - 1)]
+        t0 = time.perf_counter()
+        rc = fn(ctx, a, b, c, None, 0, pp, pt)
+        lat[i] = time.perf_counter() - t0
+        assert rc == 0
+    return lat[50:] * 1e6
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     m = synth.make_motion(7, 1, 600, body, conf="mixed")
     out = {}
-    for mode in ("graph", "eager"):
+    for mode in ("graph", "graph_c_abi", "eager"):
         net = Net(body=body, batch=1)
         net.load_state_dict(sd)
         net.gravityc = torch.from_numpy(m["gravityc"])
-        net.use_graph = mode == "graph"
-        lat = run(net, m, n)
+        net.use_graph = mode != "eager"
+        lat = run_c(net, m, n) if mode == "graph_c_abi" else run(net, m, n)
         out[mode] = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
                      "mean_us": round(float(lat.mean()), 1), "fps": round(1e6 / float(lat.mean()), 1)}
     print(json.dumps({"metric": "forward_online latency, batch 1, host->host", "frames": n, "weights_MB": 243.06,

@@ -1,36 +1,57 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 --pmc databases written by tools/pmc_traffic.sh to bytes per gate-GEMM launch."""
-import json, sqlite3, sys, os, glob
+"""Reduce the rocprofv3 --pmc databases written by tools/pmc_traffic.sh to fabric-side bytes per launch of the dominant
+kernel (the wide-tile gate GEMM: rc_gemm_split_kernel, or rc_gemm_kernel in fp32-MFMA mode), keyed by the workload
+(batch, confidence schedule) so that bench.py only quotes it for the run it belongs to.
+    python tools/pmc_traffic.py gpurun_out/pmc [batch] [conf] > profiles/rNN_pmc_traffic.json"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
 root = sys.argv[1]
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+conf = sys.argv[3] if len(sys.argv) > 3 else "mixed"
+
+
 def per_launch(tag, counters):
     db = glob.glob(os.path.join(root, tag, "**", "*.db"), recursive=True)[0]
     con = sqlite3.connect(db)
     tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
     view = "counters_collection" if "counters_collection" in tabs else [t for t in tabs if "counter" in t.lower()][0]
-    cols = [d[1] for d in con.execute(f"pragma table_info({view})")]
     out = {}
     for c in counters:
-        rows = list(con.execute(f"select kernel_name, value from {view} where counter_name = ?", (c,))) if "kernel_name" in cols else []
-        vals = [v for n, v in rows if n.startswith("rc_gemm")]
-        out[c] = (sum(vals) / max(len(vals), 1), len(vals))
-    return out, cols, view
+        rows = list(con.execute(f"select kernel_name, value from {view} where counter_name = ?", (c,)))
+        by = {}
+        for n, v in rows:
+            by.setdefault(n.split("(")[0], []).append(v)
+        out[c] = {k: (sum(v) / len(v), len(v)) for k, v in by.items() if k.startswith("rc_gemm")}
+    return out
+
+
 res = {}
 for tag, cs in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("TCC_HIT_sum", ["TCC_HIT_sum", "TCC_MISS_sum"])):
     try:
-        o, cols, view = per_launch(tag, cs)
-        res.update(o)
-    except Exception as e:
-        print("pass", tag, "failed:", e)
-print(res)
-if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
-    f, n = res["FETCH_SIZE"]; w, _ = res["WRITE_SIZE"]
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh), bench.py --steps 32 --warmup 8, gate-GEMM launches (rc_gemm_kernel + rc_gemm_small_kernel), per-launch average over %d launches (round-1 final build)" % n,
+        res.update(per_launch(tag, cs))
+    except Exception as e:  # noqa: BLE001
+        print("pass", tag, "failed:", e, file=sys.stderr)
+wide = next((k for k in ("rc_gemm_split_kernel", "rc_gemm_kernel") if k in res.get("FETCH_SIZE", {})), None)
+if wide and wide in res.get("WRITE_SIZE", {}):
+    f, n = res["FETCH_SIZE"][wide]
+    w, _ = res["WRITE_SIZE"][wide]
+    out = {"batch": batch, "conf": conf, "kernel": wide,
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in three separate passes with --kernel-trace only "
+                     "(tools/pmc_traffic.sh: bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-variants), per-launch average over "
+                     "%d launches of %s" % (n, wide),
            "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
            "traffic_bytes_per_launch": (2 * f + w) * 1024,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
-           "unique_weight_bytes_per_launch": 243.06e6 / 11}
-    if "TCC_HIT_sum" in res and res["TCC_HIT_sum"][1]:
-        h, m = res["TCC_HIT_sum"][0], res["TCC_MISS_sum"][0]
+           "other_kernels_KB_per_launch": {k: {"fetch": res["FETCH_SIZE"][k][0], "write": res["WRITE_SIZE"].get(k, (0, 0))[0], "launches": res["FETCH_SIZE"][k][1]}
+                                           for k in res["FETCH_SIZE"] if k != wide}}
+    if wide in res.get("TCC_HIT_sum", {}):
+        h, m = res["TCC_HIT_sum"][wide][0], res["TCC_MISS_sum"][wide][0]
         out["l2_hit_rate"] = h / (h + m)
     print(json.dumps(out, indent=1))
-    json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+else:
+    print(json.dumps({"error": "no wide-tile gate-GEMM launches found", "kernels": sorted(res.get("FETCH_SIZE", {}))}))
+    sys.exit(1)
