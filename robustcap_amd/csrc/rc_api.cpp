@@ -22,6 +22,11 @@
 #include <string>
 #include <vector>
 
+// From this batch on a context defaults to the split-bf16 products and to 64-row tiles for its full-batch stages. Below it
+// the frame is bound by its launch chain and by weight streaming (6 B per weight would slow it: measured 165k vs 193k
+// body-frames/s at batch 32, 442k vs 461k at 128; at 256 the split wins 770k vs 685k).
+#define RC_SPLIT_MIN_BATCH 192
+
 #ifndef RC_NC1280
 #define RC_NC1280 10      // 16-column blocks per rnn4 LSTM tile (probe builds: 8 lets two workgroups share a CU's LDS)
 #endif
@@ -108,7 +113,7 @@ struct rc_ctx {
     // sequence mode (rc_sequence on all-visible stretches): skewed stage pipeline, one gate-GEMM launch per tick
     bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
     int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (rc_set_sequence_mode)
-    int seq_min_frames = 16;             // shortest stretch worth filling the 11-stage pipeline for
+    int seq_min_frames = 48;             // shortest stretch worth filling and draining the 11-stage pipeline for (break-even ~40)
     bool ring_ready = false;
     FrameBuffers ring[16];               // slot 0 = fb; slots 1..15 allocated on first use
     float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
@@ -333,7 +338,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.epi = RC_EPI_LSTM;
     int mr, nc;
     pick_tile(n.H, s.rows_hint < 0 ? c->B : s.rows_hint, &mr, &nc);
-    if (s.rows_hint < 0 && c->B >= 128) {
+    if (s.rows_hint < 0 && c->B >= RC_SPLIT_MIN_BATCH) {   // below that, 64-row tiles leave CUs without a tile
         // Second stage of a frame {rnn6, rnn3, rnn7, rnn8}: 64-row tiles. 128 CUs run the 128 rnn6 tiles (64 x 128) while
         // the other 128 run the 3 x 128 tiles (64 x 64) of the H = 512 nets in three rounds of a third of that length each,
         // instead of one round of 32 x 128 tiles followed by three rounds of 32 x 64 tiles: half as many tile prologues /
@@ -573,7 +578,7 @@ int build_tick_problems(rc_ctx* ctx) {
                 }
             }
             if (ts.kind == 1) p.seg[0].base = x1;
-            if ((ts.kind == 1 || ts.kind == 2) && ctx->B >= 128) {
+            if ((ts.kind == 1 || ts.kind == 2) && ctx->B >= RC_SPLIT_MIN_BATCH) {
                 const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
                 const int mr = t[0], nc = t[1];
                 p.mr = mr; p.nc = nc;
@@ -715,7 +720,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     (void)hipGetDevice(&ctx->dev);
     if (hipEventCreateWithFlags(&ctx->eager_ev, hipEventDisableTiming) != hipSuccess) ctx->eager_ev = nullptr;
     rc_default_params(live, &ctx->prm);
-    ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= 32 ? 1 : 0) != 0;
+    ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0;
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
     // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
@@ -964,6 +969,10 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     std::vector<unsigned char> mode((size_t)(T > 0 ? T : 0), (unsigned char)SEQ_STEPPED_TR);
     const int B = ctx->B;
     if (ctx->seq_mode && !ctx->prm.live && T >= 2) {
+        // rings, second stream and tick problems are set up by the first planned call (a warm-up call pays for them), not by
+        // the first call that happens to contain a long all-visible stretch
+        if (int rc = ensure_sequence_buffers(ctx)) return rc;
+        if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
         const size_t need = (size_t)B * T;
         if (need > ctx->scan_cap) {
             if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);

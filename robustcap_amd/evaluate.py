@@ -115,7 +115,7 @@ def first_translations(dataset, rows):
 
 
 def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda",
-                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080), smplify_workers=4):
+                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080), smplify_workers=4, nets=None):
     """Run every (sequence, camera) row of ``dataset`` (or the given subset) through the net; rows are sharded over
     the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU.
 
@@ -125,7 +125,9 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     -- takes the optimised pose and translation whether or not ``update`` says they improved. Rows are independent
     optimisation problems (the reference runs them one after another): ``smplify_workers`` host threads each drive their
     own optimiser context and HIP stream, so the line searches of several rows overlap on the device. ``gmm`` is the pose
-    prior (dict means/covars/weights); ``smplify_info`` (a dict) receives the per-row optimiser records."""
+    prior (dict means/covars/weights); ``smplify_info`` (a dict) receives the per-row optimiser records. ``nets``: an optional
+    dict the caller keeps between calls -- the ``Net`` of a given row count is then built (weights re-packed and uploaded,
+    ~0.4 s) once and only reset for the next dataset."""
     all_rows = rows_of(dataset) if rows is None else list(rows)
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -138,8 +140,14 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     if n:
         j2d, acc, ori, grav = camera_inputs_rows(dataset, mine, Tmax, image_size=image_size, device=device)
         ft = first_translations(dataset, mine)
-        net = Net(body=body, batch=n, device=device)
-        net.load_state_dict(state_dict)
+        net = None if nets is None else nets.get((n, id(state_dict)))
+        if net is None:
+            net = Net(body=body, batch=n, device=device)
+            net.load_state_dict(state_dict)
+            if nets is not None:
+                nets[(n, id(state_dict))] = net
+        else:
+            net.reset_states()
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)

@@ -232,7 +232,7 @@ class Net:
 
     def set_gemm_mode(self, split):
         """Product arithmetic of every GEMM of this context (rc_set_gemm_mode): False = fp32 MFMA (fma chains), True =
-        split-bf16 partial products with fp32 accumulation (default for batch >= 32). Results are bitwise reproducible
+        split-bf16 partial products with fp32 accumulation (default for batch >= 192). Results are bitwise reproducible
         across batch sizes and shards WITHIN one mode."""
         _lib.check(self._ctx, self._lib.rc_set_gemm_mode(self._ctx, int(bool(split))), "rc_set_gemm_mode")
         self.__dict__["_live_on"] = False
@@ -241,7 +241,7 @@ class Net:
     def gemm_mode(self):
         return int(self._lib.rc_get_gemm_mode(self._ctx))
 
-    def set_sequence_mode(self, enabled=True, min_frames=16):
+    def set_sequence_mode(self, enabled=True, min_frames=48):
         """Scheduling of ``forward_sequence`` (rc_set_sequence_mode): with ``enabled`` (the default) all-visible stretches
         of at least ``min_frames`` frames run on the wavefront engine (bitwise the same outputs, one GEMM launch per tick)."""
         _lib.check(self._ctx, self._lib.rc_set_sequence_mode(self._ctx, int(bool(enabled)), int(min_frames)), "rc_set_sequence_mode")

@@ -26,11 +26,16 @@ def main():
     ds = synth.make_dataset(21, n_seq, T, body, n_cam=9, conf="mixed")
     rows = len(ev.rows_of(ds))
     out = {"sequences": n_seq, "cameras": 9, "frames": T, "rows": rows, "world": world}
+    nets = {}
+    t0 = time.perf_counter()
+    ev.run_dataset(ds, sd, body, nets=nets)                 # builds the context: weights re-packed + uploaded once
+    torch.cuda.synchronize()
+    out["first_call_incl_weight_packing_s"] = round(time.perf_counter() - t0, 3)
     for smp in (False, True):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         info = {}
-        res = ev.run_dataset(ds, sd, body, run_smplify=smp, gmm=gmm if smp else None, smplify_info=info)
+        res = ev.run_dataset(ds, sd, body, run_smplify=smp, gmm=gmm if smp else None, smplify_info=info, nets=nets)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         key = "with_smplify" if smp else "net_only"
