@@ -10,8 +10,10 @@
  *   - All tensors are float32, row-major, resident in device memory unless a parameter says "host".
  *   - The caller owns every I/O buffer and passes raw device pointers plus the HIP stream to enqueue on
  *     (hipStream_t is passed as void*). The library owns only its context (packed weights, recurrent state,
- *     scratch). No call synchronises the device except rc_create / rc_finalize_weights / rc_set_body /
- *     rc_get_state / rc_destroy.
+ *     scratch). No call synchronises the device except rc_create / rc_finalize_weights / rc_set_body / rc_set_mesh /
+ *     rc_shape_body / rc_get_state / rc_get_trace / rc_destroy; rc_sequence synchronises `stream` ONCE per call when its
+ *     launch planner is on (rc_set_sequence_mode; the default), rc_camera_inputs_rows once (constant upload), the
+ *     *_host-mean variants of the metric calls and rc_smplify_* as documented with them.
  *   - Every function returns 0 on success or a negative rc_status; rc_last_error() gives a message. Nothing
  *     throws across the boundary. A context is not re-entrant; distinct contexts on distinct streams are
  *     independent.

@@ -104,9 +104,6 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 #ifndef RC_SPLIT_PRODUCTS
 #define RC_SPLIT_PRODUCTS 6
 #endif
-#ifndef RC_INTERLEAVE
-#define RC_INTERLEAVE 0       // 1: the k-block loads are issued one at a time between groups of MFMAs (sched_group_barrier)
-#endif
 #ifndef RC_ABL_SPLIT
 #define RC_ABL_SPLIT 0        // timing-only probe builds (wrong results), bit mask: 1 = weight loads hit one k-block only (cache
 #endif                        // resident), 2 = no operand split (constant operands), 4 = activation loads hit one k-block only, 8 = no loads at all
@@ -132,23 +129,6 @@ __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const
     for (int r = 0; r < MR; ++r) {
         f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
         f.a1[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff + 256);
-    }
-#pragma unroll
-    for (int j = 0; j < NC; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
-}
-
-// The same load with the K segment chosen by selects instead of a branch: the loads then sit in the SAME basic block as the
-// MFMAs of the k-block in flight, where sched_group_barrier can spread them between the MFMAs (RC_INTERLEAVE).
-template <int MR, int NC>
-__device__ __forceinline__ void load_kblock_sel(FragS<MR, NC>& f, const float* const (&pa0)[MR], const float* const (&pa1)[MR],
-                                                const bool second, const long long aoff, const u32x4* pb, long long bstride) {
-#pragma unroll
-    for (int r = 0; r < MR; ++r) {
-        const float* p = (second ? pa1[r] : pa0[r]) + aoff;
-        f.a0[r] = *reinterpret_cast<const f32x4*>(p);
-        f.a1[r] = *reinterpret_cast<const f32x4*>(p + 256);
     }
 #pragma unroll
     for (int j = 0; j < NC; ++j)
@@ -331,26 +311,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         // tile shapes whose registers allow it run THREE k-block buffers (two blocks in flight behind every MFMA block).
         constexpr bool DEEP = DEEPOK && MR >= 2 && (MR * 8 + NC * 12) * 3 + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
         int q = 0;
-#if RC_INTERLEAVE
-        // one scheduling region per k-block step: [MFMA x MPG, load x 1, VALU x VPG] repeated for every load of the block two
-        // steps ahead, so that the texture-address path works through the 1 KiB loads WHILE the matrix pipe runs (issued as
-        // one burst they block the wave's issue for ~1,500 cycles per k-block: profiles/r02_kloop_ablation.txt)
-        constexpr int NLD = 2 * MR + 3 * NC, MPG = (6 * MR * NC) / NLD, VPG = (44 * MR + NLD - 1) / NLD + 1;
-#define STEP(FL, QL, FM)                                                                                            \
-    do {                                                                                                            \
-        const int k_ = kb0 + (QL) * 32;                                                                             \
-        load_kblock_sel<MR, NC>(FL, pa0, pa1, k_ >= K0, (long long)(k_ >= K0 ? k_ - K0 : k_) * 16, pbs + (long long)(QL) * 192, bs); \
-        mma_kblock<MR, NC>(FM, acc);                                                                                \
-        _Pragma("unroll") for (int g_ = 0; g_ < NLD; ++g_) {                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                      \
-            __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);                                                    \
-        }                                                                                                           \
-        SB();                                                                                                       \
-    } while (0)
-#else
+        // (Spreading the loads between the MFMAs -- sched_group_barrier patterns, or slices of the next block's loads in front of
+        // every row block's MFMAs -- was measured at -2 % / +-1 %: profiles/r02_kloop_ablation.txt.)
 #define STEP(FL, QL, FM) do { LOADS(FL, QL); SB(); mma_kblock<MR, NC>(FM, acc); SB(); } while (0)
-#endif
         if constexpr (DEEP) {
             FragS<MR, NC> fa = {}, fb = {}, fc = {};
             LOADS(fa, 0);
