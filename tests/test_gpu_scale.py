@@ -133,3 +133,10 @@ def test_strong_split_over_two_ranks_equals_one_rank():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_total"] == 37 and d["config"]["batch_per_gpu"] == 19
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    # weak scaling with the variants, as the driver launches it for N > 1 (here 2 ranks x 48 bodies on the one GPU)
+    r = subprocess.run(base + ["--master-port", port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--batch", "48"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["bodies_total"] == 96 and d["variants"]["high"]["value"] > 0
+    assert d["roofline"] is not None and d["cpu_baseline"] is None
