@@ -492,8 +492,8 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
 // TILE DURATION instead of by data dependence: four launches on the caller's stream,
 //   {rnn4 l0, l1}   {rnn6 l0, l1}   {rnn2 l0, l1, rnn3 l0, l1}   {rnn7 l0, l1, rnn8 l0, l1},
 // each a whole number of rounds of equal tiles at batch 256 (the frame-stepped stages mix 58 us and 14 us tiles and end on
-// a partly filled round), and -- every row being active -- 64-row tiles for the H = 512 nets (half as many tiles, so half
-// the per-tile prologue / reduction / epilogue time, which is 20 % of a 32 x 64 tile). The weight-streaming launches
+// a partly filled round), and -- every row being active -- 64 x 128 tiles for the H = 512 nets (a quarter of the tiles, so a
+// quarter of the per-tile prologue / reduction / epilogue time, which is 20 % of a 32 x 64 tile). The weight-streaming launches
 // (linear1, linear2: 16-row tiles on the small-tile kernel, 4 workgroups per CU) and the three per-row kernels run beside them
 // on a context-owned second stream; the two streams hand over once per tick. Inter-stage buffers are rings of 16 frames;
 // the step counters stand still during a segment (parity comes from step_off) and are advanced once at its end.
@@ -543,10 +543,11 @@ int ensure_sequence_buffers(rc_ctx* ctx) {
 }
 
 // GEMM problems of the 16 tick residues: the problem of stage s at residue r works on ring slot (r - s) mod 16.
-// Tile shapes (batch >= 128; smaller batches keep pick_tile's choice): rnn4 / rnn6 as in the frame-stepped launches,
-// H = 512 nets 64 x 64 (4 x 4 blocks): 128 workgroups per layer-step, four layer-steps per launch = two full rounds.
+// Tile shapes (batch >= RC_SPLIT_MIN_BATCH; smaller batches keep pick_tile's choice): rnn4 / rnn6 as in the frame-stepped
+// launches, H = 512 nets 64 x 128 (4 x 8 blocks): 64 workgroups per layer-step, four layer-steps per launch = ONE full round
+// of 256 (64 x 64 tiles: two rounds of shorter, less efficient tiles; measured 995k -> 1,070k body-frames/s, r02y).
 int build_tick_problems(rc_ctx* ctx) {
-    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 4};
+    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
