@@ -534,9 +534,8 @@ int ensure_sequence_buffers(rc_ctx* ctx) {
         if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) {
-        // device-scope release: the hand-over is between two streams of this GPU; the default system-scope release writes the
-        // L2 back at every record (a 10-12 us bubble on the caller's stream per tick in the kernel timeline)
-        const unsigned evf = tune_env("RC_SEQ_EVENT_SYSTEM", 0) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
+        // device-scope release: the hand-over is between two streams of this GPU
+        const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], evf));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], evf));
     }
@@ -628,7 +627,7 @@ int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
     for (int k = t0; k < t1 + kStages - 1; ++k) {
         const int e = (k - t0) & 3, ep = (k - t0 + 3) & 3;          // event slots of this tick / the previous tick
         // ---- per-row kernels and the weight-streaming GEMMs of tick k (second stream: after the previous tick's wide launches)
-        if (two && k > t0 && tune_env("RC_SEQ_SYNC_MODE", 0) != 3) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
+        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
         if (in_seg(k)) rc_launch_prep(ctx->ring[k % kRing], io_at(k), prm, B, 0, aux);
         if (int rc = group(k, 4, aux)) return rc;
         if (in_seg(k - 5)) rc_launch_fuse(ctx->ring[(k - 5) % kRing], io_at(k - 5), prm, B, aux);
@@ -636,13 +635,12 @@ int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
         if (in_seg(k - 10)) rc_launch_tail(ctx->ring[(k - 10) % kRing], io_at(k - 10), prm, ctx->body, B, 0, aux);
         if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
         // ---- the LSTM layer-steps of tick k (caller's stream: after the previous tick's second-stream work)
-        static const int sync_mode = tune_env("RC_SEQ_SYNC_MODE", 0);
-        if (two && k > t0 && sync_mode == 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-        for (int g = 0; g < 4; ++g) {
-            if (two && k > t0 && sync_mode == 1 && g == 3) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        // (The two hand-overs cost ~13 us of a 232 us tick -- timing-only probe without them, r02z; waiting in front of the last
+        // launch instead of the first, or releasing at device scope, changes nothing: the packets themselves are the cost.)
+        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        for (int g = 0; g < 4; ++g)
             if (int rc = group(k, g, st)) return rc;
-        }
-        if (two && sync_mode != 3) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
+        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
         ctx->stat_ticks += 1;
     }
     // the caller's stream continues after the last tail; every sub-net stepped (t1 - t0) times on every row
