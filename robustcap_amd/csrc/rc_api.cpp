@@ -399,6 +399,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     return RC_OK;
 }
 
+int tune_env(const char* name, int dflt);
 int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const std::vector<GemmProblem>* extra, hipStream_t st, bool fp32 = false) {
     for (int phase = 0; phase < (with_lin2 ? 4 : 3); ++phase) {
         std::vector<GemmProblem> ps;
@@ -408,7 +409,11 @@ int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const
             else ps.push_back(lstm_problem(ctx, s, phase - 1));
         }
         if (extra && phase < (int)extra->size()) ps.push_back((*extra)[phase]);
-        if (int rc = launch_problems(ctx, ps, nullptr, st, fp32)) return rc;
+        // linear1 / linear2 launches are latency chains of a few k-blocks per wave, not MFMA time: on the fp32-input kernels
+        // (deeper prefetch, 4 B instead of 6 B per weight) they are 1.7 us shorter each at batch 256 (r03c), and bitwise fma chains
+        static const int lin2_fp32 = tune_env("RC_LIN2_FP32", 1), lin1_fp32 = tune_env("RC_LIN1_FP32", 1);
+        const bool f = fp32 || (phase == 3 && lin2_fp32) || (phase == 0 && lin1_fp32);
+        if (int rc = launch_problems(ctx, ps, nullptr, st, f)) return rc;
     }
     return RC_OK;
 }
