@@ -399,7 +399,6 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     return RC_OK;
 }
 
-int tune_env(const char* name, int dflt);
 int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const std::vector<GemmProblem>* extra, hipStream_t st, bool fp32 = false) {
     for (int phase = 0; phase < (with_lin2 ? 4 : 3); ++phase) {
         std::vector<GemmProblem> ps;
@@ -409,10 +408,10 @@ int run_stage(rc_ctx* ctx, const std::vector<Stage>& nets, bool with_lin2, const
             else ps.push_back(lstm_problem(ctx, s, phase - 1));
         }
         if (extra && phase < (int)extra->size()) ps.push_back((*extra)[phase]);
-        // linear1 / linear2 launches are latency chains of a few k-blocks per wave, not MFMA time: on the fp32-input kernels
-        // (deeper prefetch, 4 B instead of 6 B per weight) they are 1.7 us shorter each at batch 256 (r03c), and bitwise fma chains
-        static const int lin2_fp32 = tune_env("RC_LIN2_FP32", 1), lin1_fp32 = tune_env("RC_LIN1_FP32", 1);
-        const bool f = fp32 || (phase == 3 && lin2_fp32) || (phase == 0 && lin1_fp32);
+        // linear2 launches are latency chains of a few k-blocks per wave, not MFMA time: on the fp32-input kernel (deeper
+        // prefetch, 4 B instead of 6 B per weight) they are 2 us shorter each at batch 256 (r03c), and bitwise fma chains.
+        // (linear1 likewise, -1.8 us, but sequence mode runs linear1 inside a split-product launch: kept equal, bit for bit.)
+        const bool f = fp32 || phase == 3;
         if (int rc = launch_problems(ctx, ps, nullptr, st, f)) return rc;
     }
     return RC_OK;
@@ -623,7 +622,7 @@ int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
             p.step_off = 1 + (f - t0);                                        // steps[row] stands still during the segment
             ps.push_back(p);
         }
-        return launch_problems(ctx, ps, nullptr, s);
+        return launch_problems(ctx, ps, nullptr, s, g == 5);               // linear2 on the fp32-input kernel, as in run_stage
     };
     if (two) {   // the second stream joins: everything enqueued so far on `st` (earlier frames, weight uploads) is visible to it
         HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));
