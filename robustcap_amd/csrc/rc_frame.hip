@@ -25,46 +25,22 @@
 // One wave, one body. pend_in / uv_count: the row's pending-updater mark and landmark refresh counter as they stand BEFORE this
 // frame (read from the state by rc_prep_kernel, handed over in registers when the previous frame's tail runs this in the same
 // wave -- rc_tail_kernel with a next frame).
-struct PrepLoads {             // what one lane of prep_body reads of its row's inputs
-    float x, y, cf;            // keypoint `lane` (< 33)
-    float Rcr[9];              // root IMU orientation (row-uniform)
-    float a3[3], a;            // acc[3 i .. 3 i + 2] of sensor i = lane / 3, acc[lane]      (lane < 18)
-    float o3[3], o;            // column cc of sensor i's orientation, ori[lane]              (lane < 54)
-};
-__device__ __forceinline__ PrepLoads prep_load(const FrameIO& io, const int row, const int lane) {
+__device__ __forceinline__ void prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
+                                          const int lane, const int first_frame, const int pend_in, const int uv_count) {
     const float* kp = io.j2d + row * io.s_j2d;
     const float* acc = io.acc + row * io.s_acc;
     const float* ori = io.ori + row * io.s_ori;
-    PrepLoads L;
-    L.x = L.y = L.cf = 0.f;
-    if (lane < 33) { L.x = kp[3 * lane]; L.y = kp[3 * lane + 1]; L.cf = kp[3 * lane + 2]; }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) L.Rcr[k] = ori[45 + k];                   // L139
-    L.a3[0] = L.a3[1] = L.a3[2] = L.a = 0.f;
-    if (lane < 18) {
-        const int i = lane / 3;
-        L.a3[0] = acc[3 * i]; L.a3[1] = acc[3 * i + 1]; L.a3[2] = acc[3 * i + 2];
-        L.a = acc[lane];
-    }
-    L.o3[0] = L.o3[1] = L.o3[2] = L.o = 0.f;
-    if (lane < 54) {
-        const float* o = ori + 9 * (lane / 9);
-        const int cc = lane % 3;
-        L.o3[0] = o[cc]; L.o3[1] = o[3 + cc]; L.o3[2] = o[6 + cc];
-        L.o = ori[lane];
-    }
-    return L;
-}
-__device__ __forceinline__ void prep_body(const FrameBuffers& fb, const PrepLoads& L, const rc_params_dev& prm, const int row,
-                                          const int lane, const int first_frame, const int pend_in, const int uv_count) {
-    const float x = L.x, y = L.y, cf = L.cf;
+    float x = 0.f, y = 0.f, cf = 0.f;
+    if (lane < 33) { x = kp[3 * lane]; y = kp[3 * lane + 1]; cf = kp[3 * lane + 2]; }
     const float c = wave_sum(cf) / 33.0f;                                 // L138
     const double c64 = (double)c;                                         // python-double compares
     const bool gt_lo = c64 > prm.conf_lo, is_hi = c64 >= prm.conf_hi;
     const bool refresh = !prm.live || uv_count == 0;
     float xn, yn;
     bbox_normalise(x, y, lane, xn, yn);                                   // L150-152
-    const float* Rcr = L.Rcr;
+    float Rcr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];                     // L139
     if (lane == 0) {
         unsigned f = 0;
         const bool vis = gt_lo || first_frame;
@@ -86,22 +62,25 @@ __device__ __forceinline__ void prep_body(const FrameBuffers& fb, const PrepLoad
         tr[1] = 0; tr[2] = 0; tr[4] = 0; tr[5] = 0; tr[6] = 0; tr[7] = 0;
     }
     if (lane < 18) {                                                      // accr = accc . Rcr, L142
-        const int j = lane % 3;
-        const float v = (L.a3[0] * Rcr[j] + L.a3[1] * Rcr[3 + j]) + L.a3[2] * Rcr[6 + j];
+        const int i = lane / 3, j = lane % 3;
+        const float v = (acc[3 * i] * Rcr[j] + acc[3 * i + 1] * Rcr[3 + j]) + acc[3 * i + 2] * Rcr[6 + j];
         fb.x2[rc_pk(row, lane, LD_X2)] = v;
         fb.x3[rc_pk(row, lane, LD_X3)] = v;
         fb.x78[rc_pk(row, lane, LD_X78)] = v;
-        fb.x4[rc_pk(row, lane, LD_X4)] = L.a;
-        fb.x6[rc_pk(row, lane, LD_X6)] = L.a;
+        const float a = acc[lane];
+        fb.x4[rc_pk(row, lane, LD_X4)] = a;
+        fb.x6[rc_pk(row, lane, LD_X6)] = a;
     }
     if (lane < 54) {                                                      // orir = Rcr^T . oric, L143
-        const int r = (lane % 9) / 3;
-        const float v = (Rcr[r] * L.o3[0] + Rcr[3 + r] * L.o3[1]) + Rcr[6 + r] * L.o3[2];
+        const int i = lane / 9, r = (lane % 9) / 3, cc = lane % 3;
+        const float* o = ori + 9 * i;
+        const float v = (Rcr[r] * o[cc] + Rcr[3 + r] * o[3 + cc]) + Rcr[6 + r] * o[6 + cc];
         fb.x2[rc_pk(row, 18 + lane, LD_X2)] = v;
         fb.x3[rc_pk(row, 18 + lane, LD_X3)] = v;
         fb.x78[rc_pk(row, 18 + lane, LD_X78)] = v;
-        fb.x4[rc_pk(row, 18 + lane, LD_X4)] = L.o;
-        fb.x6[rc_pk(row, 18 + lane, LD_X6)] = L.o;
+        const float a = ori[lane];
+        fb.x4[rc_pk(row, 18 + lane, LD_X4)] = a;
+        fb.x6[rc_pk(row, 18 + lane, LD_X6)] = a;
     }
     if (lane < 33) {
         const int k = 72 + 3 * lane;
@@ -112,7 +91,7 @@ __device__ __forceinline__ void prep_body(const FrameBuffers& fb, const PrepLoad
 
 __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
     const int row = blockIdx.x;
-    prep_body(fb, prep_load(io, row, threadIdx.x), prm, row, threadIdx.x, first_frame, fb.pend[row], fb.uv_count[row]);
+    prep_body(fb, io, prm, row, threadIdx.x, first_frame, fb.pend[row], fb.uv_count[row]);
 }
 
 // =================================================================================== fuse (L154-167, L178-180)
@@ -174,31 +153,6 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     float Rcr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];
-    // This kernel is one latency chain per body (one wave per CU at batch 256): every global read of the row's state, and
-    // the next frame's inputs of the chained prep, are requested here in one go instead of one round trip per use.
-    PrepLoads next_in = {};
-    if (has_next) next_in = prep_load(io_next, row, lane);
-    const float ct0 = fb.contact[row * 2], ct1 = fb.contact[row * 2 + 1];
-    const bool has_last = fb.has_last[row] != 0;
-    const int regime = fb.regime[row];
-    const double k64 = fb.kconf[row];
-    const float pc[3] = {fb.pc[row * 4], fb.pc[row * 4 + 1], fb.pc[row * 4 + 2]};
-    const float vr[3] = {fb.vr[row * 4], fb.vr[row * 4 + 1], fb.vr[row * 4 + 2]};
-    float lpf[6], ltr[3], g[3], fl6[18], ftr[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 6; ++c) lpf[c] = fb.last_pfoot[row * 6 + c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { ltr[c] = fb.last_tran[row * 3 + c]; g[c] = fb.gravity[row * 3 + c]; }
-#pragma unroll
-    for (int c = 0; c < 18; ++c) fl6[c] = fb.floor[row * 33 + 15 + c];     // entries 5..10 of the floor history
-    const bool ft_given = io.first_tran != nullptr;
-    if (ft_given) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ftr[c] = io.first_tran[row * 3 + c];
-    }
-    int n_floor = fb.n_floor[row];
-    const unsigned flags = fb.flags[row];
-    const int uvc = fb.uv_count[row];
 
     // L173: 6D -> global rotations (root-relative frame)
     if (lane < 24) {
@@ -232,12 +186,17 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
 
     // L187-203: root translation
-    const float c0 = sigmoidf_(ct0), c1 = sigmoidf_(ct1);                 // L170
+    const float c0 = sigmoidf_(fb.contact[row * 2]), c1 = sigmoidf_(fb.contact[row * 2 + 1]);   // L170
     const float cmax = fmaxf(c0, c1);
     const int foot = c1 > c0 ? 1 : 0;
+    const bool has_last = fb.has_last[row] != 0;
     const bool use_vel = (cmax < prm.contact_threshold) || !has_last;
+    const int regime = fb.regime[row];
+    const double k64 = fb.kconf[row];
+    const float pc[3] = {fb.pc[row * 4], fb.pc[row * 4 + 1], fb.pc[row * 4 + 2]};
     float tran[3];
     {
+        const float* vr = fb.vr + row * 4;
         float v[3];
         if (use_vel) {
             mat3_vec(Rcr, vr, v);
@@ -245,10 +204,10 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             for (int c = 0; c < 3; ++c) v[c] = v[c] * 3.0f / 60.0f;        // vel_scale / 60, L188
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = (foot ? lpf[3 + c] : lpf[c]) - pf[foot][c];            // L190
+            for (int c = 0; c < 3; ++c) v[c] = fb.last_pfoot[row * 6 + 3 * foot + c] - pf[foot][c];   // L190
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tran[c] = has_last ? ltr[c] + v[c] : v[c];
+        for (int c = 0; c < 3; ++c) tran[c] = has_last ? fb.last_tran[row * 3 + c] + v[c] : v[c];
     }
     bool far = false;
     if (regime == 2) {                                                     // L196-203
@@ -265,7 +224,10 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         }
     }
     // L206-221: floor height along gravity
+    const float* g = fb.gravity + row * 3;
     const bool on_ground = cmax > prm.contact_threshold;
+    const bool ft_given = io.first_tran != nullptr;
+    int n_floor = fb.n_floor[row];
     float p0[3], p1[3], pick[3] = {0.f, 0.f, 0.f};
     int appended = -1;
     {
@@ -286,7 +248,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         for (int q = 5; q < 11; ++q) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float e = (q == appended) ? pick[c] : fl6[3 * (q - 5) + c];
+                const float e = (q == appended) ? pick[c] : fb.floor[row * 33 + 3 * q + c];
                 m[c] = (q == 5) ? e : m[c] + e;
             }
         }
@@ -303,11 +265,13 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
     if (ft_given) {                                                        // L222-225
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tran[c] = ftr[c];
+        for (int c = 0; c < 3; ++c) tran[c] = io.first_tran[row * 3 + c];
     } else if (first_frame) {
         tran[0] = pc[0]; tran[1] = pc[1]; tran[2] = pc[2];
     }
+    const unsigned flags = fb.flags[row];
     const bool live = prm.live != 0;
+    const int uvc = fb.uv_count[row];
     const bool refresh = !live || uvc == 0;
     const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
     const int pend_next = (flags & RC_ROW_UPD) ? 1 : 0;
@@ -412,7 +376,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             fb.c2[fb.c2_layer_stride + row * 512 + e] = src[1536 + e];
         }
     }
-    if (has_next) prep_body(fb, next_in, prm, row, lane, 0, pend_next, uvc_next);
+    if (has_next) prep_body(fb, io_next, prm, row, lane, 0, pend_next, uvc_next);
 }
 
 // ================================================================================================== reset

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timeline of a steady-state window from a rocprofv3 results database (rocpd sqlite): per kernel name and stream the
 launches, busy time and the gaps between consecutive kernels of the same stream; plus the union busy time over all streams.
-    python tools/rocpd_timeline.py x_results.db [skip_fraction=0.5] [window_us=2000]"""
+    python tools/rocpd_timeline.py x_results.db [skip_fraction_of_dispatches=0.5] [window_us=2000]"""
 import sqlite3, sys, collections
 
 def main(path, skip=0.5, window_us=2000.0):
@@ -14,9 +14,11 @@ def main(path, skip=0.5, window_us=2000.0):
     rows = cur.execute(f"select s.{name_col}, d.stream_id, d.queue_id, d.start, d.end, d.grid_size_x, d.workgroup_size_x from {disp} d "
                        f"join {sym} s on d.kernel_id = s.id order by d.start").fetchall()
     t_lo, t_hi = rows[0][3], rows[-1][4]
-    w0 = t_lo + (t_hi - t_lo) * skip
+    w0 = rows[min(len(rows) - 1, int(len(rows) * skip))][3]                # the window starts at dispatch number skip * N
     w1 = w0 + window_us * 1e3
     win = [r for r in rows if r[3] >= w0 and r[4] <= w1]
+    if not win:
+        raise SystemExit(f"no dispatch inside the window ({skip:.0%} + {window_us:.0f} us of a {(t_hi - t_lo) / 1e3:.0f} us trace): pick another skip fraction")
     print(f"{len(rows)} dispatches, window {window_us:.0f} us from {skip:.0%}: {len(win)} dispatches")
     # union busy
     busy, cur_s, cur_e = 0, None, None
