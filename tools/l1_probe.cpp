@@ -20,6 +20,57 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // flight per wave, s_waitcnt vmcnt(DEPTH - 1) in front of the use of the oldest): hipcc's own waits would be vmcnt(0) here.
 #define STR_(x) #x
 #define STR(x) STR_(x)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// the same with v_mfma_f32_32x32x16_bf16 (twice the MACs and cycles per instruction: half the MFMA issue slots per MAC)
+template <int MFMA_PER_LOAD, int VALU_PER_MFMA, int DEPTH, int NWAVE = 4>
+__global__ __launch_bounds__(64 * NWAVE) void k_mix32(const u32x4* __restrict__ src, long long window_u4, int iters, unsigned long long* cyc, float* sink) {
+    __shared__ float pad[24 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32x4* p = src + ((long long)blockIdx.x * NWAVE + wave) * window_u4 + lane;
+    u32x4 buf[DEPTH ? DEPTH : 1];
+#pragma unroll
+    for (int u = 0; u < (DEPTH ? DEPTH : 1); ++u) buf[u] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+    float v[4] = {1.f, 2.f, 3.f, 4.f};
+    long long off = 0;
+    if (DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(buf[u]) : "v"(p) : "memory");
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < (DEPTH ? DEPTH : 8); ++u) {
+            const int ub = DEPTH ? u : 0;
+            if (DEPTH) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[ub]) : "n"(DEPTH ? DEPTH - 1 : 0));
+#pragma unroll
+            for (int m = 0; m < MFMA_PER_LOAD; ++m) {
+                acc[(m + u) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, buf[ub]), __builtin_bit_cast(bf16x8, buf[ub]), acc[(m + u) & 3], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < VALU_PER_MFMA; ++q) v[q & 3] = v[q & 3] * 1.0001f + 0.5f;
+            }
+            if (DEPTH) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(buf[ub]) : "v"(p + off), "v"(acc[(MFMA_PER_LOAD - 1 + u) & 3]) : "memory");
+                off += 64;
+                if (off >= window_u4) off = 0;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s += acc[a][0] + acc[a][1];
+#pragma unroll
+    for (int u = 0; u < (DEPTH ? DEPTH : 1); ++u) s += __uint_as_float(buf[u][1] & 0x3fffffffu);
+    if (s == 12345.678f) sink[0] = s + pad[lane];
+    if (lane == 0) cyc[blockIdx.x * NWAVE + wave] = t1 - t0;
+}
+
 template <int MFMA_PER_LOAD, int VALU_PER_MFMA, int DEPTH, int NWAVE = 4>
 __global__ __launch_bounds__(64 * NWAVE) void k_mix(const u32x4* __restrict__ src, long long window_u4, int iters, unsigned long long* cyc, float* sink) {
     __shared__ float pad[24 * 1024];                   // 96 KiB: one workgroup per CU
@@ -171,6 +222,13 @@ int main() {
         VG(0, 0, 8, win) VG(0, 0, 24, win) LD(0, 0, 8, win) LD(0, 0, 24, win)
         VG(5, 0, 24, win) LD(5, 0, 24, win) VG(5, 2, 24, win) LD(5, 2, 24, win) VG(8, 0, 24, win) LD(8, 0, 24, win)
     }
+    // 32x32x16 MFMAs (32 cycles each): the same filler densities per MAC are half as many per instruction gap
+    printf("-- v_mfma_f32_32x32x16_bf16, one wave per SIMD (cycles per MFMA: floor 32)\n");
+#define VG32(N, V, D, WIN)                                                                                                   \
+    snprintf(nm, sizeof nm, "mfma32 %2d in flight, %d MFMA+%dv/load, %3lldK", D, N, V, (long long)(WIN) / 1024);               \
+    run(nm, [&] { hipLaunchKernelGGL((k_mix32<N, V, D>), dim3(n_wg), dim3(256), 0, 0, d_src, (long long)(WIN) / 16, iters, d_cyc, d_sink); }, iters, D, (double)(D ? D : 8) * N);
+    VG32(4, 0, 0, 16384) VG32(4, 2, 0, 16384) VG32(4, 3, 0, 16384) VG32(4, 4, 0, 16384)
+    VG32(2, 0, 24, 16384) VG32(3, 0, 24, 16384) VG32(2, 2, 24, 16384) VG32(3, 2, 24, 16384) VG32(3, 3, 24, 16384) VG32(2, 3, 24, 16384) VG32(2, 4, 24, 16384)
     // two waves per SIMD (512-thread workgroups, 256 VGPRs per wave): does the second wave's issue hide behind the first's MFMAs?
     n_wave = 8;
     printf("-- two waves per SIMD\n");
