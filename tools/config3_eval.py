@@ -43,6 +43,22 @@ def main():
         if smp and info:
             out[key]["smplify_rows_optimised"] = int(sum(1 for v in info.values() if v["status"] == 1))
             out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
+    if rank == 0 and world == 1:     # where the net-only time goes: the harness's three steps timed one by one
+        mine = ev.rows_of(ds)
+        net = nets[(rows, id(sd))]
+        bd = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        j2d, acc, ori, grav = ev.camera_inputs_rows(ds, mine, T)
+        ft = ev.first_translations(ds, mine)
+        torch.cuda.synchronize(); bd["camera_inputs_s"] = round(time.perf_counter() - t0, 4)
+        net.reset_states(); net.gravityc = grav
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p_, t_ = net.forward_sequence(j2d, acc, ori, first_tran=ft)
+        torch.cuda.synchronize(); bd["forward_sequence_s"] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
+        p_.cpu(); t_.cpu()
+        bd["outputs_to_host_s"] = round(time.perf_counter() - t0, 4)
+        out["net_only"]["breakdown"] = bd
     if rank == 0:
         model = ParametricModel(body=body)
         model.set_regressor(synth.make_j_regressor(4), 14)
