@@ -157,6 +157,22 @@ __device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, u32x4& 
 }
 
 template <int MR, int NC>
+__device__ __forceinline__ void load_kblock_b(FragS<MR, NC>& f, const u32x4* pb, long long bstride) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+}
+template <int MR, int NC>
+__device__ __forceinline__ void load_kblock_a(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
+        f.a1[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff + 256);
+    }
+}
+
+template <int MR, int NC>
 __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[MR][NC]) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -253,10 +269,28 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     // per-lane A pointers of the MR 16-row blocks (rows may come from anywhere in the batch after compaction)
     const float* pa0[MR];
     const float* pa1[MR];
+    int row_r[MR], st_r[MR];
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-        const int row = s_rows[16 * r + i];
-        const int st = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row] + P.step_off : 0;
+        row_r[r] = s_rows[16 * r + i];
+        st_r[r] = (P.seg[0].par_mode | P.seg[1].par_mode) ? P.steps[row_r[r]] : 0;
+    }
+    // split products: the first k-blocks' weight planes depend on nothing the prologue computes -- requested here, behind the
+    // step-counter reads (vmcnt completes in order) and in front of everything that waits for those, they travel while the
+    // activation pointers are formed (a tile waits ~3 us for its first weights: profiles/r02_kloop_ablation.txt)
+    FragS<MR, NC> fa = {}, fb = {};
+    const int Qs = P.Kp / 32, Qws = Qs / RC_NW;                     // k-blocks per wave (K' % 128 == 0 -> >= 1)
+    const long long bs = (long long)Qs * 192;                       // uint4 between consecutive 16-column blocks (3 planes x 64 lanes)
+    const u32x4* pbs = reinterpret_cast<const u32x4*>(P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * 192 + lane;
+    constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 12) * 3 + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
+    if constexpr (SPLIT && !(RC_ABL_SPLIT & 9)) {
+        load_kblock_b<MR, NC>(fa, pbs, bs);
+        if constexpr (DEEP) load_kblock_b<MR, NC>(fb, pbs + (long long)min(1, Qws - 1) * 192, bs);
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int row = row_r[r];
+        const int st = st_r[r] + ((P.seg[0].par_mode | P.seg[1].par_mode) ? P.step_off : 0);
         const float* pp[2];
 #pragma unroll
         for (int sgi = 0; sgi < 2; ++sgi) {
@@ -296,10 +330,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     // the remainder (< D chunks, already loaded) is predicated. D = 2 for the wide tiles (their 64-80 MFMAs per chunk
     // cover the latency), D = 8 for the 16-row tiles whose 4-8 MFMAs per chunk do not.
     if constexpr (SPLIT) {              // split-bf16 products: k-blocks of 32, two named buffers for every tile shape
-        const int Qs = P.Kp / 32, Qws = Qs / RC_NW;                 // k-blocks per wave (K' % 128 == 0 -> >= 1)
-        const long long bs = (long long)Qs * 192;                   // uint4 between consecutive 16-column blocks (3 planes x 64 lanes)
-        const u32x4* pbs = reinterpret_cast<const u32x4*>(P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * 192 + lane;
         const int kb0 = wave * Qws * 32;
+#define LOADS_A(F, QI)                                                                                              \
+    do {                                                                                                            \
+        const int k_ = kb0 + (QI) * 32;                                                                             \
+        if (RC_ABL_SPLIT & 9) LOADS(F, QI);                                                                         \
+        else if (k_ < K0) load_kblock_a<MR, NC>(F, pa0, (long long)k_ * 16);                                        \
+        else load_kblock_a<MR, NC>(F, pa1, (long long)(k_ - K0) * 16);                                              \
+    } while (0)
 #define LOADS(F, QI)                                                                                                \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
@@ -309,15 +347,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         // With the MFMA time cut 2.7x the K loop is bound by what a wave keeps in flight (one k-block = 23 KiB for a 64 x 80
         // tile; 4 waves x 23 KiB / ~2 us of L2 / fabric latency = the 47 GB/s per CU the two-buffer loop was measured at):
         // tile shapes whose registers allow it run THREE k-block buffers (two blocks in flight behind every MFMA block).
-        constexpr bool DEEP = DEEPOK && MR >= 2 && (MR * 8 + NC * 12) * 3 + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
         int q = 0;
         // (Spreading the loads between the MFMAs -- sched_group_barrier patterns, or slices of the next block's loads in front of
         // every row block's MFMAs -- was measured at -2 % / +-1 %: profiles/r02_kloop_ablation.txt.)
 #define STEP(FL, QL, FM) do { LOADS(FL, QL); SB(); mma_kblock<MR, NC>(FM, acc); SB(); } while (0)
         if constexpr (DEEP) {
-            FragS<MR, NC> fa = {}, fb = {}, fc = {};
-            LOADS(fa, 0);
-            LOADS(fb, min(1, Qws - 1));
+            FragS<MR, NC> fc = {};
+            LOADS_A(fa, 0);
+            LOADS_A(fb, min(1, Qws - 1));
             for (; q + 3 <= Qws; q += 3) {  // prefetch indices past the end are clamped: a redundant, valid load, no branch
                 STEP(fc, min(q + 2, Qws - 1), fa);
                 STEP(fa, min(q + 3, Qws - 1), fb);
@@ -326,8 +363,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             if (q < Qws) mma_kblock<MR, NC>(fa, acc);
             if (q + 1 < Qws) mma_kblock<MR, NC>(fb, acc);
         } else {
-            FragS<MR, NC> fa = {}, fb = {};
-            LOADS(fa, 0);
+            LOADS_A(fa, 0);
             for (; q + 2 <= Qws; q += 2) {
                 STEP(fb, min(q + 1, Qws - 1), fa);
                 STEP(fa, min(q + 2, Qws - 1), fb);
@@ -335,6 +371,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             if (q < Qws) mma_kblock<MR, NC>(fa, acc);
         }
 #undef STEP
+#undef LOADS_A
 #undef LOADS
     } else if constexpr (D == 2) {      // wide tiles: two named buffers (the array form below schedules worse here)
         Frag<MR, NC> fa = {}, fb = {};
