@@ -468,6 +468,23 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf_(cn);
         }
     } else {
+        // packed outputs whose columns come in whole groups of four (linear1 -> x1: the A operand of the LSTM's first layer):
+        // four columns per item, 16-byte LDS reads and one 16-byte store -- the same sums in the same order
+        const bool vec4 = P.out_packed && P.out_bit == 0 && ((P.out_col0 | P.N) & 3) == 0;
+        if (vec4) {
+            for (int item = tid; item < MT * (NT / 4); item += RC_NW * 64) {
+                const int rr = item / (NT / 4), c4 = (item - rr * (NT / 4)) * 4;
+                if (rr >= nrows) continue;
+                const int n = n_tile * NT + c4;
+                if (n >= P.N) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + c4]);
+#pragma unroll
+                for (int w = 1; w < RC_NW; ++w) v += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + c4]);
+                v += *reinterpret_cast<const f32x4*>(&P.bias[n]);
+                if (P.epi == RC_EPI_RELU) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+                *reinterpret_cast<f32x4*>(&P.out[rc_pk(s_rows[rr], P.out_col0 + n, P.ldo)]) = v;
+            }
+        } else
         for (int item = tid; item < MT * NT; item += RC_NW * 64) {
             const int rr = item / NT, col = item - rr * NT;
             if (rr >= nrows) continue;
