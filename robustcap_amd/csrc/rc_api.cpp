@@ -991,12 +991,19 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
             HIP_TRY(ctx, hipHostMalloc((void**)&ctx->scan_codes_h, need, hipHostMallocDefault));
             ctx->scan_cap = need;
         }
-        if (!ctx->scan_state_h) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->scan_state_h, (size_t)B * 2 * sizeof(int), hipHostMallocDefault));
+        if (!ctx->scan_state_h) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->scan_state_h, (size_t)B * 3 * sizeof(int), hipHostMallocDefault));
         rc_launch_scan_conf(j2dc, rs_j2d, B, T, ctx->prm.conf_lo, ctx->prm.conf_hi, ctx->scan_codes_d, st);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->scan_codes_h, ctx->scan_codes_d, need, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->scan_state_h, ctx->fb.first_reach, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
-        std::vector<unsigned char> pend_b(B);
-        HIP_TRY(ctx, hipMemcpyAsync(pend_b.data(), ctx->fb.pend, (size_t)B, hipMemcpyDeviceToHost, st));
+        unsigned char* pend_b = reinterpret_cast<unsigned char*>(ctx->scan_state_h + 2 * B);     // pinned, like the other two
+        HIP_TRY(ctx, hipMemcpyAsync(pend_b, ctx->fb.pend, (size_t)B, hipMemcpyDeviceToHost, st));
+        {   // a blocking wait wakes up tens of microseconds late: poll for a bounded while first (the stream may still hold
+            // milliseconds of earlier frames, which a sleeping wait serves better)
+            const auto t_spin = std::chrono::steady_clock::now();
+            static const int spin = tune_env("RC_SEQ_SPIN", 1);
+            while (spin && hipStreamQuery(st) == hipErrorNotReady &&
+                   std::chrono::steady_clock::now() - t_spin < std::chrono::microseconds(300)) { }
+        }
         HIP_TRY(ctx, hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) ctx->scan_state_h[B + b] = pend_b[b];
         plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h, ctx->scan_state_h + B, (flags & RC_FLAG_FIRST_FRAME) != 0,

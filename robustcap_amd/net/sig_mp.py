@@ -163,6 +163,22 @@ class Net:
     def _prep(self, t, shape):
         return t.to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
 
+    def _prep_rows(self, t, B, T, width):
+        """[B, T, ...] input of a sequence call as (tensor, row stride in floats) without a copy when it already is float32
+        on the device with contiguous frames -- e.g. a slice ``x[:, a:b]`` of a longer contiguous sequence tensor (the C ABI
+        takes the row stride; only a frame's ``width`` floats have to be contiguous and frames ``width`` apart)."""
+        if t.is_cuda and t.dtype == torch.float32 and t.dim() >= 3 and t.shape[0] == B and t.shape[1] == T:
+            inner = tuple(t.shape[2:])
+            st = t.stride()
+            expect, ok = 1, True
+            for d in range(t.dim() - 1, 1, -1):                       # the frame itself contiguous
+                ok = ok and (st[d] == expect or t.shape[d] == 1)
+                expect *= t.shape[d]
+            if ok and expect == width and (st[1] == width or T == 1) and (st[0] >= T * width or B == 1) and inner:
+                return t, int(st[0]) if B > 1 else T * width
+        t = self._prep(t, (B, T, width))
+        return t, T * width
+
     @torch.no_grad()
     def forward_batch(self, j2dc, accc, oric, first_tran=None, first_frame=False):
         """B bodies, one frame. Inputs [B,33,3], [B,6,3], [B,6,3,3]; returns device tensors pose [B,24,3,3], tran [B,3]."""
@@ -219,11 +235,11 @@ class Net:
         B = self.batch
         T = j2dc.shape[1]
         self._sync_gravity()
-        j2dc, accc, oric = self._prep(j2dc, (B, T, 99)), self._prep(accc, (B, T, 18)), self._prep(oric, (B, T, 54))
+        (j2dc, rs_j), (accc, rs_a), (oric, rs_o) = self._prep_rows(j2dc, B, T, 99), self._prep_rows(accc, B, T, 18), self._prep_rows(oric, B, T, 54)
         ft = None if first_tran is None else self._prep(first_tran, (B, 3))
         pose = torch.empty(B, T, 24, 3, 3, device=self.device)
         tran = torch.empty(B, T, 3, device=self.device)
-        rc = self._lib.rc_sequence(self._ctx, T, _lib.ptr(j2dc), T * 99, _lib.ptr(accc), T * 18, _lib.ptr(oric), T * 54, _lib.ptr(ft),
+        rc = self._lib.rc_sequence(self._ctx, T, _lib.ptr(j2dc), rs_j, _lib.ptr(accc), rs_a, _lib.ptr(oric), rs_o, _lib.ptr(ft),
                                    _lib.RC_FLAG_FIRST_FRAME if first_frame else 0, _lib.ptr(pose), T * 216, _lib.ptr(tran), T * 3,
                                    _lib.stream_ptr())
         _lib.check(self._ctx, rc, "rc_sequence")

@@ -126,3 +126,24 @@ def test_sequence_mode_respects_switches_and_live(synth_assets):
     net.gravityc = t(m["gravityc"])
     net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
     assert net.sequence_stats()[0] == 0
+
+
+def test_row_strided_inputs_need_no_copy(synth_assets):
+    """forward_sequence takes slices x[:, a:b] of longer device tensors as they are (row stride through the C ABI): same result,
+    bit for bit, as the contiguous copies."""
+    import bench
+    B, T = 24, 40
+    m = bench.make_inputs(synth_assets["body"], B, T, "mixed", seed=9)
+    j, a, o = (t(m[k]).cuda() for k in ("j2dc", "accc", "oric"))
+    outs = []
+    for strided in (True, False):
+        net = _net(synth_assets, B, True)
+        net.gravityc = t(m["gravityc"])
+        sl = (lambda x: x[:, 3:33]) if strided else (lambda x: x[:, 3:33].contiguous())
+        if strided:
+            assert not j[:, 3:33].is_contiguous() and net._prep_rows(j[:, 3:33], B, 30, 99)[1] == T * 99
+        net.forward_sequence(j[:, :3], a[:, :3], o[:, :3], first_tran=t(m["first_tran"]))
+        p, tr = net.forward_sequence(sl(j), sl(a), sl(o))
+        torch.cuda.synchronize()
+        outs.append((p, tr))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

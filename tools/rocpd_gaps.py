@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Idle gaps between consecutive kernel dispatches (all queues merged) in a rocprofv3 results database: the largest gaps of the
-last `window_ms` of the trace with the kernels on either side.    python tools/rocpd_gaps.py x_results.db [window_ms=30] [top=25]"""
+last `window_ms` of the trace with the kernels on either side.    python tools/rocpd_gaps.py x_results.db [window_ms=30] [top=25 | -min_gap_us: in time order]"""
 import sqlite3, sys
 
 def main(path, window_ms=30.0, top=25):
@@ -22,7 +22,10 @@ def main(path, window_ms=30.0, top=25):
     idle = sum(g for g, _ in gaps)
     print(f"{len(rows)} dispatches in the last {span / 1e6:.2f} ms; idle {idle / 1e3:.1f} us in {len(gaps)} gaps")
     short = lambda n: n.split("(")[0][:48]
-    for g, k in sorted(gaps, reverse=True)[:top]:
+    order = sorted(gaps, reverse=True)[:top]
+    if top < 0:                       # negative `top`: every gap of at least -top us, in time order
+        order = [(g, k) for g, k in gaps if g >= -top * 1e3]
+    for g, k in order:
         print(f"  gap {g / 1e3:8.1f} us at +{(rows[k][1] - rows[0][1]) / 1e3:9.1f} us   {short(rows[k - 1][0])}  ->  {short(rows[k][0])}")
 
 if __name__ == "__main__":
