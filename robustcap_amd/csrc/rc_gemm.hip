@@ -62,7 +62,7 @@ struct Frag {                 // one chunk (16 k): a float4 per lane for each of
     f32x4 b[NC];
 };
 
-template <int MR, int NC>
+template <int MR, int NC, bool NTL = false>
 __device__ __forceinline__ void load_chunk(Frag<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const float* pb,
                                            long long bstride) {
 #pragma unroll
@@ -70,7 +70,10 @@ __device__ __forceinline__ void load_chunk(Frag<MR, NC>& f, const float* const (
         if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
 #pragma unroll
     for (int j = 0; j < NC; ++j)
-        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) f.b[j] = *reinterpret_cast<const f32x4*>(pb + j * bstride);
+        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) {
+            if constexpr (NTL) f.b[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pb + j * bstride));
+            else f.b[j] = *reinterpret_cast<const f32x4*>(pb + j * bstride);
+        }
 }
 
 template <int MR, int NC>
@@ -210,7 +213,7 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int MR, int NC, int D, bool PIPE, bool SPLIT = false, bool DEEPOK = true>
+template <int MR, int NC, int D, bool PIPE, bool SPLIT = false, bool DEEPOK = true, bool NTW = false>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + (MR >= 8 ? 4 : LDS_PAD);   // 128-row tiles: 140 KB with pad 4
 #ifdef RC_TRACE_TILES
@@ -318,8 +321,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define LOADC(F, QI)                                                                                      \
     do {                                                                                                  \
         const int k_ = kbase + (QI) * RC_KC;                                                              \
-        if (k_ < K0) load_chunk<MR, NC>(F, pa0, (long long)k_ * 16, pb + (long long)(QI) * 256, bstride);  \
-        else load_chunk<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pb + (long long)(QI) * 256, bstride);   \
+        if (k_ < K0) load_chunk<MR, NC, NTW>(F, pa0, (long long)k_ * 16, pb + (long long)(QI) * 256, bstride);  \
+        else load_chunk<MR, NC, NTW>(F, pa1, (long long)(k_ - K0) * 16, pb + (long long)(QI) * 256, bstride);   \
     } while (0)
 #define SB() do { if (PIPE) __builtin_amdgcn_sched_barrier(0); } while (0)
     // The steady-state loop has NO conditionals on the load path other than the wave-uniform segment select: with a
@@ -600,17 +603,24 @@ __global__ __launch_bounds__(RC_NW * 64, 2) void rc_gemm_mid_split_kernel(const 
 // workgroups fill a CU's register file and lock the wide tiles' 300-register waves out; a variant with its LDS padded to
 // 60 KB, so that only one fits beside a wide-tile workgroup, still stretched a 116 us rnn4 launch to 150-220 us.)
 #define RC_SMALL_LDS_FLOATS (RC_LDS_HEAD + RC_NW * 16 * (16 * 2 + LDS_PAD))
-template <bool SPLIT>
+template <bool SPLIT, bool NTW = false>
 __device__ __forceinline__ void small_tiles(const GemmLaunch& L, float* s_mem) {
     int pi, m_tile, n_tile;
     if (!locate_tile(L, pi, m_tile, n_tile)) return;
     const GemmProblem& P = L.p[pi];
-    if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem);
-    else gemm_tile<1, 1, 8, true, SPLIT>(P, L.B, m_tile, n_tile, s_mem);
+    if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT, true, NTW>(P, L.B, m_tile, n_tile, s_mem);
+    else gemm_tile<1, 1, 8, true, SPLIT, true, NTW>(P, L.B, m_tile, n_tile, s_mem);
 }
 __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
     small_tiles<false>(L, s_mem);
+}
+// Every weight slice of the launch is read by ONE workgroup (a single row tile per column tile: live mode, transition steps,
+// linear2 at up to 16 rows): non-temporal weight loads -- measured 127 -> 123 us on the live frame's p50; with two row tiles
+// per slice (batch 32) they cost 8 % instead, so the choice is per launch.
+__global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_nt_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
+    small_tiles<false, true>(L, s_mem);
 }
 __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_split_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
@@ -632,7 +642,10 @@ bool rc_gemm_is_mid(const GemmLaunch& L) {
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
     const dim3 g(total_wg), b(RC_NW * 64);
     if (rc_gemm_is_small(L)) {
+        bool single_reader = true;
+        for (int q = 0; q < L.n; ++q) single_reader = single_reader && L.p[q].m_tiles == 1;
         if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
+        else if (single_reader) hipLaunchKernelGGL(rc_gemm_small_nt_kernel, g, b, 0, s, L);
         else hipLaunchKernelGGL(rc_gemm_small_kernel, g, b, 0, s, L);
     } else if (rc_gemm_is_mid(L)) {
         if (L.split) hipLaunchKernelGGL(rc_gemm_mid_split_kernel, g, b, 0, s, L);
