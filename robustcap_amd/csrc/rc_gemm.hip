@@ -17,6 +17,7 @@
 // Row selection is stateless: every workgroup derives the compacted list of active rows from the per-row flag
 // bytes itself (one ballot per wave), so masked sub-steps (vision branch on/off) cost only the rows they touch.
 #include "rc_internal.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -615,9 +616,9 @@ __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const Gemm
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
     small_tiles<false>(L, s_mem);
 }
-// Every weight slice of the launch is read by ONE workgroup (a single row tile per column tile: live mode, transition steps,
-// linear2 at up to 16 rows): non-temporal weight loads -- measured 127 -> 123 us on the live frame's p50; with two row tiles
-// per slice (batch 32) they cost 8 % instead, so the choice is per launch.
+// Live frames (one frame per host round trip), every weight slice read by ONE workgroup: non-temporal weight loads -- measured
+// 127 -> 122 us on the live frame's p50. Not for throughput runs: back-to-back frames at batch 1-16 lose 6-11 % with them (what
+// the ordinary loads leave in the Infinity Cache serves the next frame), two row tiles per slice (batch 32) 8 %.
 __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_nt_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
     small_tiles<false, true>(L, s_mem);
@@ -642,7 +643,7 @@ bool rc_gemm_is_mid(const GemmLaunch& L) {
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
     const dim3 g(total_wg), b(RC_NW * 64);
     if (rc_gemm_is_small(L)) {
-        bool single_reader = true;
+        bool single_reader = L.pad_ != 0;      // GemmLaunch.pad_: 1 = launch of a live frame (rc_api.cpp: launch_problems)
         for (int q = 0; q < L.n; ++q) single_reader = single_reader && L.p[q].m_tiles == 1;
         if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
         else if (single_reader) hipLaunchKernelGGL(rc_gemm_small_nt_kernel, g, b, 0, s, L);
