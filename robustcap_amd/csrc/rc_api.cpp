@@ -112,7 +112,7 @@ struct rc_ctx {
     long long timed_launches = 0;
     // sequence mode (rc_sequence on all-visible stretches): skewed stage pipeline, one gate-GEMM launch per tick
     bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
-    bool live_launch = false;            // set while a live frame is captured / launched (GemmLaunch.pad_)
+    bool live_launch = false;            // set while a live frame is captured / launched (GemmLaunch.live)
     int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (rc_set_sequence_mode)
     int seq_min_frames = 48;             // shortest stretch worth filling and draining the 11-stage pipeline for (break-even ~40)
     bool ring_ready = false;
@@ -367,7 +367,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     GemmLaunch L{};
     L.B = ctx->B;
     L.split = (ctx->gemm_split && !fp32) ? 1 : 0;
-    L.pad_ = ctx->live_launch ? 1 : 0;
+    L.live = ctx->live_launch ? 1 : 0;
     // XCD-aligned problems first so that (block id % 8) is the XCD for them
     std::vector<GemmProblem> ordered;
     for (auto& p : ps) if ((p.n_tiles & 7) == 0) ordered.push_back(p);

@@ -643,7 +643,7 @@ bool rc_gemm_is_mid(const GemmLaunch& L) {
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
     const dim3 g(total_wg), b(RC_NW * 64);
     if (rc_gemm_is_small(L)) {
-        bool single_reader = L.pad_ != 0;      // GemmLaunch.pad_: 1 = launch of a live frame (rc_api.cpp: launch_problems)
+        bool single_reader = L.live != 0;      // a live frame's launch (rc_api.cpp: launch_problems)
         for (int q = 0; q < L.n; ++q) single_reader = single_reader && L.p[q].m_tiles == 1;
         if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
         else if (single_reader) hipLaunchKernelGGL(rc_gemm_small_nt_kernel, g, b, 0, s, L);

@@ -85,7 +85,7 @@ struct GemmLaunch {
     int n;                  // problems
     int B;                  // rows in the batch
     int split;              // 1: products as split-bf16 partial products on the bf16 MFMA (rc_gemm.hip: mma_kblock), W -> Ws
-    int pad_;               // 1: launch of a live frame (16-row launches then stream their weights with non-temporal loads)
+    int live;               // 1: launch of a live frame (16-row launches then stream their weights with non-temporal loads)
     GemmProblem p[RC_MAX_PROB];
 };
 
