@@ -30,7 +30,6 @@ def run(net, m, n):
 def run_c(net, m, n):
     """The library call alone (rc_live_step through ctypes on preallocated host tensors): what a C caller of the ABI sees."""
     import ctypes as C
-    from robustcap_amd import _lib
     t = torch.from_numpy
     T = m["j2dc"].shape[1]
     ins = [(t(m["j2dc"][0, k]).contiguous(), t(m["accc"][0, k]).contiguous(), t(m["oric"][0, k]).contiguous()) for k in range(T)]
