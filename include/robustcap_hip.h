@@ -118,26 +118,38 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
 int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode);
 int rc_get_gemm_mode(const rc_ctx* ctx);
 
-/* Sequence mode of rc_sequence (on by default). With mode = 1 every rc_sequence call of T >= 2 frames first classifies
+/* Sequence mode of rc_sequence (on by default). With mode >= 1 every rc_sequence call of T >= 2 frames first classifies
  * each (frame, row) on the device (the arithmetic of the per-frame prep kernel), reads the codes back -- ONE
  * synchronisation of `stream` per call -- and plans the launches on the host:
- *   - stretches of >= min_frames frames on which every row sees the camera (c > conf_lo), no row fires the one-shot
- *     init_net (net/sig_mp.py:178-183) and no deferred vision-updater step is pending run on the WAVEFRONT engine: the 11
- *     stages of a frame are skewed over consecutive ticks, one gate-GEMM launch per tick carries all 24 GEMM problems
- *     (each on its own frame), the per-row kernels run beside it on a context-owned second stream. This is the full-sequence
- *     form of the recurrence (the reference's own is RNN.forward over packed sequences, articulate/utils/torch/rnn.py:129-133);
- *     outputs are bitwise those of the frame-stepped launches;
- *   - every other frame runs the frame-stepped launches, without the three transition launches when the plan proves that
- *     no row needs one.
+ *   - the PER-ROW-CURSOR WAVEFRONT engine runs every frame but one that takes first_frame / first_tran: the stages of a
+ *     frame (prep | linear1 | LSTM l0 | l1 | linear2 of {rnn2, rnn4} | fuse | the same four of {rnn6, rnn3, rnn7, rnn8} |
+ *     tail) are skewed over consecutive ticks and a 16-slot ring, four gate-GEMM launches per tick carry the stages of up
+ *     to ten frames, the per-row kernels run beside them on a context-owned second stream. Rows are independent, so each
+ *     row has its own frame cursor: the vision updater's feedback (net/sig_mp.py:264-271) and the one-shot init_net
+ *     (L178-183) make only THAT row wait (10 / 8 ticks, once per occlusion / once per sequence) while the batch keeps
+ *     ticking; the updater's rnn6 / rnn4 steps ride the launches of the ring slot that starts when the frame's tail runs.
+ *     This is the full-sequence form of the recurrence (the reference's own is RNN.forward over packed sequences,
+ *     articulate/utils/torch/rnn.py:129-133); every row's outputs and states are bitwise those of the frame-stepped launches;
+ *   - mode 1 takes that engine when the plan's cost estimate beats the frame-stepped launches (short calls with lagging
+ *     rows do not) and the call has >= min_frames frames; mode 2 takes it whenever the call has >= min_frames frames;
+ *   - frame-stepped frames run without the three transition launches when the plan proves that no row needs one.
  * mode = 0: frame-stepped launches only, no pre-pass, no synchronisation. Live contexts (rc_params.live) always behave
  * like mode 0. rc_get_sequence_stats: frames run by each engine and ticks launched since rc_create (any may be NULL).
- * rc_plan_sequence is the planner alone on HOST data (tests): codes[T*B] (0: c <= lo, 1: mid, 2: c >= hi; frame-major),
- * first_reach[B], pend[B] -> mode_out[T] (0 frame-stepped with transition launches, 1 without, 2 wavefront). */
+ * rc_plan_sequence (frame-stepped marks; all-visible stretches of the round-2 engine, RC_SEQ_ENGINE=1) and rc_plan_wave are
+ * the planners alone on HOST data (tests): codes[T*B] (0: c <= lo, 1: mid, 2: c >= hi; frame-major), first_reach[B],
+ * pend[B] (state in front of frame t0) -> mode_out[T] (0 frame-stepped with transition launches, 1 without, 2 wavefront);
+ * rc_plan_wave -> *n_ticks, *n_prep (ticks that start frames or riders), frame_at[n_prep*B] (frame row b starts at tick k,
+ * or -1), counts[4*n_prep] (rows starting a frame / of them visible / riders / init_net rows, per tick; may be NULL),
+ * est_us[2] (cost estimates wavefront / frame-stepped; may be NULL). RC_ERR_INVALID with *n_prep set when frame_at_cap
+ * (ints) is too small. */
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames);
 int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_frames, int64_t* ticks);
 int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* first_reach, const int32_t* pend, uint32_t flags,
                      int32_t has_first_tran, int32_t use_imu_updater, int32_t use_vision_updater, int32_t min_frames,
                      uint8_t* mode_out);
+int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const int32_t* first_reach, const int32_t* pend,
+                 int32_t use_imu_updater, int32_t use_vision_updater, int32_t* frame_at, int64_t frame_at_cap,
+                 int32_t* n_ticks, int32_t* n_prep, int32_t* counts, double* est_us);
 
 /* ---- live / streaming mode (BASELINE config 5) ------------------------------------------------------------- */
 /* The live_server.py loop (live_server.py:40-48): one frame per call, HOST tensors in and out exactly like

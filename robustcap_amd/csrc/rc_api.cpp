@@ -13,6 +13,7 @@
 #include "../../include/robustcap_hip.h"
 #include "rc_internal.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -130,6 +131,16 @@ struct rc_ctx {
     int* scan_state_h = nullptr;         // pinned: first_reach[B] then pend[B] (as ints)
     size_t scan_cap = 0;
     long long stat_wave_frames = 0, stat_stepped_frames = 0, stat_ticks = 0;
+    // per-row-cursor wavefront engine (run_wave2_segment)
+    int seq_engine = 2;                  // 0: frame-stepped only, 1: all-visible stretches only (round-2 engine), 2: per-row cursors
+    bool ring2_ready = false;
+    FrameBuffers ring2[16];              // ring[] slots + their own updater-input buffers, frame index and step numbers per row
+    std::vector<GemmProblem> wave2_prob; // [16 slots][W2_PROB]
+    bool wave2_valid = false;
+    int* frame_at_d = nullptr;           // [cap] host plan: frame every row starts at every tick
+    int* frame_at_h = nullptr;           // pinned
+    size_t frame_at_cap = 0;
+    double cost_tick_us = 235.0, cost_tick_small_us = 115.0, cost_frame_us = 300.0, cost_tr_us = 60.0;   // engine choice (plan_wave)
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
 };
@@ -444,10 +455,9 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
         Stage t6{N6, (int)RC_ROW2_TR, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         Stage t4{N4, (int)RC_ROW2_TR, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2};
         t6.rows_hint = t4.rows_hint = 8;  // regime changes: a handful of rows per frame -> narrow tiles
-        // Weight-streaming launches: always on the fp32 weights (4 B instead of the 6 B of the three bf16 planes). Which
-        // rows take this launch depends on each row's own regime history only, so a row's result stays independent of the
-        // batch it runs in.
-        if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st, true)) return rc;
+        // In the context's product arithmetic: the per-row-cursor engine runs the same two steps inside the slot's own rnn4 /
+        // rnn6 launches, and a row's result must not depend on the engine (or on the batch) it runs in.
+        if (int rc = run_stage(ctx, {t6, t4}, false, nullptr, st)) return rc;
     }
     // inertial pose branch (L144) + visual pose branch (L153); rnn4 also takes the rows whose deferred updater
     // step is still pending and that do not step on camera keypoints this frame (they read x4l)
@@ -484,7 +494,7 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
     const FrameBuffers& fb = ctx->fb;
     rc_launch_flush_flags(fb, ctx->B, st);
     return run_stage(ctx, {Stage{N6, (int)RC_ROW2_FLUSH, fb.x6l, 256, Out{nullptr, 0, 0, false}, fb.flags2},
-                           Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st, true);
+                           Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st);
 }
 
 // ====================================================================================== sequence mode (wavefront)
@@ -687,6 +697,268 @@ void plan_sequence(const signed char* codes, int B, int T, const int* first_reac
     }
 }
 
+// ============================================================== per-row-cursor wavefront engine ("wave2", round 3)
+// The all-visible engine above stops at the first occluded row: the vision updater (net/sig_mp.py:264-271) feeds the END of a
+// frame (landmarks of the tail) back into rnn6 / rnn4, so a row's next camera step has to wait for it. But rows are independent
+// (SURVEY.md 8(e)), so a row can simply LAG the batch. Here every row has its own frame cursor:
+//   * tick k initialises ring slot k % 16: row r starts its next frame there, or nothing (a bubble) when that frame has to
+//     wait. The slot carries, per row, the frame index and the step number of every sub-net step the frame takes, so the stages
+//     of a row's frames can be in flight at different step counts while the row's counters move on;
+//   * the stages are those of the frame-stepped launch plan (step_impl) skewed over the ring: stage s of the slot initialised
+//     at tick e runs at tick e + s with the slot's row flags selecting its rows (the stateless row compaction of the GEMM);
+//   * an occluded frame's two updater steps RIDE the slot that is initialised at the tick its tail runs (tail = stage 10 ->
+//     slot e + 10): the tail writes their inputs into that slot's x4l / x6l and marks the row there, and the steps merge into
+//     that slot's own rnn4 / rnn6 launches exactly like the "merged deferred rows" of the frame-stepped plan. The row's next
+//     VISIBLE frame may start at tick e + 11 at the earliest (its rnn4 / rnn6 layer steps then follow the rider's by one tick);
+//     a further occluded frame starts at e + 1 as usual: an occlusion costs a row 10 ticks of lag once, at its end;
+//   * the one-shot init_net (L178-183) writes rnn2's state in the tail: the row's next frame starts at e + 9;
+//   * a step left pending by the frames before the segment rides slot 0; the last frame of the segment leaves its updater step
+//     pending in the context's own buffers, as the frame-stepped path does.
+// The host plans all of it from the regime codes of the pre-pass (plan_wave: pure host logic, exposed as rc_plan_wave) and
+// uploads one table, frame_at[tick][row]; per tick it launches only the problems that have rows, with tile shapes picked
+// from the exact row counts (ticks that only serve lagging rows stream the weights through 16/32-row tiles).
+// Arithmetic per row is that of the frame-stepped plan, operation for operation: outputs and states are bitwise equal.
+enum { W2_INIT0 = RC_TICK_PROB, W2_INIT1, W2_INIT2, W2_PROB };
+const int kRideStage = 10;                     // the tail's stage: an updater rides the slot initialised at that tick
+
+struct WavePlan {
+    int n_ticks = 0;                           // ticks to launch
+    int n_prep = 0;                            // ticks [0, n_prep) initialise a slot (a row starts a frame or a rider joins)
+    std::vector<int> frame_at;                 // [n_prep][B]
+    std::vector<int> n_valid, n_vis, n_rider, n_reach;   // rows per slot (index = tick that initialises it)
+    double est_wave_us = 0.0, est_stepped_us = 0.0;
+    int lag_max = 0;                           // largest lag of a row's last frame behind the batch (ticks)
+};
+
+// t0: first frame of the segment (1 when frame 0 takes first_frame / first_tran and runs frame-stepped); first_reach / pend:
+// the rows' state in front of frame t0.
+void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_reach, const int* pend, bool use_imu_updater,
+               bool use_vision_updater, const double* cost, WavePlan& P) {
+    const int n_frames = T - t0;
+    std::vector<int> entry((size_t)B * (n_frames > 0 ? n_frames : 0));
+    auto grow = [&](int tick) {
+        if ((int)P.n_valid.size() <= tick) { P.n_valid.resize(tick + 1, 0); P.n_vis.resize(tick + 1, 0); P.n_rider.resize(tick + 1, 0); P.n_reach.resize(tick + 1, 0); }
+    };
+    int need = 0, n_prep = 0;
+    P.lag_max = 0;
+    std::vector<unsigned char> tr_frame((size_t)(n_frames > 0 ? n_frames : 0), 0);
+    for (int b = 0; b < B; ++b) {
+        int e_prev = -1, ready_any = 0, ready_vis = 0;
+        bool fr = first_reach[b] != 0;
+        bool pd = pend[b] != 0 && use_vision_updater;
+        if (pd) { grow(0); P.n_rider[0] += 1; ready_vis = 1; need = std::max(need, 9); n_prep = std::max(n_prep, 1); }
+        for (int f = t0; f < T; ++f) {
+            const int c = codes[(size_t)f * B + b];
+            const bool vis = c >= 1;
+            int e = std::max(e_prev + 1, ready_any);
+            if (vis) e = std::max(e, ready_vis);
+            entry[(size_t)b * n_frames + (f - t0)] = e;
+            grow(e);
+            P.n_valid[e] += 1;
+            if (vis) P.n_vis[e] += 1;
+            if (pd && vis) tr_frame[f - t0] = 1;                            // frame-stepped plan: transition launches on this frame
+            if (fr && c == 2 && use_imu_updater) { fr = false; P.n_reach[e] += 1; ready_any = e + kRideStage - 1; }   // L178-183
+            pd = c == 0 && use_vision_updater;                              // L264
+            if (pd && f != T - 1) {
+                const int ride = e + kRideStage;
+                grow(ride);
+                P.n_rider[ride] += 1;
+                ready_vis = ride + 1;
+                need = std::max(need, ride + 9);
+                n_prep = std::max(n_prep, ride + 1);
+            }
+            need = std::max(need, e + kRideStage + 1);
+            n_prep = std::max(n_prep, e + 1);
+            e_prev = e;
+        }
+        if (n_frames > 0) P.lag_max = std::max(P.lag_max, e_prev - (n_frames - 1));
+    }
+    P.n_ticks = need;
+    P.n_prep = n_prep;
+    grow(n_prep > 0 ? n_prep - 1 : 0);
+    P.frame_at.assign((size_t)n_prep * B, -1);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < n_frames; ++i) P.frame_at[(size_t)entry[(size_t)b * n_frames + i] * B + b] = t0 + i;
+    // cost model for the engine choice: a tick whose busiest stage has >= 96 rows costs a full tick, other ticks stream the
+    // weights through small tiles; a frame-stepped frame costs a frame (+ the transition launches where a row needs them)
+    P.est_wave_us = 0.0;
+    for (int k = 0; k < P.n_ticks; ++k) {
+        int rows = 0;
+        for (int st = 1; st <= 9; ++st) {
+            const int e = k - st;
+            if (e >= 0 && e < n_prep) rows = std::max(rows, P.n_valid[e] + P.n_rider[e]);
+        }
+        P.est_wave_us += rows >= 96 ? cost[0] : (rows > 0 ? cost[1] : 25.0);
+    }
+    P.est_stepped_us = 0.0;
+    for (int i = 0; i < n_frames; ++i) P.est_stepped_us += cost[2] + (tr_frame[i] ? cost[3] : 0.0);
+}
+
+int ensure_wave2_buffers(rc_ctx* ctx) {
+    if (ctx->ring2_ready) return RC_OK;
+    if (int rc = ensure_sequence_buffers(ctx)) return rc;
+    const size_t B = (size_t)ctx->B, Bp = (size_t)ctx->Bp;
+    for (int s = 0; s < kRing; ++s) {
+        FrameBuffers f = ctx->ring[s];
+        int rc = RC_OK;
+#define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
+        A(f.x4l, Bp * 256); A(f.x6l, Bp * 256); A(f.frame, B); A(f.wsteps, 6 * B);
+        if (s == 0) { A(f.flags, B); A(f.flags2, B); A(f.regime, B); A(f.kconf, B); }   // slot 0 of ring[] is the context's own set
+#undef A
+        if (rc) return rc;
+        ctx->ring2[s] = f;
+    }
+    ctx->ring2_ready = true;
+    ctx->wave2_valid = false;
+    return RC_OK;
+}
+
+// GEMM problems of every ring slot: problem q (kTick order, then the three init_net layers) working on slot sl. Rows come from
+// the slot's flag bytes as in step_impl; tile shapes and row-tile counts are filled in per tick from the plan's row counts.
+int build_wave2_problems(rc_ctx* ctx) {
+    ctx->seq_lin1_main = true;
+    ctx->seq_two_streams = tune_env("RC_SEQ_STREAMS", 2) == 2;
+    ctx->wave2_prob.assign((size_t)kRing * W2_PROB, GemmProblem{});
+    const int B = ctx->B;
+    for (int sl = 0; sl < kRing; ++sl) {
+        const FrameBuffers& fb = ctx->ring2[sl];
+        for (int q = 0; q < RC_TICK_PROB; ++q) {
+            const TickStage& ts = kTick[q];
+            const NetDev& n = ctx->net[ts.net];
+            float* x1 = (sl & 1) ? ctx->x1_alt[ts.net] : n.x1;
+            Stage st{ts.net, (int)RC_ROW2_VALID, nullptr, 256, Out{nullptr, 0, 0, false}, fb.flags2};
+            switch (ts.net) {
+                case N4: st.x = fb.x4; st.y = Out{fb.x6, 256, 171, true}; st.flag_bit = (int)RC_ROW2_M4; st.x_alt = fb.x4l;
+                         st.sel_bit = (int)RC_ROW_VIS; st.out_bit = (int)RC_ROW_VIS; break;
+                case N2: st.x = fb.x2; st.ldx = 128; st.y = Out{fb.x3, 256, 72, true}; break;
+                case N6: st.x = fb.x6; st.y = Out{fb.pc, 4, 0, false}; st.flag_bit = (int)RC_ROW2_M6; st.x_alt = fb.x6l;
+                         st.sel_bit = (int)RC_ROW_PC; st.out_bit = (int)RC_ROW_PC; break;
+                case N3: st.x = fb.x3; st.y = Out{fb.vr, 4, 0, false}; break;
+                case N7: st.x = fb.x78; st.y = Out{fb.r6d, 144, 0, false}; break;
+                default: st.x = fb.x78; st.y = Out{fb.contact, 2, 0, false}; break;
+            }
+            GemmProblem p = ts.kind == 0 ? lin1_problem(ctx, st) : (ts.kind == 3 ? lin2_problem(ctx, st) : lstm_problem(ctx, st, ts.kind - 1));
+            if (ts.kind == 0) { p.out = x1; p.sel_flags = fb.flags; }
+            if (ts.kind == 1) p.seg[0].base = x1;
+            if (ts.kind == 3) p.out_flags = fb.flags;
+            p.steps = fb.wsteps + (size_t)ts.net * B;                         // the step number travels with the slot
+            p.open_step = 0; p.step_off = 0;
+            ctx->wave2_prob[(size_t)sl * W2_PROB + q] = p;
+        }
+        ctx->wave2_prob[(size_t)sl * W2_PROB + W2_INIT0] = dense_problem(ctx, ctx->init[0], seg(fb.xi, 128, 0), Out{ctx->hid1, 512, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false);
+        ctx->wave2_prob[(size_t)sl * W2_PROB + W2_INIT1] = dense_problem(ctx, ctx->init[1], seg(ctx->hid1, 512, 0), Out{ctx->hid2, 1024, 0, true}, true, RC_ROW_REACH, fb.flags, nullptr, false);
+        ctx->wave2_prob[(size_t)sl * W2_PROB + W2_INIT2] = dense_problem(ctx, ctx->init[2], seg(ctx->hid2, 1024, 0), Out{ctx->fb.init_out, 2048, 0, false}, false, RC_ROW_REACH, fb.flags, nullptr, false);
+    }
+    ctx->wave2_valid = true;
+    return RC_OK;
+}
+
+// stage and launch group of the problems beyond kTick (init_net layers: beside linear1 / LSTM l0 / l1 of the second half)
+inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : 6 + (q - W2_INIT0); }
+inline int w2_group(int q) { return q < RC_TICK_PROB ? (kTick[q].group == 4 ? 3 : kTick[q].group) : 2; }
+
+int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0, int t_last, hipStream_t st) {
+    if (int rc = ensure_wave2_buffers(ctx)) return rc;
+    if (!ctx->wave2_valid) if (int rc = build_wave2_problems(ctx)) return rc;
+    const int B = ctx->B;
+    const rc_params_dev prm = dev_params(ctx->prm);
+    const bool two = ctx->seq_two_streams;
+    hipStream_t aux = two ? ctx->aux_stream : st;
+    // the plan's table: frame every row starts at every tick
+    const size_t need = (size_t)P.n_prep * B;
+    if (need > ctx->frame_at_cap) {
+        if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
+        if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
+        ctx->frame_at_d = nullptr; ctx->frame_at_h = nullptr; ctx->frame_at_cap = 0;
+        const size_t cap = need + need / 4 + 4096;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->frame_at_d, cap * sizeof(int)));
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->frame_at_h, cap * sizeof(int), hipHostMallocDefault));
+        ctx->frame_at_cap = cap;
+    }
+    std::memcpy(ctx->frame_at_h, P.frame_at.data(), need * sizeof(int));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_at_d, ctx->frame_at_h, need * sizeof(int), hipMemcpyHostToDevice, st));
+
+    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
+    tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
+    tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
+    tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
+    auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
+    auto group = [&](int k, int g, hipStream_t s) -> int {                  // launch the problems of group g that have rows at tick k
+        std::vector<GemmProblem> ps;
+        for (int q = 0; q < W2_PROB; ++q) {
+            const int gq = q < RC_TICK_PROB && kTick[q].group == 5 ? 5 : w2_group(q);
+            if (gq != g) continue;
+            const int e = k - w2_stage(q);
+            if (e < 0 || e >= P.n_prep) continue;
+            const int net = q < RC_TICK_PROB ? kTick[q].net : -1;
+            const int kind = q < RC_TICK_PROB ? kTick[q].kind : 4;                 // 4: init_net layer
+            const int riders = P.n_rider[e];
+            const int rows = kind == 4 ? P.n_reach[e] : ((net == N4 || net == N6) ? P.n_vis[e] + riders : P.n_valid[e]);
+            if (rows <= 0) continue;
+            GemmProblem p = ctx->wave2_prob[(size_t)(e % kRing) * W2_PROB + q];
+            if (kind == 1 || kind == 2) {
+                const NetDev& n = ctx->net[net];
+                int mr, nc;
+                if (B >= RC_SPLIT_MIN_BATCH && rows >= 128) {
+                    const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
+                    mr = t[0]; nc = t[1];
+                } else {
+                    pick_tile(n.H, rows, &mr, &nc);
+                }
+                p.mr = mr; p.nc = nc; p.n_tiles = n.H / (4 * nc);
+            } else if (kind == 0 || kind == 4) {
+                if (rows <= 16) { p.mr = 1; p.nc = 1; p.n_tiles = (p.N + 15) / 16; }
+            }
+            p.m_tiles = (rows + 16 * p.mr - 1) / (16 * p.mr);
+            if (rows == B && kind != 4) {                                      // every row: no compaction needed
+                p.flags = nullptr; p.flag_bit = 0;
+                if (riders == 0 && (net == N4 || net == N6) && P.n_vis[e] == B) {
+                    p.alt_base = nullptr; p.sel_flags = nullptr; p.sel_bit = 0; p.out_flags = nullptr; p.out_bit = 0;
+                }
+            }
+            ps.push_back(p);
+        }
+        return launch_problems(ctx, ps, nullptr, s, g == 5);               // linear2 on the fp32-input kernel, as in run_stage
+    };
+    WavePrep wp{};
+    for (int i = 0; i < 6; ++i) wp.steps[i] = ctx->net[i].steps;
+    wp.cx4l = ctx->fb.x4l; wp.cx6l = ctx->fb.x6l;
+    WaveTail wt{};
+    wt.on = 1; wt.t_last = t_last;
+    wt.steps4 = ctx->net[N4].steps; wt.steps6 = ctx->net[N6].steps;
+    wt.cx4l = ctx->fb.x4l; wt.cx6l = ctx->fb.x6l;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));                    // the second stream joins (also: the table upload)
+    if (two) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
+    for (int k = 0; k < P.n_ticks; ++k) {
+        const int e = k & 3, ep = (k + 3) & 3;
+        // ---- per-row kernels and linear2 of tick k (second stream: after the previous tick's wide launches)
+        if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
+        if (k < P.n_prep) {
+            wp.frame_at = ctx->frame_at_d + (size_t)k * B;
+            wp.first_tick = k == 0 ? 1 : 0;
+            rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);
+        }
+        if (cnt(P.n_valid, k - 5) > 0) rc_launch_fuse(ctx->ring2[(k - 5) % kRing], io0, prm, B, aux);
+        if (int rc = group(k, 5, aux)) return rc;
+        if (cnt(P.n_valid, k - kRideStage) > 0) {
+            const FrameBuffers& tgt = ctx->ring2[k % kRing];
+            wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
+            rc_launch_tail(ctx->ring2[(k - kRideStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt);
+        }
+        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
+        // ---- the GEMM stages of tick k (caller's stream: after the previous tick's second-stream work)
+        if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        for (int g = 0; g < 4; ++g)
+            if (int rc = group(k, g, st)) return rc;
+        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
+        ctx->stat_ticks += 1;
+    }
+    if (two && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(P.n_ticks - 1) & 3], 0));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->stat_wave_frames += t_last - t0 + 1;
+    return RC_OK;
+}
+
 int check_ready(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
     if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "weights not finalized (rc_finalize_weights)");
@@ -733,6 +1005,13 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     rc_default_params(live, &ctx->prm);
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0;
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
+    ctx->seq_engine = tune_env("RC_SEQ_ENGINE", 2);
+    if (ctx->seq_engine < 0 || ctx->seq_engine > 2) ctx->seq_engine = 2;
+    if (ctx->seq_engine == 2) ctx->seq_min_frames = 8;
+    ctx->cost_tick_us = tune_env("RC_COST_TICK_US", (int)ctx->cost_tick_us);
+    ctx->cost_tick_small_us = tune_env("RC_COST_TICK_SMALL_US", (int)ctx->cost_tick_small_us);
+    ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
+    ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
     // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
     // only lengthens the launch). 64-row tiles halve the weight bytes a CU pulls per product -- with the MFMA time cut 2.7x
@@ -796,6 +1075,8 @@ int rc_destroy(rc_ctx* ctx) {
     if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
     if (ctx->scan_codes_h) (void)hipHostFree(ctx->scan_codes_h);
     if (ctx->scan_state_h) (void)hipHostFree(ctx->scan_state_h);
+    if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
+    if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
@@ -859,6 +1140,7 @@ int rc_finalize_weights(rc_ctx* ctx) {
     ctx->weight_allocs.clear();
     ctx->have_weights = false;
     ctx->tick_valid = false;             // the sequence-mode launch tables hold weight pointers
+    ctx->wave2_valid = false;
     ctx->alloc_weights = true;
     const int rc = finalize_weights_impl(ctx);
     ctx->alloc_weights = false;
@@ -979,11 +1261,18 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     // the three transition launches.
     std::vector<unsigned char> mode((size_t)(T > 0 ? T : 0), (unsigned char)SEQ_STEPPED_TR);
     const int B = ctx->B;
+    WavePlan wplan;
+    int wave2_from = -1;                    // first frame of the per-row-cursor segment (it runs to the end of the call)
     if (ctx->seq_mode && !ctx->prm.live && T >= 2) {
         // rings, second stream and tick problems are set up by the first planned call (a warm-up call pays for them), not by
         // the first call that happens to contain a long all-visible stretch
-        if (int rc = ensure_sequence_buffers(ctx)) return rc;
-        if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
+        if (ctx->seq_engine == 2) {
+            if (int rc = ensure_wave2_buffers(ctx)) return rc;
+            if (!ctx->wave2_valid) if (int rc = build_wave2_problems(ctx)) return rc;
+        } else if (ctx->seq_engine == 1) {
+            if (int rc = ensure_sequence_buffers(ctx)) return rc;
+            if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
+        }
         const size_t need = (size_t)B * T;
         if (need > ctx->scan_cap) {
             if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
@@ -1008,13 +1297,35 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
         }
         HIP_TRY(ctx, hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) ctx->scan_state_h[B + b] = pend_b[b];
-        plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h, ctx->scan_state_h + B, (flags & RC_FLAG_FIRST_FRAME) != 0,
-                      first_tran != nullptr, ctx->prm.use_imu_updater != 0, ctx->prm.use_vision_updater != 0, ctx->seq_min_frames,
-                      mode.data());
+        const bool ff = (flags & RC_FLAG_FIRST_FRAME) != 0;
+        const bool imu = ctx->prm.use_imu_updater != 0, vup = ctx->prm.use_vision_updater != 0;
+        const int w0 = (ff || first_tran) ? 1 : 0;           // a frame that takes first_frame / first_tran runs frame-stepped
+        if (ctx->seq_engine == 2 && T - w0 >= std::max(1, ctx->seq_min_frames)) {
+            // per-row-cursor engine on frames [w0, T): the rows' state in front of frame w0
+            std::vector<int> fr(ctx->scan_state_h, ctx->scan_state_h + B), pd(ctx->scan_state_h + B, ctx->scan_state_h + 2 * B);
+            if (w0) {
+                for (int b = 0; b < B; ++b) {
+                    const int c = ctx->scan_codes_h[b];
+                    if (fr[b] && c == 2 && imu) fr[b] = 0;
+                    pd[b] = (c == 0 && vup) ? 1 : 0;
+                }
+            }
+            const double cost[4] = {ctx->cost_tick_us, ctx->cost_tick_small_us, ctx->cost_frame_us, ctx->cost_tr_us};
+            plan_wave(ctx->scan_codes_h, B, T, w0, fr.data(), pd.data(), imu, vup, cost, wplan);
+            if (ctx->seq_mode == 2 || wplan.est_wave_us < wplan.est_stepped_us) wave2_from = w0;
+        }
+        // frame-stepped marks (and, for the round-2 engine, its all-visible stretches)
+        plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h, ctx->scan_state_h + B, ff, first_tran != nullptr, imu, vup,
+                      ctx->seq_engine == 1 ? ctx->seq_min_frames : (1 << 30), mode.data());
     }
     bool prep_done = false;                 // the previous frame's tail kernel already ran this frame's prep
     for (int t = 0; t < T;) {
-        if (mode[t] == SEQ_WAVE) {
+        if (t == wave2_from) {
+            FrameIO io0 = io_at(0);
+            io0.first_tran = nullptr;
+            if (int rc = run_wave2_segment(ctx, wplan, io0, t, T - 1, st)) return rc;
+            t = T;
+        } else if (mode[t] == SEQ_WAVE) {
             int e = t;
             while (e < T && mode[e] == SEQ_WAVE) ++e;
             if (int rc = run_wave_segment(ctx, t, e, io_at, st)) return rc;
@@ -1022,7 +1333,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
         } else {
             // consecutive frame-stepped frames: tail(t) and prep(t + 1) are back to back on the stream and per row, so
             // one wave does both (one launch boundary and the prep kernel's start-up latency less per frame)
-            const bool chain = t + 1 < T && mode[t + 1] != SEQ_WAVE;
+            const bool chain = t + 1 < T && mode[t + 1] != SEQ_WAVE && t + 1 != wave2_from;
             const FrameIO next = chain ? io_at(t + 1) : FrameIO{};
             if (int rc = step_impl(ctx, io_at(t), t == 0 ? flags : 0u, st, mode[t] == SEQ_STEPPED_TR, prep_done, chain ? &next : nullptr)) return rc;
             prep_done = chain;
@@ -1042,7 +1353,7 @@ int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode) {
 int rc_get_gemm_mode(const rc_ctx* ctx) { return ctx ? (ctx->gemm_split ? 1 : 0) : RC_ERR_INVALID; }
 
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames) {
-    if (!ctx || mode < 0 || mode > 1 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1, min_frames >= 1") : RC_ERR_INVALID;
+    if (!ctx || mode < 0 || mode > 2 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1|2, min_frames >= 1") : RC_ERR_INVALID;
     ctx->seq_mode = mode;
     ctx->seq_min_frames = min_frames;
     return RC_OK;
@@ -1061,6 +1372,26 @@ int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* f
     if (!codes || !first_reach || !pend || !mode_out || B < 1 || T < 0 || min_frames < 1) return RC_ERR_INVALID;
     plan_sequence(reinterpret_cast<const signed char*>(codes), B, T, first_reach, pend, (flags & RC_FLAG_FIRST_FRAME) != 0,
                   has_first_tran != 0, use_imu_updater != 0, use_vision_updater != 0, min_frames, mode_out);
+    return RC_OK;
+}
+
+int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const int32_t* first_reach, const int32_t* pend,
+                 int32_t use_imu_updater, int32_t use_vision_updater, int32_t* frame_at, int64_t frame_at_cap, int32_t* n_ticks,
+                 int32_t* n_prep, int32_t* counts, double* est_us) {
+    if (!codes || !first_reach || !pend || !n_ticks || !n_prep || B < 1 || T < 1 || t0 < 0 || t0 >= T) return RC_ERR_INVALID;
+    WavePlan P;
+    const double cost[4] = {235.0, 115.0, 300.0, 60.0};
+    plan_wave(reinterpret_cast<const signed char*>(codes), B, T, t0, first_reach, pend, use_imu_updater != 0, use_vision_updater != 0, cost, P);
+    *n_ticks = P.n_ticks;
+    *n_prep = P.n_prep;
+    if (est_us) { est_us[0] = P.est_wave_us; est_us[1] = P.est_stepped_us; }
+    if (!frame_at || (int64_t)P.frame_at.size() > frame_at_cap) return RC_ERR_INVALID;
+    std::memcpy(frame_at, P.frame_at.data(), P.frame_at.size() * sizeof(int));
+    if (counts)
+        for (int k = 0; k < P.n_prep; ++k) {
+            counts[k] = P.n_valid[k]; counts[P.n_prep + k] = P.n_vis[k];
+            counts[2 * P.n_prep + k] = P.n_rider[k]; counts[3 * P.n_prep + k] = P.n_reach[k];
+        }
     return RC_OK;
 }
 

@@ -25,8 +25,10 @@
 // One wave, one body. pend_in / uv_count: the row's pending-updater mark and landmark refresh counter as they stand BEFORE this
 // frame (read from the state by rc_prep_kernel, handed over in registers when the previous frame's tail runs this in the same
 // wave -- rc_tail_kernel with a next frame).
-__device__ __forceinline__ void prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
-                                          const int lane, const int first_frame, const int pend_in, const int uv_count) {
+// Returns the RC_ROW_* byte of the row (the same value on every lane); flags2_extra is OR-ed into the second flag byte.
+__device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
+                                              const int lane, const int first_frame, const int pend_in, const int uv_count,
+                                              const unsigned flags2_extra = 0u) {
     const float* kp = io.j2d + row * io.s_j2d;
     const float* acc = io.acc + row * io.s_acc;
     const float* ori = io.ori + row * io.s_ori;
@@ -41,16 +43,16 @@ __device__ __forceinline__ void prep_body(const FrameBuffers& fb, const FrameIO&
     float Rcr[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];                     // L139
+    unsigned f = 0;
+    const bool vis = gt_lo || first_frame;
+    if (vis) f |= RC_ROW_VIS;                                             // L149
+    if (gt_lo) f |= RC_ROW_PC;                                            // L161 / L165
+    if (!gt_lo && refresh && prm.use_vision_updater) f |= RC_ROW_UPD;     // L264
     if (lane == 0) {
-        unsigned f = 0;
-        const bool vis = gt_lo || first_frame;
-        if (vis) f |= RC_ROW_VIS;                                         // L149
-        if (gt_lo) f |= RC_ROW_PC;                                        // L161 / L165
-        if (!gt_lo && refresh && prm.use_vision_updater) f |= RC_ROW_UPD; // L264
         fb.flags[row] = (unsigned char)f;
         // deferred updater steps of the previous frame (see RC_ROW2_*)
         const bool pend = pend_in != 0;
-        unsigned f2 = 0;
+        unsigned f2 = flags2_extra;
         if (pend && vis) f2 |= RC_ROW2_TR;
         if (vis || pend) f2 |= RC_ROW2_M4;
         if (gt_lo || (pend && !vis)) f2 |= RC_ROW2_M6;
@@ -87,6 +89,7 @@ __device__ __forceinline__ void prep_body(const FrameBuffers& fb, const FrameIO&
         fb.x4[rc_pk(row, k, LD_X4)] = xn; fb.x4[rc_pk(row, k + 1, LD_X4)] = yn; fb.x4[rc_pk(row, k + 2, LD_X4)] = cf;
         fb.x6[rc_pk(row, k, LD_X6)] = x; fb.x6[rc_pk(row, k + 1, LD_X6)] = y; fb.x6[rc_pk(row, k + 2, LD_X6)] = cf;
     }
+    return f;
 }
 
 __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
@@ -94,11 +97,56 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
     prep_body(fb, io, prm, row, threadIdx.x, first_frame, fb.pend[row], fb.uv_count[row]);
 }
 
+// Per-row-cursor wavefront engine (rc_api.cpp: run_wave2_segment): the prep of one TICK. Row `row` starts frame
+// w.frame_at[row] of the call in ring slot `fb`, or nothing (-1: the row waits for a feedback step of an earlier frame, or has
+// no frame left). It opens the step of every sub-net the frame will take -- the step NUMBER travels with the slot (wsteps), so
+// that the stages of several frames of a row can be in flight while the row's counters move on. On the first tick of a
+// segment a deferred updater step left pending by the frames before it (fb.pend) becomes a rider of this slot: its inputs are
+// copied from the context's own buffers and the row joins the slot's rnn4 / rnn6 launches (net/sig_mp.py:264-271).
+__global__ __launch_bounds__(64) void rc_prep_wave_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, WavePrep w) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int f = w.frame_at[row];
+    const bool rider = w.first_tick && prm.use_vision_updater && fb.pend[row] != 0;
+    unsigned fl = 0;
+    if (f >= 0) {
+        FrameIO iof = io;
+        iof.j2d += (long long)f * 99; iof.acc += (long long)f * 18; iof.ori += (long long)f * 54;
+        fl = prep_body(fb, iof, prm, row, lane, 0, 0, 0, RC_ROW2_VALID);
+    }
+    if (lane == 0) {
+        fb.frame[row] = f;
+        unsigned f2 = f >= 0 ? (RC_ROW2_VALID | ((fl & RC_ROW_VIS) ? RC_ROW2_M4 : 0u) | ((fl & RC_ROW_PC) ? RC_ROW2_M6 : 0u)) : 0u;
+        if (f < 0) fb.flags[row] = 0;
+        else {
+            const int always[4] = {0, 1, 4, 5};                            // rnn2, rnn3, rnn7, rnn8 step on every frame
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int n = always[q]; fb.wsteps[n * B + row] = ++w.steps[n][row]; }
+            if (fl & RC_ROW_VIS) fb.wsteps[2 * B + row] = ++w.steps[2][row];   // rnn4 on camera keypoints (L149-153)
+            if (fl & RC_ROW_PC) fb.wsteps[3 * B + row] = ++w.steps[3][row];    // rnn6 (L161 / L165)
+        }
+        if (rider) {
+            fb.wsteps[2 * B + row] = ++w.steps[2][row];
+            fb.wsteps[3 * B + row] = ++w.steps[3][row];
+            f2 |= RC_ROW2_M4 | RC_ROW2_M6;
+            fb.pend[row] = 0;
+        }
+        fb.flags2[row] = (unsigned char)f2;
+    }
+    if (rider) {
+        for (int k = lane; k < 256; k += 64) {
+            fb.x4l[rc_pk(row, k, LD_X4)] = w.cx4l[rc_pk(row, k, LD_X4)];
+            fb.x6l[rc_pk(row, k, LD_X6)] = w.cx6l[rc_pk(row, k, LD_X6)];
+        }
+    }
+}
+
 // =================================================================================== fuse (L154-167, L178-180)
 __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int row = idx / 24, j = idx % 24;
     if (row >= B) return;
+    int frame = 0;
+    if (fb.frame) { frame = fb.frame[row]; if (frame < 0) return; }       // ring slot of the per-row-cursor engine: bubble
     const int regime = fb.regime[row];
     if (j == 23) {                                                        // L178-180
         if (regime == 2 && prm.use_imu_updater && fb.first_reach[row]) {
@@ -108,7 +156,7 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
         }
         return;
     }
-    const float* R = io.ori + row * io.s_ori + 45;
+    const float* R = io.ori + row * io.s_ori + (long long)frame * 54 + 45;
     float vc[3], vi[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -141,12 +189,22 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
 // ============================================================================================ tail (L173-273)
 // has_next: the same wave goes on with the prep of the NEXT frame of its row (io_next) -- in a frame-stepped sequence the two
 // kernels are back to back on the stream anyway, and the row's state they share travels in registers.
+// wt.on: ring slot of the per-row-cursor engine -- the row's frame index comes from the slot (bubbles exit), and the vision
+// updater's inputs go to the slot that starts at this tick (see WaveTail).
 __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
                                                      const BodyConst* __restrict__ body_g, int B, int first_frame, FrameIO io_next,
-                                                     int has_next) {
+                                                     int has_next, WaveTail wt) {
     __shared__ WaveScratch s;
     __shared__ BodyConst s_body;
     const int row = blockIdx.x, lane = threadIdx.x;
+    int frame = 0;
+    if (wt.on) {
+        frame = fb.frame[row];
+        if (frame < 0) return;                                             // bubble: the whole wave leaves
+        io.j2d += (long long)frame * 99; io.acc += (long long)frame * 18; io.ori += (long long)frame * 54;
+        io.pose_out += (long long)frame * 216; io.tran_out += (long long)frame * 3;
+    }
+    const bool wave_ride = wt.on && frame != wt.t_last;                    // updater inputs ride the target slot
     stage_body(&s_body, body_g, lane, 64);
     const BodyConst* body = &s_body;
     const float* ori = io.ori + row * io.s_ori;
@@ -274,7 +332,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     const int uvc = fb.uv_count[row];
     const bool refresh = !live || uvc == 0;
     const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
-    const int pend_next = (flags & RC_ROW_UPD) ? 1 : 0;
+    const int pend_next = ((flags & RC_ROW_UPD) && !wave_ride) ? 1 : 0;
     __syncthreads();   // all lanes have read the per-row state; lane 0 may now overwrite it
     if (lane == 0) {                                                       // L227, L273
 #pragma unroll
@@ -291,7 +349,14 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         // L228, L234-242: the refresh counter only moves while one of its two consumers is switched on
         if (live && (prm.use_reproj_opt || prm.use_vision_updater)) fb.uv_count[row] = uvc_next;
         fb.pend[row] = pend_next;                                         // L264-271 run at the start of the next frame
+        if ((flags & RC_ROW_UPD) && wave_ride) {                          // the two updater steps join the target slot's launches
+            wt.flags2[row] |= (unsigned char)(RC_ROW2_M4 | RC_ROW2_M6);
+            wt.wsteps[2 * B + row] = ++wt.steps4[row];
+            wt.wsteps[3 * B + row] = ++wt.steps6[row];
+        }
         int* tr = fb.trace + row * 8;
+        tr[0] = regime;                                                   // (also written by prep / fuse; with several frames of
+        tr[4] = (flags & RC_ROW_REACH) ? 1 : 0;                           //  a row in flight the LAST tail must own every field)
         tr[1] = ((flags & RC_ROW_VIS) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
         tr[2] = (first_frame ? 1 : 0) + ((flags & RC_ROW_PC) ? 1 : 0) + ((flags & RC_ROW_UPD) ? 1 : 0);
         tr[3] = n_floor;
@@ -344,30 +409,32 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     if (flags & RC_ROW_UPD) {
         // the updater's sub-net steps run at the start of the NEXT frame: this frame's IMU data goes with them
         const float* acc = io.acc + row * io.s_acc;
-        if (lane < 18) { fb.x4l[rc_pk(row, lane, LD_X4)] = acc[lane]; fb.x6l[rc_pk(row, lane, LD_X6)] = acc[lane]; }
-        if (lane < 54) { fb.x4l[rc_pk(row, 18 + lane, LD_X4)] = ori[lane]; fb.x6l[rc_pk(row, 18 + lane, LD_X6)] = ori[lane]; }
+        float* const x4l = wt.on ? (wave_ride ? wt.x4l : wt.cx4l) : fb.x4l;
+        float* const x6l = wt.on ? (wave_ride ? wt.x6l : wt.cx6l) : fb.x6l;
+        if (lane < 18) { x4l[rc_pk(row, lane, LD_X4)] = acc[lane]; x6l[rc_pk(row, lane, LD_X6)] = acc[lane]; }
+        if (lane < 54) { x4l[rc_pk(row, 18 + lane, LD_X4)] = ori[lane]; x6l[rc_pk(row, 18 + lane, LD_X6)] = ori[lane]; }
         float x = 0.f, y = 0.f, z1 = 0.f;
         if (lane < 33) {
             const float z = s.J33[lane][2];
             x = s.J33[lane][0] / z; y = s.J33[lane][1] / z; z1 = z / z;    // L265
             const int k = 72 + 3 * lane;
-            fb.x6l[rc_pk(row, k, LD_X6)] = x; fb.x6l[rc_pk(row, k + 1, LD_X6)] = y; fb.x6l[rc_pk(row, k + 2, LD_X6)] = z1;
+            x6l[rc_pk(row, k, LD_X6)] = x; x6l[rc_pk(row, k + 1, LD_X6)] = y; x6l[rc_pk(row, k + 2, LD_X6)] = z1;
         }
         if (lane >= 1 && lane < 24) {                                     // L266: joint[1:] - joint[:1]
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                fb.x6l[rc_pk(row, 171 + 3 * (lane - 1) + c, LD_X6)] = (s.P[lane][c] + tran[c]) - (s.P[0][c] + tran[c]);
+                x6l[rc_pk(row, 171 + 3 * (lane - 1) + c, LD_X6)] = (s.P[lane][c] + tran[c]) - (s.P[0][c] + tran[c]);
         }
         float xn, yn;
         bbox_normalise(x, y, lane, xn, yn);                                // L268-270
         if (lane < 33) {
             const int k = 72 + 3 * lane;
-            fb.x4l[rc_pk(row, k, LD_X4)] = xn; fb.x4l[rc_pk(row, k + 1, LD_X4)] = yn; fb.x4l[rc_pk(row, k + 2, LD_X4)] = z1;
+            x4l[rc_pk(row, k, LD_X4)] = xn; x4l[rc_pk(row, k + 1, LD_X4)] = yn; x4l[rc_pk(row, k + 2, LD_X4)] = z1;
         }
     }
     // L181-183: rnn2 state <- init_net(j3dr); takes effect from the next frame
     if (flags & RC_ROW_REACH) {
-        const int cur = fb.steps2[row] & 1;
+        const int cur = (wt.on ? fb.wsteps[row] : fb.steps2[row]) & 1;      // parity of the rnn2 step this frame took
         const float* src = fb.init_out + row * 2048;
         for (int e = lane; e < 512; e += 64) {
             fb.h2[cur * fb.h2_par_stride + rc_pk(row, e, 512)] = src[e];
@@ -679,8 +746,12 @@ void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
     hipLaunchKernelGGL(rc_fuse_kernel, dim3((B * 24 + 255) / 256), dim3(256), 0, st, fb, io, prm, B);
 }
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
-                    int first_frame, hipStream_t st, const FrameIO* io_next) {
-    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0);
+                    int first_frame, hipStream_t st, const FrameIO* io_next, const WaveTail* wt) {
+    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0,
+                       wt ? *wt : WaveTail{});
+}
+void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t st) {
+    hipLaunchKernelGGL(rc_prep_wave_kernel, dim3(B), dim3(64), 0, st, slot, io0, prm, B, w);
 }
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t st) {

@@ -41,6 +41,7 @@ enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
 #define RC_ROW2_M4 2u     // rows of the merged rnn4 launch  (VIS | pending)
 #define RC_ROW2_M6 4u     // rows of the merged rnn6 launch  (PC  | pending)
 #define RC_ROW2_FLUSH 8u  // rc_get_state: run every pending step now
+#define RC_ROW2_VALID 16u // per-row-cursor wavefront engine: the row carries a frame in this ring slot (not a bubble)
 
 struct GemmSeg {
     const float* base;      // activation matrix [rows, ld] in rc_pk order
@@ -121,6 +122,29 @@ struct FrameBuffers {       // device pointers owned by the context (all [B, ld]
     float *h2, *c2;
     int* steps2;
     long long h2_par_stride, h2_layer_stride, c2_layer_stride;
+    // per-row-cursor wavefront engine (ring slots only; nullptr in the context's own frame-stepped buffers):
+    int* frame;             // [B] frame index (relative to the call) the row carries in this slot, -1 = bubble
+    int* wsteps;            // [6][B] step number of each sub-net for the step this slot's frame (or rider) takes
+};
+
+// rc_prep_wave_kernel: which frame every row starts at this tick (host plan), the global step counters it opens steps on,
+// and the context's own updater-input buffers (a deferred updater step pending from before the segment rides the first slot)
+struct WavePrep {
+    const int* frame_at;    // [B] of this tick
+    int* steps[6];          // the sub-nets' per-row step counters
+    const float *cx4l, *cx6l;
+    int first_tick;
+};
+// rc_tail_kernel in the per-row-cursor engine: the vision updater's two sub-net steps of a frame "ride" the ring slot that
+// is initialised at the tick its tail runs (target slot); the last frame of the segment leaves them pending instead.
+struct WaveTail {
+    int on;                 // 0 = frame-stepped / all-visible engine
+    int t_last;             // last frame of the segment
+    float *x4l, *x6l;       // target slot
+    unsigned char* flags2;
+    int* wsteps;
+    int *steps4, *steps6;   // global step counters of rnn4 / rnn6
+    float *cx4l, *cx6l;     // the context's own buffers (pending step of the last frame)
 };
 
 struct FrameIO {
@@ -143,7 +167,9 @@ bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_g
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
-                    int first_frame, hipStream_t s, const FrameIO* io_next = nullptr);   // io_next: also the next frame's prep
+                    int first_frame, hipStream_t s, const FrameIO* io_next = nullptr,    // io_next: also the next frame's prep
+                    const WaveTail* wt = nullptr);
+void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t s);
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
 

@@ -257,10 +257,12 @@ class Net:
     def gemm_mode(self):
         return int(self._lib.rc_get_gemm_mode(self._ctx))
 
-    def set_sequence_mode(self, enabled=True, min_frames=48):
-        """Scheduling of ``forward_sequence`` (rc_set_sequence_mode): with ``enabled`` (the default) all-visible stretches
-        of at least ``min_frames`` frames run on the wavefront engine (bitwise the same outputs, one GEMM launch per tick)."""
-        _lib.check(self._ctx, self._lib.rc_set_sequence_mode(self._ctx, int(bool(enabled)), int(min_frames)), "rc_set_sequence_mode")
+    def set_sequence_mode(self, enabled=True, min_frames=8, force=False):
+        """Scheduling of ``forward_sequence`` (rc_set_sequence_mode). ``enabled`` (the default): calls of at least
+        ``min_frames`` frames run on the per-row-cursor wavefront engine when the launch plan's cost estimate beats the
+        frame-stepped launches (``force``: whenever they are long enough). Outputs and states are bitwise the same either way."""
+        mode = 0 if not enabled else (2 if force else 1)
+        _lib.check(self._ctx, self._lib.rc_set_sequence_mode(self._ctx, mode, int(min_frames)), "rc_set_sequence_mode")
 
     def sequence_stats(self):
         """(frames run by the wavefront engine, frames run frame-stepped, ticks launched) since construction."""
