@@ -15,8 +15,13 @@ Scaling: ``weak`` (default) = 256 bodies on EVERY rank; ``strong`` = 256 bodies 
 dist.shard_range. For N > 1 the outputs are gathered to rank 0 (RCCL) inside the timed region, in four asynchronous
 chunks that overlap the remaining frames.
 
-Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline). The roofline pass and the CPU leg are
-guarded: a failure there is recorded as {"error": ...} and the line is still printed.
+Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline). The K-step call is timed ``--reps`` times
+(default 5; every repetition = reset + W warm-up frames + K timed frames between barrier + synchronize) and ``value`` /
+``ms_per_step`` are those of the MEDIAN repetition (``timing`` carries min / max). ``variants`` carries the other
+configurations of BASELINE.json on the same box: ``high`` (all-visible, same K), ``fp32_mfma``, ``mixed_long`` /
+``high_long`` (256 frames per call whatever --steps is: the wavefront engine's steady state), ``occ1024`` (config 4) and
+``live_b1`` (config 5: p50 / p99 of the hipGraph-captured batch-1 frame). The roofline pass and the side legs are guarded: a
+failure there is recorded as {"error": ...} and the line is still printed.
 """
 import argparse
 import json
@@ -36,11 +41,14 @@ from robustcap_amd import dist as rdist  # noqa: E402
 from robustcap_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA (16x16x4 / 32x32x2), dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA; the split kernel issues 6 bf16 MFMAs per fp32-equivalent product
+LONG_FRAMES = 256                      # frames per call of the *_long variants
 PRODUCTS_SPLIT = ("fp32 operands split exactly into 3 bf16 terms each; every product = 6 partial products on "
                   "v_mfma_f32_16x16x32_bf16 (all terms >= 2^-16 of the product), fp32 accumulation, fp32 gates / state")
 PRODUCTS_FP32 = "v_mfma_f32_16x16x4_f32 (fp32 operands, an fma chain per output element)"
-CPU_FRAMES_BATCHED = 16                # cpu_baseline sample: B x 16 frames batched + 96 frames batch-1 (~10-30 s)
-CPU_FRAMES_SINGLE = 96
+CPU_FRAMES_BATCHED = 8                 # cpu_baseline: 3 samples of B x 8 frames batched (median) + 48 frames batch-1 (~10-30 s)
+CPU_FRAMES_SINGLE = 48
+CPU_SAMPLES = 3
 
 
 def pmc_traffic(batch, conf):
@@ -75,9 +83,10 @@ def make_inputs(body, B, T, conf, seed, unique=32):
     return out
 
 
-def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=CPU_FRAMES_SINGLE):
-    """The oracle (a port, parity-pinned to the reference) on this host's cores: batched and batch-1.
-    ``m`` only has to hold ONE frame more than it is asked to time; shorter inputs shorten the sample."""
+def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=CPU_FRAMES_SINGLE, samples=CPU_SAMPLES):
+    """The oracle (a port, parity-pinned to the reference) on this host's cores: batched (median of ``samples``
+    back-to-back samples of ``frames_batched`` frames each) and batch-1 frame by frame like evaluate.py.
+    ``m`` only has to hold ONE frame more than a sample; shorter inputs shorten the sample."""
     from oracle import sig_mp_oracle as O
     t = torch.from_numpy
     B, T = m["j2dc"].shape[:2]
@@ -89,10 +98,15 @@ def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=C
     net.load_numpy_state_dict(sd)
     net.gravityc = t(m["gravityc"])
     net.forward_batch(t(m["j2dc"][:, 0]), t(m["accc"][:, 0]), t(m["oric"][:, 0]), None, True)
-    t0 = time.perf_counter()
-    for i in range(1, 1 + frames_batched):
-        net.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]))
-    dt_b = time.perf_counter() - t0
+    rates, secs = [], []
+    for s_ in range(max(1, samples)):
+        t0 = time.perf_counter()
+        for q in range(frames_batched):
+            i = 1 + (s_ * frames_batched + q) % (T - 1)
+            net.forward_batch(t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]))
+        dt_b = time.perf_counter() - t0
+        rates.append(B * frames_batched / dt_b)
+        secs.append(dt_b)
     one = O.OracleNet(body, batch=1)
     one.load_numpy_state_dict(sd)
     one.forward_online(t(m["j2dc"][0, 0]), t(m["accc"][0, 0]), t(m["oric"][0, 0]), None, True)
@@ -100,8 +114,10 @@ def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=C
     for i in range(1, 1 + frames_single):
         one.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
     dt_1 = time.perf_counter() - t0
-    return {"value": round(B * frames_batched / dt_b, 1), "unit": "body-frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU, oneDNN LSTM) batched B={B} x {frames_batched} frames = {dt_b:.1f}s; "
+    return {"value": round(float(np.median(rates)), 1), "unit": "body-frames/s", "cores": threads, "kind": "port",
+            "samples": len(rates), "min": round(min(rates), 1), "max": round(max(rates), 1),
+            "sample": f"oracle (torch CPU, oneDNN LSTM) batched B={B} x {frames_batched} frames, median of {len(rates)} samples "
+                      f"({', '.join('%.1fs' % x for x in secs)}); "
                       f"batch-1 frame-by-frame like evaluate.py: {frames_single / dt_1:.1f} body-frames/s "
                       f"({frames_single} frames = {dt_1:.1f}s); nproc={os.cpu_count()}"}
 
@@ -118,10 +134,10 @@ def guarded(fn, *a, **k):
 class Workload:
     """One confidence schedule: inputs resident on the device, a context of this rank's rows, timed/instrumented runs."""
 
-    def __init__(self, sd, body, conf, B, W, K, rank, world, seed_base=2, split=None):
+    def __init__(self, sd, body, conf, B, W, frames, rank, world, seed_base=2, split=None):
         from robustcap_amd.net.sig_mp import Net
-        self.conf, self.B, self.W, self.K, self.rank, self.world = conf, B, W, K, rank, world
-        self.m = make_inputs(body, B, W + K, conf, seed=seed_base + rank)
+        self.conf, self.B, self.W, self.rank, self.world = conf, B, W, rank, world
+        self.m = make_inputs(body, B, W + frames, conf, seed=seed_base + rank)
         dev = torch.device("cuda")
         self.dev = dev
         self.j2d, self.acc, self.ori = (torch.from_numpy(self.m[k]).to(dev) for k in ("j2dc", "accc", "oric"))
@@ -142,9 +158,9 @@ class Workload:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(self, gather_rows_total=None):
+    def timed(self, K, gather_rows_total=None):
         """W untimed warmup frames, then exactly K timed frames between barrier + synchronize; max over ranks."""
-        B, W, K, world, rank = self.B, self.W, self.K, self.world, self.rank
+        B, W, world, rank = self.B, self.W, self.world, self.rank
         self.net.reset_states()
         if W > 0:
             self.run(0, W, True)
@@ -180,13 +196,17 @@ class Workload:
         assert torch.isfinite(pose).all() and torch.isfinite(tran).all()
         return dt
 
-    def roofline(self, dt, bodies_total):
+    def timed_reps(self, K, reps, gather_rows_total=None):
+        """`reps` repetitions of timed(K); returns the sorted list of their times."""
+        return sorted(self.timed(K, gather_rows_total) for _ in range(max(1, reps)))
+
+    def roofline(self, K, dt, bodies_total):
         """Dominant kernel: HIP-event timing (on the launch stream, inside the library) of every wide-tile gate-GEMM
         launch over the same K steps. rc_gemm_kernel runs linear1 and both LSTM layers of all six sub-nets: 99.7 % of
         the algorithmic FLOPs. The 16-row launches (transition steps, linear2) run on rc_gemm_small_kernel, a
         weight-streaming kernel outside this roofline; `path_frac` is the whole frame (every kernel, the timed
         region's own clock) against the same peak."""
-        B, W, K, net = self.B, self.W, self.K, self.net
+        B, W, net = self.B, self.W, self.net
         net.reset_states()
         if W > 0:
             self.run(0, W, True)
@@ -203,9 +223,13 @@ class Workload:
         ach = flop_per_launch / avg_s / 1e12
         path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
         traffic, src = pmc_traffic(B, self.conf)
+        issued_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if self.split else PEAK_FP32_MFMA_TFLOPS
+        wave, stepped, ticks = net.sequence_stats()
         return {"bound": "mfma", "kernel": "rc_gemm_split_kernel" if self.split else "rc_gemm_kernel", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "peak_issued": round(issued_peak, 1), "frac_issued": round(ach / issued_peak, 4),
+                "traffic": traffic,
                 "traffic_note": (f"fabric-side L2 miss bytes per gate-GEMM launch, rocprofv3 PMC pass of this batch/schedule "
                                  f"(profiles/{src})" if src else
                                  "no PMC pass committed for this batch/schedule (profiles/*pmc_traffic*.json are keyed by batch + conf)"),
@@ -213,11 +237,52 @@ class Workload:
                 "flop_per_launch": flop_per_launch,
                 "path_achieved": round(path, 2), "path_frac": round(path / PEAK_FP32_MFMA_TFLOPS, 4),
                 "products": PRODUCTS_SPLIT if self.split else PRODUCTS_FP32,
+                "engine": {"wavefront_frames": wave, "frame_stepped_frames": stepped, "ticks": ticks},
                 "note": "frac: the wide-tile gate-GEMM kernel alone (its algorithmic fp32 FLOPs / its HIP-event time) against the "
-                        "dense fp32-input MFMA peak, the peak of the type the path computes in; path_frac: whole frame incl. the "
-                        "weight-streaming 16-row launches and the per-frame logic kernels. With split-bf16 products the kernel "
-                        "issues 6 bf16 MFMAs per 16x16x32 block (2.7x fewer MFMA cycles than the fp32-input instruction): the "
-                        "fp32 MFMA roof no longer binds it, operand delivery L2 -> CU does (DESIGN.md section 3.1)"}
+                        "dense fp32-input MFMA peak, the peak of the type the path computes in; frac_issued: the same rate against "
+                        "the roof of the instructions the kernel actually issues (split mode: dense bf16 MFMA peak / 6 partial "
+                        "products = 416.7 TFLOP/s fp32-equivalent) -- the figure to read as MFMA utilisation; path_frac: whole "
+                        "frame incl. the weight-streaming 16-row launches and the per-frame logic kernels"}
+
+
+def rate(dts, K, bodies_total, what):
+    """variant record from the sorted times of its repetitions (median = the value)."""
+    med = dts[len(dts) // 2]
+    return {"value": round(bodies_total * K / med, 1), "ms_per_step": round(med / K * 1e3, 4), "frames": K, "reps": len(dts),
+            "min": round(bodies_total * K / dts[-1], 1), "max": round(bodies_total * K / dts[0], 1), "workload": what}
+
+
+def live_b1(sd, body, frames=2000):
+    """BASELINE config 5: batch 1, one hipGraph-captured frame per host round trip through the C ABI (rc_live_step on
+    host tensors, like live_server.py:40-48 hands them over): p50 / p99 latency of `frames` frames."""
+    import ctypes as C_
+    from robustcap_amd.net.sig_mp import Net
+    m = synth.make_motion(7, 1, 600, body, conf="mixed")
+    t = torch.from_numpy
+    net = Net(body=body, batch=1)
+    net.load_state_dict(sd)
+    net.gravityc = t(m["gravityc"])
+    net.use_graph = True
+    T = m["j2dc"].shape[1]
+    ins = [(t(m["j2dc"][0, k]).contiguous(), t(m["accc"][0, k]).contiguous(), t(m["oric"][0, k]).contiguous()) for k in range(T)]
+    pose, tran = torch.empty(1, 24, 3, 3), torch.empty(1, 3)
+    net.forward_online(*ins[0], first_frame=True)                       # captures the frame
+    fn, ctx = net._lib.rc_live_step, net._ctx
+    pp, pt = C_.c_void_p(pose.data_ptr()), C_.c_void_p(tran.data_ptr())
+    ptrs = [(C_.c_void_p(a.data_ptr()), C_.c_void_p(b.data_ptr()), C_.c_void_p(c.data_ptr())) for a, b, c in ins]
+    lat = np.empty(frames + 50)
+    for i in range(frames + 50):
+        a, b, c = ptrs[1 + i % (T - 1)]
+        t0 = time.perf_counter()
+        rc = fn(ctx, a, b, c, None, 0, pp, pt)
+        lat[i] = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(f"rc_live_step failed ({rc})")
+    lat = lat[50:] * 1e6
+    return {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+            "mean_us": round(float(lat.mean()), 1), "frames": frames, "value": round(1e6 / float(lat.mean()), 1),
+            "unit": "body-frames/s", "weight_stream_floor_us": 38.6,
+            "workload": "BASELINE config 5: batch 1, hipGraph-captured frame, host tensors in / out through rc_live_step"}
 
 
 def main():
@@ -225,14 +290,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step call (value = median)")
     ap.add_argument("--batch", type=int, default=256, help="bodies per GPU (weak) or in total (strong)")
     ap.add_argument("--conf", default="mixed", choices=["mixed", "high", "occ"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the all-visible (config 2a) variant")
+    ap.add_argument("--no-variants", action="store_true", help="skip the variants (other schedules / configs)")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or args.batch < 1:
-        ap.error("--steps >= 1, --warmup >= 0, --batch >= 1")
+    if args.steps < 1 or args.warmup < 0 or args.batch < 1 or args.reps < 1:
+        ap.error("--steps >= 1, --warmup >= 0, --batch >= 1, --reps >= 1")
 
     rank, world, local = rdist.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
@@ -249,37 +315,62 @@ def main():
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     # equal row blocks use the asynchronous RowGather; uneven strong splits (batch % world != 0) the padded gather
     strong_total = bodies_total if (args.scaling == "strong" and world > 1 and args.batch % world) else None
+    # The product arithmetic follows the TOTAL workload, not this rank's shard: the same rows give the same bits on 1 or N GPUs.
+    from robustcap_amd.net.sig_mp import Net
+    split_total = Net.default_gemm_mode(bodies_total)
+    long_frames = LONG_FRAMES if (not args.no_variants and K < LONG_FRAMES) else 0
 
-    main_w = Workload(sd, body, args.conf, B, W, K, rank, world)
-    dt = main_w.timed(strong_total)
-    roof = guarded(main_w.roofline, dt, bodies_total) if rank == 0 else None
+    main_w = Workload(sd, body, args.conf, B, W, max(K, long_frames), rank, world, split=split_total)
+    dts = main_w.timed_reps(K, args.reps, strong_total)
+    dt = dts[len(dts) // 2]
+    roof = guarded(main_w.roofline, K, dt, bodies_total) if rank == 0 else None
 
     variants = None
     if not args.no_variants:
-        def variant(conf, split, what):
-            w = guarded(Workload, sd, body, conf, B, W, K, rank, world, 2, split)
-            dtv = w if isinstance(w, dict) else guarded(w.timed, strong_total)
-            return dtv if isinstance(dtv, dict) else {"value": round(bodies_total * K / dtv, 1), "ms_per_step": round(dtv / K * 1e3, 4),
-                                                      "workload": what}
-        del main_w.j2d, main_w.acc, main_w.ori
         v = {}
-        if args.conf != "high":
-            v["high"] = variant("high", None, "SURVEY.md 8(d) config 2a: every frame visible (c >= 0.8), same batch and frame count")
+
+        def variant(w, k, what, reps=3):
+            d = guarded(w.timed_reps, k, reps, strong_total)
+            return d if isinstance(d, dict) else rate(d, k, bodies_total, what)
+        if long_frames:
+            v[f"{args.conf}_long"] = variant(main_w, long_frames, f"the main schedule at {long_frames} frames per call (the wavefront "
+                                             "engine's steady state; the driver's --steps is shorter than its fill + drain)")
         if main_w.split:
-            v["fp32_mfma"] = variant(args.conf, False, "the main workload with the products on the fp32-input MFMA instead of the "
-                                                      "split-bf16 partial products (rc_set_gemm_mode 0): bitwise fma chains")
+            main_w.net.set_gemm_mode(False)
+            v["fp32_mfma"] = variant(main_w, K, "the main workload with the products on the fp32-input MFMA instead of the "
+                                                "split-bf16 partial products (rc_set_gemm_mode 0): bitwise fma chains")
+            main_w.net.set_gemm_mode(True)
+        del main_w.j2d, main_w.acc, main_w.ori
+        if args.conf != "high":
+            hw = guarded(Workload, sd, body, "high", B, W, max(K, long_frames), rank, world, 2, split_total)
+            if isinstance(hw, dict):
+                v["high"] = hw
+            else:
+                v["high"] = variant(hw, K, "SURVEY.md 8(d) config 2a: every frame visible (c >= 0.8), same batch and frame count")
+                if long_frames:
+                    v["high_long"] = variant(hw, long_frames, f"config 2a at {long_frames} frames per call")
+                del hw
+        if world == 1:
+            def occ():
+                w = Workload(sd, body, "occ", 1024, 8, 64, 0, 1)
+                return rate(w.timed_reps(64, 3), 64, 1024, "BASELINE config 4: batch 1024, occlusion-masked keypoints (runs of "
+                            "c <= 0.7: the confidence-gated branch + vision updater), 64 frames per call")
+            v["occ1024"] = guarded(occ)
+            v["live_b1"] = guarded(live_b1, sd, body)
         variants = v if rank == 0 else None
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            m_cpu = make_inputs(body, B, 1 + max(CPU_FRAMES_BATCHED, CPU_FRAMES_SINGLE), args.conf, seed=2)
+            m_cpu = make_inputs(body, B, 1 + max(CPU_SAMPLES * CPU_FRAMES_BATCHED, CPU_FRAMES_SINGLE), args.conf, seed=2)
             cpu = guarded(cpu_baseline, sd, body, m_cpu)
         value = bodies_total * K / dt
         print(json.dumps({
             "metric": "body-frames/sec (sig_mp fwd + FK) at batch 256", "value": round(value, 1), "unit": "body-frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": {"reps": len(dts), "stat": "median", "call_ms": round(dt * 1e3, 4), "min_call_ms": round(dts[0] * 1e3, 4),
+                       "max_call_ms": round(dts[-1] * 1e3, 4)},
             "products": PRODUCTS_SPLIT if main_w.split else PRODUCTS_FP32,
             "config": {"workload": f"synthetic 60 fps, 6 IMU + 33 keypoints, batch {B} x {K} frames per GPU "
                                    f"({bodies_total} bodies in total, {args.scaling} scaling), "

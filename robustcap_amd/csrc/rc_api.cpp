@@ -78,12 +78,17 @@ struct rc_ctx {
     BodyConst* body = nullptr;
     float *mesh_vt = nullptr, *mesh_w = nullptr;      // full mesh (metrics only): v_template [V,3], weights [V,24]
     int mesh_V = 0;
-    float* mesh_Jr = nullptr;                         // keypoint regressor [n_used, V] (metrics only)
+    float* mesh_kM = nullptr;                         // keypoint regressor folded with the skinning data [n_used][24][4] (metrics only)
     int mesh_nk = 0;
+    std::vector<float> mesh_vt_h, mesh_w_h, mesh_Jr_h; // host copies: the fold is recomputed when mesh, regressor or root change
+    float jroot_h[3] = {0.f, 0.f, 0.f};
+    bool fold_dirty = false;
+    float* sweep_scratch = nullptr;                   // per-frame transforms + slab partial sums of the mesh sweeps (grow-only)
+    size_t sweep_scratch_cap = 0;
     unsigned long long ign_mask = RC_IGN_DEFAULT;     // smplify: landmarks with zeroed confidence
     bool have_body = false, have_weights = false;
-    std::map<std::string, std::vector<float>> staged;    // host copy of every loaded tensor: kept, so that a partial
-                                                         // (non-strict) load_state_dict re-packs on top of the rest
+    std::map<std::string, std::vector<float>> staged;    // host copy of the tensors loaded since the last rc_finalize_weights
+                                                         // (released there: a context does not hold 254 MB of host memory)
     std::vector<void*> allocs;
     std::vector<void*> weight_allocs;    // packed weights of the current rc_finalize_weights (freed by the next one)
     bool alloc_weights = false;          // dev_alloc books into weight_allocs
@@ -867,7 +872,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // the plan's table: frame every row starts at every tick
     const size_t need = (size_t)P.n_prep * B;
     if (need > ctx->frame_at_cap) {
-        if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
+        if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
+    if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
         if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
         ctx->frame_at_d = nullptr; ctx->frame_at_h = nullptr; ctx->frame_at_cap = 0;
         const size_t cap = need + need / 4 + 4096;
@@ -959,6 +965,43 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     return RC_OK;
 }
 
+// grow-only device scratch of the mesh sweeps (rc_metrics.hip); a reallocation waits for whatever still reads the old one
+int sweep_scratch(rc_ctx* ctx, size_t floats, hipStream_t st) {
+    if (floats <= ctx->sweep_scratch_cap) return RC_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
+    ctx->sweep_scratch = nullptr; ctx->sweep_scratch_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->sweep_scratch, floats * sizeof(float)));
+    ctx->sweep_scratch_cap = floats;
+    return RC_OK;
+}
+
+// Skinning is linear in the joint transforms: a regressed keypoint sum_v Jr[k,v] sum_j w[v,j] (G_j x_v + T_j) equals
+// sum_j (G_j M[k,j] + T_j m[k,j]) with the pose-independent M[k,j] = sum_v Jr[k,v] w[v,j] x_v, m[k,j] = sum_v Jr[k,v] w[v,j]
+// (float64 here, once per mesh / regressor / root) -- evaluate.py:122-125 without touching a vertex per frame.
+int fold_regressor(rc_ctx* ctx) {
+    const int V = ctx->mesh_V, nk = ctx->mesh_nk;
+    std::vector<double> acc((size_t)nk * 24 * 4, 0.0);
+    for (int k = 0; k < nk; ++k)
+        for (int v = 0; v < V; ++v) {
+            const double jw = ctx->mesh_Jr_h[(size_t)k * V + v];
+            if (jw == 0.0) continue;
+            const double x[3] = {(double)ctx->mesh_vt_h[3 * (size_t)v] - ctx->jroot_h[0], (double)ctx->mesh_vt_h[3 * (size_t)v + 1] - ctx->jroot_h[1],
+                                 (double)ctx->mesh_vt_h[3 * (size_t)v + 2] - ctx->jroot_h[2]};
+            for (int j = 0; j < 24; ++j) {
+                const double ww = jw * ctx->mesh_w_h[(size_t)v * 24 + j];
+                double* a = &acc[((size_t)k * 24 + j) * 4];
+                a[0] += ww * x[0]; a[1] += ww * x[1]; a[2] += ww * x[2]; a[3] += ww;
+            }
+        }
+    std::vector<float> kM(acc.begin(), acc.end());
+    if (!ctx->mesh_kM) if (int rc = dev_alloc(ctx, &ctx->mesh_kM, (size_t)17 * 24 * 4, false)) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());                    // nothing in flight may still read the old fold
+    HIP_TRY(ctx, hipMemcpy(ctx->mesh_kM, kM.data(), kM.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->fold_dirty = false;
+    return RC_OK;
+}
+
 int check_ready(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
     if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "weights not finalized (rc_finalize_weights)");
@@ -1008,6 +1051,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->seq_engine = tune_env("RC_SEQ_ENGINE", 2);
     if (ctx->seq_engine < 0 || ctx->seq_engine > 2) ctx->seq_engine = 2;
     if (ctx->seq_engine == 2) ctx->seq_min_frames = 8;
+    ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
+    if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_US", (int)ctx->cost_tick_us);
     ctx->cost_tick_small_us = tune_env("RC_COST_TICK_SMALL_US", (int)ctx->cost_tick_small_us);
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
@@ -1187,6 +1232,9 @@ static int finalize_weights_impl(rc_ctx* ctx) {
     }
     ctx->have_weights = true;
     HIP_TRY(ctx, hipDeviceSynchronize());
+    // the ~254 MB host copy is not kept: a later partial reload has to pass every tensor again (the Python host keeps
+    // references to the caller's own arrays for that, robustcap_amd/net/sig_mp.py: load_state_dict)
+    std::map<std::string, std::vector<float>>().swap(ctx->staged);
     return RC_OK;
 }
 
@@ -1215,6 +1263,8 @@ int rc_set_body(rc_ctx* ctx, const int32_t* parent, const float* J, const float*
     for (auto& o : ov) b.override_joint[o[0]] = o[1];
     HIP_TRY(ctx, hipMemcpy(ctx->body, &b, sizeof(b), hipMemcpyHostToDevice));
     ctx->have_body = true;
+    for (int c = 0; c < 3; ++c) ctx->jroot_h[c] = b.jroot[c];
+    ctx->fold_dirty = true;
     return RC_OK;
 }
 
@@ -1263,7 +1313,9 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     const int B = ctx->B;
     WavePlan wplan;
     int wave2_from = -1;                    // first frame of the per-row-cursor segment (it runs to the end of the call)
-    if (ctx->seq_mode && !ctx->prm.live && T >= 2) {
+    // (calls shorter than min_frames are not planned at all: no pre-pass, no synchronisation, fully asynchronous)
+    if (ctx->seq_mode && !ctx->prm.live && T >= 2 &&
+        (ctx->seq_engine != 2 || T - ((flags & RC_FLAG_FIRST_FRAME) || first_tran ? 1 : 0) >= std::max(1, ctx->seq_min_frames))) {
         // rings, second stream and tick problems are set up by the first planned call (a warm-up call pays for them), not by
         // the first call that happens to contain a long all-visible stretch
         if (ctx->seq_engine == 2) {
@@ -1649,14 +1701,24 @@ int rc_set_mesh(rc_ctx* ctx, const float* vt, const float* w, int32_t V) {
     HIP_TRY(ctx, hipDeviceSynchronize());                    // nothing in flight may still read the old mesh
     HIP_TRY(ctx, hipMemcpy(ctx->mesh_vt, vt, (size_t)V * 3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->mesh_w, w, (size_t)V * 24 * sizeof(float), hipMemcpyHostToDevice));
+    if (ctx->mesh_V != V) { ctx->mesh_Jr_h.clear(); ctx->mesh_nk = 0; }      // a regressor of another vertex count is void
     ctx->mesh_V = V;
+    ctx->mesh_vt_h.assign(vt, vt + (size_t)V * 3);
+    ctx->mesh_w_h.assign(w, w + (size_t)V * 24);
+    ctx->fold_dirty = true;
     return RC_OK;
 }
 int rc_body_mesh(rc_ctx* ctx, const float* pose, const float* tran, float* vert, int64_t n, void* stream) {
     if (!ctx || !ctx->have_body || ctx->mesh_V == 0) return ctx ? fail(ctx, RC_ERR_STATE, "rc_body_mesh: rc_set_body / rc_set_mesh first") : RC_ERR_INVALID;
     if (n == 0) return RC_OK;
     if (!pose || !tran || !vert || n < 0) return fail(ctx, RC_ERR_INVALID, "rc_body_mesh: bad argument");
-    rc_launch_body_mesh(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, pose, tran, vert, n, (hipStream_t)stream);
+    const int64_t chunk = 65536;
+    if (int rc = sweep_scratch(ctx, (size_t)rc_body_mesh_scratch_floats(std::min(n, chunk)), (hipStream_t)stream)) return rc;
+    for (int64_t a = 0; a < n; a += chunk) {
+        const int64_t m = std::min(chunk, n - a);
+        rc_launch_body_mesh(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, pose + a * 216, tran + a * 3, vert + a * ctx->mesh_V * 3, m,
+                            ctx->sweep_scratch, (hipStream_t)stream);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
 }
@@ -1664,17 +1726,24 @@ int rc_set_regressor(rc_ctx* ctx, const float* Jr, int32_t n_rows, int32_t n_use
     if (!ctx) return RC_ERR_INVALID;
     if (ctx->mesh_V == 0) return fail(ctx, RC_ERR_STATE, "rc_set_regressor: rc_set_mesh first");
     if (!Jr || n_used < 1 || n_used > n_rows || n_used > 17) return fail(ctx, RC_ERR_INVALID, "rc_set_regressor: 1 <= n_used <= min(n_rows, 17)");
-    if (int rc = dev_alloc(ctx, &ctx->mesh_Jr, (size_t)n_used * ctx->mesh_V, false)) return rc;
-    HIP_TRY(ctx, hipMemcpy(ctx->mesh_Jr, Jr, (size_t)n_used * ctx->mesh_V * sizeof(float), hipMemcpyHostToDevice));
+    ctx->mesh_Jr_h.assign(Jr, Jr + (size_t)n_used * ctx->mesh_V);
     ctx->mesh_nk = n_used;
+    ctx->fold_dirty = true;
     return RC_OK;
 }
 int rc_mesh_metrics(rc_ctx* ctx, const float* pose, const float* gt_pose, int64_t n, float* per_frame, double* mean_host, void* stream) {
     if (!ctx || !ctx->have_body || ctx->mesh_V == 0) return ctx ? fail(ctx, RC_ERR_STATE, "rc_mesh_metrics: rc_set_body / rc_set_mesh first") : RC_ERR_INVALID;
     if (n <= 0 || !pose || !gt_pose || !per_frame) return fail(ctx, RC_ERR_INVALID, "rc_mesh_metrics: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    rc_launch_mesh_metrics(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, ctx->mesh_Jr, ctx->mesh_Jr ? ctx->mesh_nk : 24, pose, gt_pose,
-                           per_frame, n, st);
+    const bool have_reg = ctx->mesh_nk > 0 && !ctx->mesh_Jr_h.empty();
+    if (have_reg && ctx->fold_dirty) if (int rc = fold_regressor(ctx)) return rc;
+    const int64_t chunk = 65536;
+    if (int rc = sweep_scratch(ctx, (size_t)rc_mesh_metrics_scratch_floats(ctx->mesh_V, std::min(n, chunk)), st)) return rc;
+    for (int64_t a = 0; a < n; a += chunk) {
+        const int64_t m = std::min(chunk, n - a);
+        rc_launch_mesh_metrics(ctx->body, ctx->mesh_vt, ctx->mesh_w, ctx->mesh_V, have_reg ? ctx->mesh_kM : nullptr, have_reg ? ctx->mesh_nk : 24,
+                               pose + a * 216, gt_pose + a * 216, per_frame + a * 3, m, ctx->sweep_scratch, st);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (mean_host) {                                       // evaluate.py:131-133: the three means over the sequence
         std::vector<float> h((size_t)n * 3);

@@ -51,7 +51,12 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #endif
 #if RC_FAST_GATES
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x)); }
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|) in (0, 1]: no cancellation near 0 (1 - 2 / (1 + e^2x) loses every
+// significant bit of a small x there)
+__device__ __forceinline__ float tanhf_(float x) {
+    const float t = __builtin_amdgcn_exp2f(-2.88539008177793f * __builtin_fabsf(x));
+    return __builtin_copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
 #else
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }

@@ -200,12 +200,15 @@ void rc_launch_fk_bone(const BodyConst* body, const float* Rg, float* joints, lo
 void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tran, float* grot, float* joint,
                        float* j33, long long n, hipStream_t s);
 void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w, int V, const float* pose, const float* tran,
-                         float* vert, long long n, hipStream_t s);
+                         float* vert, long long n, float* scratch, hipStream_t s);   // scratch: rc_body_mesh_scratch_floats(n)
+long long rc_body_mesh_scratch_floats(long long n);
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K,
                         float sigma, unsigned long long ign_mask, float* loss, long long T, hipStream_t s);
 #define RC_IGN_DEFAULT 0x1800003FEull     // MediaPipe landmarks {1..9, 31, 32} (temporal_smplify.py:92); use_head: {31, 32}
-void rc_launch_mesh_metrics(const BodyConst* body, const float* vt, const float* w, int V, const float* Jr, int nk, const float* pose_p,
-                            const float* pose_t, float* out, long long n, hipStream_t s);
+// kM: regressor folded with the skinning data, [nk][24][4] (rc_api.cpp: fold_regressor), or nullptr (the SMPL joints stand in)
+void rc_launch_mesh_metrics(const BodyConst* body, const float* vt, const float* w, int V, const float* kM, int nk, const float* pose_p,
+                            const float* pose_t, float* out, long long n, float* scratch, hipStream_t s);
+long long rc_mesh_metrics_scratch_floats(int V, long long n);
 void rc_launch_imu_frames(const BodyConst* body, const float* vt, const float* w, const int* vid, const int* jid, const float* pose,
                           const float* tran, float* ori, float* joint, float* vert6, long long T, hipStream_t s);
 void rc_launch_syn_acc(const float* v, float* acc, long long T, long long width, int n, hipStream_t s);

@@ -115,7 +115,8 @@ def first_translations(dataset, rows):
 
 
 def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=True, rows=None, device="cuda",
-                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080), smplify_workers=4, nets=None):
+                run_smplify=False, gmm=None, smplify_info=None, image_size=(1920, 1080), smplify_workers=4, nets=None,
+                gemm_mode=None):
     """Run every (sequence, camera) row of ``dataset`` (or the given subset) through the net; rows are sharded over
     the ranks of the initialised process group and gathered. Returns {(i, j): (pose [T,24,3,3], tran [T,3])} on the CPU.
 
@@ -127,7 +128,10 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     own optimiser context and HIP stream, so the line searches of several rows overlap on the device. ``gmm`` is the pose
     prior (dict means/covars/weights); ``smplify_info`` (a dict) receives the per-row optimiser records. ``nets``: an optional
     dict the caller keeps between calls -- the ``Net`` of a given row count is then built (weights re-packed and uploaded,
-    ~0.4 s) once and only reset for the next dataset."""
+    ~0.4 s) once and only reset for the next dataset (an entry is reused only for the very same ``state_dict`` object).
+    ``gemm_mode``: product arithmetic of the GEMMs (False fp32 MFMA, True split-bf16 products); None picks the library's
+    default for the TOTAL number of rows of the run, not for this rank's shard, so a row's result does not depend on
+    the number of ranks (``Net.default_gemm_mode``)."""
     all_rows = rows_of(dataset) if rows is None else list(rows)
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -140,14 +144,16 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     if n:
         j2d, acc, ori, grav = camera_inputs_rows(dataset, mine, Tmax, image_size=image_size, device=device)
         ft = first_translations(dataset, mine)
-        net = None if nets is None else nets.get((n, id(state_dict)))
+        hit = None if nets is None else nets.get(n)
+        net = hit[0] if hit is not None and hit[1] is state_dict else None      # identity, not id(): ids are reused after gc
         if net is None:
             net = Net(body=body, batch=n, device=device)
             net.load_state_dict(state_dict)
             if nets is not None:
-                nets[(n, id(state_dict))] = net
+                nets[n] = (net, state_dict)
         else:
             net.reset_states()
+        net.set_gemm_mode(Net.default_gemm_mode(len(all_rows)) if gemm_mode is None else gemm_mode)
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)

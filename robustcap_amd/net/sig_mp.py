@@ -108,16 +108,16 @@ class Net:
         seen = self.__dict__.get("_gravity_seen")                           # same tensor object, not modified in place since
         if seen is not None and seen[0] is g and isinstance(g, torch.Tensor) and seen[1] == g._version:
             return
-        self.__dict__["_gravity_seen"] = (g, g._version) if isinstance(g, torch.Tensor) else None
+        mark = (g, g._version) if isinstance(g, torch.Tensor) else None
         g = torch.as_tensor(g, dtype=torch.float32).detach().cpu().reshape(-1, 3)
         key = g.numpy().tobytes()
-        if key == self._gravity_key:
-            return
-        g = g.expand(self.batch, 3).contiguous() if g.shape[0] == 1 else g.contiguous()
-        if g.shape[0] != self.batch:
-            raise ValueError(f"gravityc must be [3] or [{self.batch}, 3]")
-        _lib.check(self._ctx, self._lib.rc_set_gravity(self._ctx, _lib.ptr(g)), "rc_set_gravity")
-        self.__dict__["_gravity_key"] = key
+        if key != self._gravity_key:
+            g = g.expand(self.batch, 3).contiguous() if g.shape[0] == 1 else g.contiguous()
+            if g.shape[0] != self.batch:
+                raise ValueError(f"gravityc must be [3] or [{self.batch}, 3]")     # nothing recorded: the next call raises again
+            _lib.check(self._ctx, self._lib.rc_set_gravity(self._ctx, _lib.ptr(g)), "rc_set_gravity")
+            self.__dict__["_gravity_key"] = key
+        self.__dict__["_gravity_seen"] = mark                               # only a value that reached the device is remembered
 
     # ------------------------------------------------------------------------------------- torch.nn.Module-like
     def to(self, device=None, *a, **k):
@@ -136,6 +136,7 @@ class Net:
         unexpected = [k for k in state_dict if k not in want]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for Net: missing {missing[:4]} unexpected {unexpected[:4]}")
+        new = {}
         for k, shape in want.items():
             if k not in state_dict:
                 continue
@@ -143,7 +144,11 @@ class Net:
             v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             if tuple(v.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
-            v = np.ascontiguousarray(v, dtype=np.float32)
+            new[k] = np.ascontiguousarray(v, dtype=np.float32)      # float32 CPU tensors / arrays: a view of the caller's memory
+        # The library packs from the tensors passed since its last finalize and keeps no host copy: a partial (non-strict)
+        # load goes on top of the tensors of the previous loads, which are kept here BY REFERENCE (no second copy).
+        self._sd_cpu.update(new)
+        for k, v in self._sd_cpu.items():
             _lib.check(self._ctx, self._lib.rc_load_weight(self._ctx, k.encode(), v.ctypes.data_as(C.c_void_p), v.size), "rc_load_weight")
         _lib.check(self._ctx, self._lib.rc_finalize_weights(self._ctx), "rc_finalize_weights")
         self.__dict__["_live_on"] = False          # the library dropped its captured frame (it held the old weight pointers)
@@ -245,6 +250,13 @@ class Net:
         _lib.check(self._ctx, rc, "rc_sequence")
         self.__dict__["_keep"] = (j2dc, accc, oric, ft)
         return pose, tran
+
+    @staticmethod
+    def default_gemm_mode(total_rows):
+        """The library's default product arithmetic for a workload of ``total_rows`` bodies (split-bf16 products from 192).
+        Sharded runs pass their TOTAL row count here and pin every shard's context with ``set_gemm_mode``, so that a row's
+        bits do not depend on the number of ranks it was split over."""
+        return int(total_rows) >= 192
 
     def set_gemm_mode(self, split):
         """Product arithmetic of every GEMM of this context (rc_set_gemm_mode): False = fp32 MFMA (fma chains), True =

@@ -18,6 +18,7 @@ def test_cpu_baseline_on_short_inputs(synth_assets):
     out = bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], m)
     assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert "x 4 frames" in out["sample"] and "(4 frames" in out["sample"]          # clamped to T - 1
+    assert out["samples"] == 3 and out["min"] <= out["value"] <= out["max"]        # median of three samples
     with pytest.raises(ValueError):
         bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], {k: v[:, :1] if v.ndim > 2 else v for k, v in m.items()})
 
@@ -63,7 +64,15 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     roof = d["roofline"]
     assert "error" not in roof and 0 < roof["frac"] < 1 and roof["bound"] == "mfma"
     assert roof["traffic"] is None or roof["traffic"] > 0
-    assert d["variants"]["high"]["value"] > 0
+    assert roof["frac_issued"] <= roof["frac"] and roof["peak_issued"] > roof["peak"]      # split products: the bf16 roof / 6
+    tm = d["timing"]
+    assert tm["reps"] >= 5 and tm["min_call_ms"] <= tm["call_ms"] <= tm["max_call_ms"]
+    assert abs(tm["call_ms"] - d["ms_per_step"] * d["steps"]) < 0.01 * tm["call_ms"]        # value = the median repetition
+    var = d["variants"]
+    for k in ("high", "fp32_mfma", "mixed_long", "high_long", "occ1024"):
+        assert "error" not in var[k] and var[k]["value"] > 0, (k, var[k])
+    assert var["mixed_long"]["frames"] >= 128 and var["high_long"]["frames"] >= 128
+    assert "error" not in var["live_b1"] and 0 < var["live_b1"]["p50_us"] <= var["live_b1"]["p99_us"]
     if not extra:
         cpu = d["cpu_baseline"]
         assert "error" not in cpu and cpu["value"] > 0 and cpu["kind"] == "port"

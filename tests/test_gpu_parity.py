@@ -198,6 +198,25 @@ def test_lstm_step_vs_torch(name, split, synth_assets):
     assert maxdiff(h, ora.h[name]) <= 2e-5 and maxdiff(c, ora.c[name]) <= 2e-5
 
 
+def test_partial_state_dict_reload_goes_on_top_of_the_previous_load(synth_assets):
+    """load_state_dict(strict=False) with a subset of the keys (torch semantics): the library keeps no host copy of the
+    weights, the Python host re-sends the tensors of the earlier loads by reference."""
+    sd = dict(synth_assets["state_dict"])
+    net = make_net(synth_assets, 3)
+    x = t(np.linspace(-1, 1, 3 * 141, dtype=np.float32).reshape(3, 141))
+    y0 = net.lstm_step("rnn7", x).cpu()
+    w = np.array(sd["rnn7.linear2.weight"], copy=True) * 0.5
+    res = net.load_state_dict({"rnn7.linear2.weight": w}, strict=False)
+    assert len(res.missing_keys) == len(sd) - 1 and not res.unexpected_keys
+    net.reset_states()
+    y1 = net.lstm_step("rnn7", x).cpu()
+    full = make_net({"state_dict": {**sd, "rnn7.linear2.weight": w}, "body": synth_assets["body"]}, 3)
+    y2 = full.lstm_step("rnn7", x).cpu()
+    assert torch.equal(y1, y2) and not torch.equal(y0, y1)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({"rnn7.linear2.weight": w})                       # strict: every key is required
+
+
 # ------------------------------------------------------------------------------------------- full sequences
 SEQS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "seq_*.npz")))
 

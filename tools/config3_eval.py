@@ -45,7 +45,7 @@ def main():
             out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
     if rank == 0 and world == 1:     # where the net-only time goes: the harness's three steps timed one by one
         mine = ev.rows_of(ds)
-        net = nets[(rows, id(sd))]
+        net = nets[rows][0]
         bd = {}
         torch.cuda.synchronize(); t0 = time.perf_counter()
         j2d, acc, ori, grav = ev.camera_inputs_rows(ds, mine, T)
