@@ -122,11 +122,11 @@ int rc_get_gemm_mode(const rc_ctx* ctx);
  * each (frame, row) on the device (the arithmetic of the per-frame prep kernel), reads the codes back -- ONE
  * synchronisation of `stream` per call -- and plans the launches on the host:
  *   - the PER-ROW-CURSOR WAVEFRONT engine runs every frame but one that takes first_frame / first_tran: the stages of a
- *     frame (prep | linear1 | LSTM l0 | l1 | linear2 of {rnn2, rnn4} | fuse | the same four of {rnn6, rnn3, rnn7, rnn8} |
+ *     frame (prep | linear1 | LSTM l0 | l1 | linear2 of {rnn2, rnn4} + fuse | the same four of {rnn6, rnn3, rnn7, rnn8} +
  *     tail) are skewed over consecutive ticks and a 16-slot ring, four gate-GEMM launches per tick carry the stages of up
- *     to ten frames, the per-row kernels run beside them on a context-owned second stream. Rows are independent, so each
+ *     to eight frames, the per-row kernels run beside them on a context-owned second stream. Rows are independent, so each
  *     row has its own frame cursor: the vision updater's feedback (net/sig_mp.py:264-271) and the one-shot init_net
- *     (L178-183) make only THAT row wait (10 / 8 ticks, once per occlusion / once per sequence) while the batch keeps
+ *     (L178-183) make only THAT row wait (8 / 6 ticks, once per occlusion / once per sequence) while the batch keeps
  *     ticking; the updater's rnn6 / rnn4 steps ride the launches of the ring slot that starts when the frame's tail runs.
  *     This is the full-sequence form of the recurrence (the reference's own is RNN.forward over packed sequences,
  *     articulate/utils/torch/rnn.py:129-133); every row's outputs and states are bitwise those of the frame-stepped launches;
@@ -135,17 +135,16 @@ int rc_get_gemm_mode(const rc_ctx* ctx);
  *   - frame-stepped frames run without the three transition launches when the plan proves that no row needs one.
  * mode = 0: frame-stepped launches only, no pre-pass, no synchronisation. Live contexts (rc_params.live) always behave
  * like mode 0. rc_get_sequence_stats: frames run by each engine and ticks launched since rc_create (any may be NULL).
- * rc_plan_sequence (frame-stepped marks; all-visible stretches of the round-2 engine, RC_SEQ_ENGINE=1) and rc_plan_wave are
- * the planners alone on HOST data (tests): codes[T*B] (0: c <= lo, 1: mid, 2: c >= hi; frame-major), first_reach[B],
- * pend[B] (state in front of frame t0) -> mode_out[T] (0 frame-stepped with transition launches, 1 without, 2 wavefront);
+ * rc_plan_sequence (transition-launch marks of frame-stepped frames) and rc_plan_wave are the planners alone on HOST data
+ * (tests): codes[T*B] (0: c <= lo, 1: mid, 2: c >= hi; frame-major), first_reach[B], pend[B] (state in front of frame 0 /
+ * t0) -> mode_out[T] (0 frame-stepped with the three transition launches, 1 without);
  * rc_plan_wave -> *n_ticks, *n_prep (ticks that start frames or riders), frame_at[n_prep*B] (frame row b starts at tick k,
  * or -1), counts[4*n_prep] (rows starting a frame / of them visible / riders / init_net rows, per tick; may be NULL),
  * est_us[2] (cost estimates wavefront / frame-stepped; may be NULL). RC_ERR_INVALID with *n_prep set when frame_at_cap
  * (ints) is too small. */
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames);
 int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_frames, int64_t* ticks);
-int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* first_reach, const int32_t* pend, uint32_t flags,
-                     int32_t has_first_tran, int32_t use_imu_updater, int32_t use_vision_updater, int32_t min_frames,
+int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* pend, uint32_t flags, int32_t use_vision_updater,
                      uint8_t* mode_out);
 int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const int32_t* first_reach, const int32_t* pend,
                  int32_t use_imu_updater, int32_t use_vision_updater, int32_t* frame_at, int64_t frame_at_cap,

@@ -44,7 +44,8 @@ def body_arrays(body):
 def shaped_body(ctx, body, shape):
     """The body dict with the shape blendshapes applied: v = shapedirs . beta + v_template, J = J_regressor . v
     (articulate/model.py:88-91; the root alignment happens in rc_set_body like for the mean shape). ``shape``: 10 betas, or
-    [n,10] with identical rows (one shape per context). Computed on the device (rc_shape_body)."""
+    [n,10] with identical rows (a context holds ONE shape; ``ParametricModel.forward_kinematics`` groups frames of different
+    shapes and calls this once per distinct row). Computed on the device (rc_shape_body)."""
     beta = torch.as_tensor(shape, dtype=torch.float32).detach().cpu().reshape(-1, 10)
     if not bool((beta == beta[:1]).all()):
         raise NotImplementedError("one shape per model / sequence: the rows of `shape` must be identical")
@@ -137,7 +138,15 @@ class ParametricModel:
         return out
 
     def get_zero_pose_joint_and_vertex(self, shape=None):
-        """articulate/model.py:78-93 for the mean shape: (joints [24,3], vertices [V,3]), root joint at the origin."""
+        """articulate/model.py:78-93: (joints [24,3], vertices [V,3]) of the mean shape, root joint at the origin; with
+        ``shape`` [batch,10] the reference's batched form ([batch,24,3], [batch,V,3]), one rc_shape_body per distinct row."""
+        if shape is not None:
+            beta = torch.as_tensor(shape, dtype=torch.float32).detach().cpu().reshape(-1, 10)
+            if beta.shape[0] > 1 and not bool((beta == beta[:1]).all()):
+                uniq, inv = torch.unique(beta, dim=0, return_inverse=True)
+                parts = [self.get_zero_pose_joint_and_vertex(uniq[g]) for g in range(uniq.shape[0])]
+                return (torch.stack([parts[int(g)][0] for g in inv]), torch.stack([parts[int(g)][1] for g in inv]))
+            shape = beta[0]
         self.set_shape(shape)
         self._ensure_mesh()
         j = torch.empty(24, 3, device=self.device)
@@ -154,10 +163,30 @@ class ParametricModel:
 
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
         """(global rotations, joints[, landmarks]). With ``calc_mesh`` the third output is the 33-landmark set
-        ``sync_mp3d(vert, joint)`` -- the only part of the 6890-vertex mesh the path consumes."""
-        self.set_shape(shape)                                           # one shape for all frames (model.py:228)
+        ``sync_mp3d(vert, joint)`` -- the only part of the 6890-vertex mesh the path consumes.
+        ``shape`` (model.py:209-229): None, 10 betas for every frame, or [batch, 10] with one row per frame -- the frames are
+        then grouped by distinct beta row and every group runs on its own shaped body (``rc_shape_body`` once per distinct
+        shape; a batch normally holds a handful of subjects)."""
         pose = _f32c(pose, self.device).view(-1, 24, 3, 3)
         n = pose.shape[0]
+        if shape is not None:
+            beta = torch.as_tensor(shape, dtype=torch.float32).detach().cpu().reshape(-1, 10)
+            if beta.shape[0] not in (1, n):
+                raise ValueError(f"shape must expand to [{n}, 10]")
+            if beta.shape[0] == n and n > 1 and not bool((beta == beta[:1]).all()):
+                uniq, inv = torch.unique(beta, dim=0, return_inverse=True)
+                outs = None
+                tr = None if tran is None else _f32c(tran, self.device).view(n, 3)
+                for g in range(uniq.shape[0]):
+                    idx = (inv == g).nonzero().flatten().to(self.device)
+                    part = self.forward_kinematics(pose[idx], uniq[g], None if tr is None else tr[idx], calc_mesh)
+                    if outs is None:
+                        outs = [torch.empty((n,) + tuple(o.shape[1:]), device=self.device) for o in part]
+                    for o, q in zip(outs, part):
+                        o[idx] = q
+                return tuple(outs)
+            shape = beta[0]
+        self.set_shape(shape)                                           # one shape for all of these frames (model.py:228)
         tran = torch.zeros(n, 3, device=self.device) if tran is None else _f32c(tran, self.device).view(n, 3)
         grot = torch.empty_like(pose)
         joint = torch.empty(n, 24, 3, device=self.device)

@@ -116,19 +116,14 @@ struct rc_ctx {
     size_t ev_used = 0;
     double timed_ms = 0.0;
     long long timed_launches = 0;
-    // sequence mode (rc_sequence on all-visible stretches): skewed stage pipeline, one gate-GEMM launch per tick
+    // sequence mode of rc_sequence: launch planner + per-row-cursor wavefront engine (run_wave2_segment)
     bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
     bool live_launch = false;            // set while a live frame is captured / launched (GemmLaunch.live)
-    int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (rc_set_sequence_mode)
-    int seq_min_frames = 48;             // shortest stretch worth filling and draining the 11-stage pipeline for (break-even ~40)
-    bool ring_ready = false;
-    FrameBuffers ring[16];               // slot 0 = fb; slots 1..15 allocated on first use
+    int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (cost estimate), 2 = wavefront whenever long enough
+    int seq_min_frames = 8;              // calls shorter than this are neither planned nor skewed (no pre-pass, no synchronisation)
     float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
-    std::vector<GemmProblem> tick_prob;  // [16][RC_TICK_PROB] GEMM problems per (tick mod 16), assembled into launches per tick
     int tile6[2] = {0, 0}, tile378[2] = {0, 0}, tile2[2] = {0, 0}, tile4[2] = {0, 0};   // LSTM tile shapes of full-batch stages (0 = pick_tile)
-    bool tick_valid = false;
-    bool seq_lin1_main = true;
-    bool seq_two_streams = true;         // tuning: per-row kernels + linear2 on the second stream (else everything on the caller's)          // tuning: linear1 problems ride in the last wide launch instead of the second stream
+    bool seq_two_streams = true;         // tuning: per-row kernels + linear2 on the second stream (else everything on the caller's)
     hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
     hipEvent_t ev_main[8] = {}, ev_aux[8] = {};
     signed char* scan_codes_d = nullptr; // [cap] regime code per (frame, row)
@@ -137,9 +132,8 @@ struct rc_ctx {
     size_t scan_cap = 0;
     long long stat_wave_frames = 0, stat_stepped_frames = 0, stat_ticks = 0;
     // per-row-cursor wavefront engine (run_wave2_segment)
-    int seq_engine = 2;                  // 0: frame-stepped only, 1: all-visible stretches only (round-2 engine), 2: per-row cursors
     bool ring2_ready = false;
-    FrameBuffers ring2[16];              // ring[] slots + their own updater-input buffers, frame index and step numbers per row
+    FrameBuffers ring2[16];              // ring slots: inter-stage buffers, updater inputs, frame index and step numbers per row
     std::vector<GemmProblem> wave2_prob; // [16 slots][W2_PROB]
     bool wave2_valid = false;
     int* frame_at_d = nullptr;           // [cap] host plan: frame every row starts at every tick
@@ -502,221 +496,69 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
                            Stage{N4, (int)RC_ROW2_FLUSH, fb.x4l, 256, Out{nullptr, 0, 0, false}, fb.flags2}}, false, nullptr, st);
 }
 
-// ====================================================================================== sequence mode (wavefront)
-// Frames on which EVERY row sees the camera (c > lo), no row fires the one-shot init_net and no deferred updater step is
-// pending have no feedback from the end of the frame into any sub-net (net/sig_mp.py:264-271 only fires at c <= lo,
-// L178-183 once per sequence). On a stretch of such frames the 11 stages of a frame
-//   0 prep | 1 linear1{rnn2,rnn4} | 2,3 LSTM l0,l1 {rnn2,rnn4} | 4 linear2{rnn2,rnn4} | 5 fuse |
-//   6 linear1{rnn6,rnn3,rnn7,rnn8} | 7,8 LSTM l0,l1 | 9 linear2 | 10 tail
-// only depend on the previous stage of the SAME frame and on their own state of the PREVIOUS frame, so tick k runs
-// stage s on frame k - s for all s at once. What the skew buys is the freedom to group the 12 LSTM layer-steps of a tick by
-// TILE DURATION instead of by data dependence: four launches on the caller's stream,
-//   {rnn4 l0, l1}   {rnn6 l0, l1}   {rnn2 l0, l1, rnn3 l0, l1}   {rnn7 l0, l1, rnn8 l0, l1},
-// each a whole number of rounds of equal tiles at batch 256 (the frame-stepped stages mix 58 us and 14 us tiles and end on
-// a partly filled round), and -- every row being active -- 64 x 128 tiles for the H = 512 nets (a quarter of the tiles, so a
-// quarter of the per-tile prologue / reduction / epilogue time, which is 20 % of a 32 x 64 tile). The weight-streaming launches
-// (linear1, linear2: 16-row tiles on the small-tile kernel, 4 workgroups per CU) and the three per-row kernels run beside them
-// on a context-owned second stream; the two streams hand over once per tick. Inter-stage buffers are rings of 16 frames;
-// the step counters stand still during a segment (parity comes from step_off) and are advanced once at its end.
-// Every output element is the same chain of fp32 operations as in the frame-stepped launches (the K split and the
-// accumulation order do not depend on the tile shape): outputs and states are bitwise equal.
-enum { SEQ_STEPPED_TR = 0, SEQ_STEPPED = 1, SEQ_WAVE = 2 };
-const int kRing = 16, kStages = 11;
+// ====================================================================================== sequence mode of rc_sequence
+// Stages of a frame in the wavefront engine below (stage s of the ring slot started at tick e runs at tick e + s):
+//   0 prep | 1 linear1{rnn2,rnn4} | 2,3 LSTM l0,l1 {rnn2,rnn4} | 4 linear2{rnn2,rnn4} then fuse |
+//   5 linear1{rnn6,rnn3,rnn7,rnn8} (+ init_net layer 0) | 6,7 LSTM l0,l1 (+ init_net layers 1, 2) | 8 linear2 then tail
+// linear2, fuse and tail are consecutive kernels of ONE tick on the second stream (a dependent chain of ~35 us beside the
+// ~220 us of wide launches), so a frame is 9 ticks deep, not 11 as in round 2.
+// Launch groups of a tick: four wide launches on the caller's stream, grouped by TILE DURATION instead of by data
+// dependence -- {rnn4 l0, l1}, {rnn6 l0, l1}, {rnn2 l0, l1, rnn3 l0, l1 + init_net}, {rnn7 l0, l1, rnn8 l0, l1 + the six
+// linear1}: each a whole number of rounds of equal tiles at batch 256 (rnn4 64 x 80, rnn6 and the H = 512 nets 64 x 128) --
+// and linear2 (16-row tiles, fp32-input kernel) with the per-row kernels on a context-owned second stream; the two streams
+// hand over once per tick. (Weight-streaming launches BESIDE the wide ones stretch those: linear1 rides in a wide launch.)
+enum { SEQ_STEPPED_TR = 0, SEQ_STEPPED = 1 };
+const int kRing = 16;
 
 struct TickStage { int kind; int net; int stage; int group; };   // kind: 0 linear1, 1 LSTM l0, 2 LSTM l1, 3 linear2
-// groups 0-3: caller's stream (wide tiles); 4 (linear1) and 5 (linear2): second stream (16-row tiles, small-tile kernel)
+// groups 0-3: caller's stream (wide tiles; linear1 rides in group 3); 5 (linear2): second stream (16-row tiles)
 const TickStage kTick[RC_TICK_PROB] = {
-    {1, N4, 2, 0}, {2, N4, 3, 0}, {1, N6, 7, 1}, {2, N6, 8, 1},
-    {1, N2, 2, 2}, {2, N2, 3, 2}, {1, N3, 7, 2}, {2, N3, 8, 2}, {1, N7, 7, 3}, {2, N7, 8, 3}, {1, N8, 7, 3}, {2, N8, 8, 3},
-    {0, N4, 1, 4}, {0, N2, 1, 4}, {0, N6, 6, 4}, {0, N3, 6, 4}, {0, N7, 6, 4}, {0, N8, 6, 4},
-    {3, N4, 4, 5}, {3, N2, 4, 5}, {3, N6, 9, 5}, {3, N3, 9, 5}, {3, N7, 9, 5}, {3, N8, 9, 5}};
+    {1, N4, 2, 0}, {2, N4, 3, 0}, {1, N6, 6, 1}, {2, N6, 7, 1},
+    {1, N2, 2, 2}, {2, N2, 3, 2}, {1, N3, 6, 2}, {2, N3, 7, 2}, {1, N7, 6, 3}, {2, N7, 7, 3}, {1, N8, 6, 3}, {2, N8, 7, 3},
+    {0, N4, 1, 3}, {0, N2, 1, 3}, {0, N6, 5, 3}, {0, N3, 5, 3}, {0, N7, 5, 3}, {0, N8, 5, 3},
+    {3, N4, 4, 5}, {3, N2, 4, 5}, {3, N6, 8, 5}, {3, N3, 8, 5}, {3, N7, 8, 5}, {3, N8, 8, 5}};
+const int kFuseStage = 4, kTailStage = 8, kInitStage = 5;
 
 int tune_env(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
 }
 
-int ensure_sequence_buffers(rc_ctx* ctx) {
-    if (ctx->ring_ready) return RC_OK;
-    const size_t B = (size_t)ctx->B, Bp = (size_t)ctx->Bp;
-    ctx->ring[0] = ctx->fb;
-    for (int s = 1; s < kRing; ++s) {
-        FrameBuffers f = ctx->fb;                      // state pointers are shared; the per-frame buffers get their own slot
-        int rc = RC_OK;
-#define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
-        A(f.x2, Bp * 128); A(f.x3, Bp * 256); A(f.x4, Bp * 256); A(f.x6, Bp * 256); A(f.x78, Bp * 256); A(f.xi, Bp * 128);
-        A(f.vr, B * 4); A(f.pc, B * 4); A(f.r6d, B * 144); A(f.contact, B * 2);
-        A(f.flags, B); A(f.flags2, B); A(f.regime, B); A(f.kconf, B);
-#undef A
-        if (rc) return rc;
-        ctx->ring[s] = f;
-    }
-    for (int i = 0; i < 6; ++i)
-        if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 8; ++i) {
-        // device-scope release: the hand-over is between two streams of this GPU
-        const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], evf));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], evf));
-    }
-    ctx->ring_ready = true;
-    ctx->tick_valid = false;
-    return RC_OK;
-}
-
-// GEMM problems of the 16 tick residues: the problem of stage s at residue r works on ring slot (r - s) mod 16.
-// Tile shapes (batch >= RC_SPLIT_MIN_BATCH; smaller batches keep pick_tile's choice): rnn4 / rnn6 as in the frame-stepped
-// launches, H = 512 nets 64 x 128 (4 x 8 blocks): 64 workgroups per layer-step, four layer-steps per launch = ONE full round
-// of 256 (64 x 64 tiles: two rounds of shorter, less efficient tiles; measured 995k -> 1,070k body-frames/s, r02y).
-int build_tick_problems(rc_ctx* ctx) {
-    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
-    tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
-    tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
-    tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
-    ctx->seq_lin1_main = tune_env("RC_SEQ_LIN1_MAIN", 1) != 0;
-    ctx->seq_two_streams = tune_env("RC_SEQ_STREAMS", 2) == 2;
-    ctx->tick_prob.assign((size_t)kRing * RC_TICK_PROB, GemmProblem{});
-    for (int r = 0; r < kRing; ++r) {
-        for (int q = 0; q < RC_TICK_PROB; ++q) {
-            const TickStage& ts = kTick[q];
-            const int fr = ((r - ts.stage) % kRing + kRing) % kRing;        // frame residue = ring slot
-            const FrameBuffers& fb = ctx->ring[fr];
-            const NetDev& n = ctx->net[ts.net];
-            float* x1 = (fr & 1) ? ctx->x1_alt[ts.net] : n.x1;
-            Stage st{ts.net, 0, nullptr, 256, Out{nullptr, 0, 0, false}};
-            switch (ts.net) {
-                case N4: st.x = fb.x4; st.y = Out{fb.x6, 256, 171, true}; break;
-                case N2: st.x = fb.x2; st.ldx = 128; st.y = Out{fb.x3, 256, 72, true}; break;
-                case N6: st.x = fb.x6; st.y = Out{fb.pc, 4, 0, false}; break;
-                case N3: st.x = fb.x3; st.y = Out{fb.vr, 4, 0, false}; break;
-                case N7: st.x = fb.x78; st.y = Out{fb.r6d, 144, 0, false}; break;
-                default: st.x = fb.x78; st.y = Out{fb.contact, 2, 0, false}; break;
-            }
-            GemmProblem p = ts.kind == 0 ? lin1_problem(ctx, st) : (ts.kind == 3 ? lin2_problem(ctx, st) : lstm_problem(ctx, st, ts.kind - 1));
-            if (ts.kind == 0) {
-                p.out = x1;                                                   // relu(linear1) double-buffered by frame parity
-                if (!ctx->seq_lin1_main) {                                    // 16 x 32 tiles: side kernel, beside the wide launches
-                    p.mr = 1; p.nc = 2;
-                    p.n_tiles = n.lin1.Np / 32; p.m_tiles = (ctx->B + 15) / 16;
-                }
-            }
-            if (ts.kind == 1) p.seg[0].base = x1;
-            if ((ts.kind == 1 || ts.kind == 2) && ctx->B >= RC_SPLIT_MIN_BATCH) {
-                const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
-                const int mr = t[0], nc = t[1];
-                p.mr = mr; p.nc = nc;
-                p.n_tiles = n.H / (4 * nc); p.m_tiles = (ctx->B + 16 * mr - 1) / (16 * mr);
-            }
-            p.flags = nullptr; p.flag_bit = 0;                                // every row steps every sub-net
-            p.alt_base = nullptr; p.sel_flags = nullptr; p.sel_bit = 0;
-            p.out_flags = nullptr; p.out_bit = 0;
-            p.open_step = 0;
-            ctx->tick_prob[(size_t)r * RC_TICK_PROB + q] = p;
-        }
-    }
-    ctx->tick_valid = true;
-    return RC_OK;
-}
-
-// One segment [t0, t1) of a rc_sequence call in sequence mode. io_at(t) gives the FrameIO of frame t.
-template <typename IoAt>
-int run_wave_segment(rc_ctx* ctx, int t0, int t1, IoAt io_at, hipStream_t st) {
-    if (int rc = ensure_sequence_buffers(ctx)) return rc;
-    if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
-    const int B = ctx->B;
-    const rc_params_dev prm = dev_params(ctx->prm);
-    const bool two = ctx->seq_two_streams;
-    hipStream_t aux = two ? ctx->aux_stream : st;
-    auto in_seg = [&](int f) { return f >= t0 && f < t1; };
-    auto group = [&](int k, int g, hipStream_t s) -> int {                  // launch the active problems of group g at tick k
-        std::vector<GemmProblem> ps;
-        for (int q = 0; q < RC_TICK_PROB; ++q) {
-            const int f = k - kTick[q].stage;
-            const int gq = (kTick[q].group == 4 && ctx->seq_lin1_main) ? 3 : kTick[q].group;
-            if (gq != g || !in_seg(f)) continue;
-            GemmProblem p = ctx->tick_prob[(size_t)(k % kRing) * RC_TICK_PROB + q];
-            p.step_off = 1 + (f - t0);                                        // steps[row] stands still during the segment
-            ps.push_back(p);
-        }
-        return launch_problems(ctx, ps, nullptr, s, g == 5);               // linear2 on the fp32-input kernel, as in run_stage
-    };
-    if (two) {   // the second stream joins: everything enqueued so far on `st` (earlier frames, weight uploads) is visible to it
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));
-        HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
-    }
-    for (int k = t0; k < t1 + kStages - 1; ++k) {
-        const int e = (k - t0) & 3, ep = (k - t0 + 3) & 3;          // event slots of this tick / the previous tick
-        // ---- per-row kernels and the weight-streaming GEMMs of tick k (second stream: after the previous tick's wide launches)
-        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
-        if (in_seg(k)) rc_launch_prep(ctx->ring[k % kRing], io_at(k), prm, B, 0, aux);
-        if (int rc = group(k, 4, aux)) return rc;
-        if (in_seg(k - 5)) rc_launch_fuse(ctx->ring[(k - 5) % kRing], io_at(k - 5), prm, B, aux);
-        if (int rc = group(k, 5, aux)) return rc;
-        if (in_seg(k - 10)) rc_launch_tail(ctx->ring[(k - 10) % kRing], io_at(k - 10), prm, ctx->body, B, 0, aux);
-        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
-        // ---- the LSTM layer-steps of tick k (caller's stream: after the previous tick's second-stream work)
-        // (The two hand-overs cost ~13 us of a 232 us tick -- timing-only probe without them, r02z; waiting in front of the last
-        // launch instead of the first, or releasing at device scope, changes nothing: the packets themselves are the cost.)
-        if (two && k > t0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-        for (int g = 0; g < 4; ++g)
-            if (int rc = group(k, g, st)) return rc;
-        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
-        ctx->stat_ticks += 1;
-    }
-    // the caller's stream continues after the last tail; every sub-net stepped (t1 - t0) times on every row
-    if (two) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(t1 + kStages - 2 - t0) & 3], 0));
-    int* steps6[6];
-    for (int i = 0; i < 6; ++i) steps6[i] = ctx->net[i].steps;
-    rc_launch_advance_steps(steps6, t1 - t0, B, st);
-    HIP_TRY(ctx, hipGetLastError());
-    ctx->stat_wave_frames += t1 - t0;
-    return RC_OK;
-}
-
-// Launch plan of a rc_sequence call from the regime codes (pure host logic, exposed as rc_plan_sequence for tests).
-void plan_sequence(const signed char* codes, int B, int T, const int* first_reach, const int* pend, bool first_frame,
-                   bool has_first_tran, bool use_imu_updater, bool use_vision_updater, int min_frames, unsigned char* mode) {
-    std::vector<unsigned char> fr(B), pd(B), ok(T);
-    for (int b = 0; b < B; ++b) { fr[b] = first_reach[b] != 0; pd[b] = pend[b] != 0; }
+// Frame-stepped launch plan of a rc_sequence call from the regime codes (pure host logic, exposed as rc_plan_sequence for
+// tests): the three transition launches are needed on the frames where some row carries a deferred updater step INTO a frame
+// it steps on camera keypoints (net/sig_mp.py:264-271 then L149-153).
+void plan_sequence(const signed char* codes, int B, int T, const int* pend, bool first_frame, bool use_vision_updater, unsigned char* mode) {
+    std::vector<unsigned char> pd(B);
+    for (int b = 0; b < B; ++b) pd[b] = pend[b] != 0;
     for (int t = 0; t < T; ++t) {
         const signed char* c = codes + (size_t)t * B;
-        bool all_vis = true, reach = false, pend_in = false, need_tr = false;
+        bool need_tr = false;
         const bool ff = t == 0 && first_frame;
         for (int b = 0; b < B; ++b) {
-            const bool vis = c[b] >= 1 || ff;                                  // rnn4 steps on the camera keypoints (L149)
-            all_vis = all_vis && c[b] >= 1;
-            if (pd[b]) { pend_in = true; if (vis) need_tr = true; }
-            if (fr[b] && c[b] == 2 && use_imu_updater) { reach = true; fr[b] = 0; }      // L178-180
-            pd[b] = (c[b] == 0 && use_vision_updater) ? 1 : 0;                           // L264 (non-live)
+            if (pd[b] && (c[b] >= 1 || ff)) need_tr = true;                    // rnn4 steps on the camera keypoints (L149)
+            pd[b] = (c[b] == 0 && use_vision_updater) ? 1 : 0;                 // L264 (non-live)
         }
-        ok[t] = all_vis && !reach && !pend_in && !(t == 0 && (first_frame || has_first_tran));
         mode[t] = need_tr ? SEQ_STEPPED_TR : SEQ_STEPPED;
-    }
-    for (int t = 0; t < T;) {
-        if (!ok[t]) { ++t; continue; }
-        int e = t;
-        while (e < T && ok[e]) ++e;
-        if (e - t >= min_frames) for (int q = t; q < e; ++q) mode[q] = SEQ_WAVE;
-        t = e;
     }
 }
 
-// ============================================================== per-row-cursor wavefront engine ("wave2", round 3)
-// The all-visible engine above stops at the first occluded row: the vision updater (net/sig_mp.py:264-271) feeds the END of a
-// frame (landmarks of the tail) back into rnn6 / rnn4, so a row's next camera step has to wait for it. But rows are independent
-// (SURVEY.md 8(e)), so a row can simply LAG the batch. Here every row has its own frame cursor:
+
+// ============================================================== per-row-cursor wavefront engine (round 3)
+// Round 2's engine skewed the stages only over stretches on which EVERY row saw the camera: the vision updater
+// (net/sig_mp.py:264-271) feeds the END of a frame (landmarks of the tail) back into rnn6 / rnn4, so a row's next camera step
+// has to wait for it -- and one occluded row stopped the batch. But rows are independent, so a row can
+// simply LAG the batch. Here every row has its own frame cursor:
 //   * tick k initialises ring slot k % 16: row r starts its next frame there, or nothing (a bubble) when that frame has to
 //     wait. The slot carries, per row, the frame index and the step number of every sub-net step the frame takes, so the stages
 //     of a row's frames can be in flight at different step counts while the row's counters move on;
 //   * the stages are those of the frame-stepped launch plan (step_impl) skewed over the ring: stage s of the slot initialised
 //     at tick e runs at tick e + s with the slot's row flags selecting its rows (the stateless row compaction of the GEMM);
-//   * an occluded frame's two updater steps RIDE the slot that is initialised at the tick its tail runs (tail = stage 10 ->
-//     slot e + 10): the tail writes their inputs into that slot's x4l / x6l and marks the row there, and the steps merge into
+//   * an occluded frame's two updater steps RIDE the slot that is initialised at the tick its tail runs (tail = stage 8 ->
+//     slot e + 8): the tail writes their inputs into that slot's x4l / x6l and marks the row there, and the steps merge into
 //     that slot's own rnn4 / rnn6 launches exactly like the "merged deferred rows" of the frame-stepped plan. The row's next
-//     VISIBLE frame may start at tick e + 11 at the earliest (its rnn4 / rnn6 layer steps then follow the rider's by one tick);
-//     a further occluded frame starts at e + 1 as usual: an occlusion costs a row 10 ticks of lag once, at its end;
-//   * the one-shot init_net (L178-183) writes rnn2's state in the tail: the row's next frame starts at e + 9;
+//     VISIBLE frame may start at tick e + 9 at the earliest (its rnn4 / rnn6 layer steps then follow the rider's by one tick);
+//     a further occluded frame starts at e + 1 as usual: an occlusion costs a row 8 ticks of lag once, at its end;
+//   * the one-shot init_net (L178-183) writes rnn2's state in the tail: the row's next frame starts at e + 7;
 //   * a step left pending by the frames before the segment rides slot 0; the last frame of the segment leaves its updater step
 //     pending in the context's own buffers, as the frame-stepped path does.
 // The host plans all of it from the regime codes of the pre-pass (plan_wave: pure host logic, exposed as rc_plan_wave) and
@@ -724,7 +566,8 @@ void plan_sequence(const signed char* codes, int B, int T, const int* first_reac
 // from the exact row counts (ticks that only serve lagging rows stream the weights through 16/32-row tiles).
 // Arithmetic per row is that of the frame-stepped plan, operation for operation: outputs and states are bitwise equal.
 enum { W2_INIT0 = RC_TICK_PROB, W2_INIT1, W2_INIT2, W2_PROB };
-const int kRideStage = 10;                     // the tail's stage: an updater rides the slot initialised at that tick
+const int kRideStage = kTailStage;              // an updater rides the slot initialised at the tick its frame's tail runs
+const int kRiderSpan = 8;                      // ... and its last launch (rnn6 l1, stage 7 of that slot) is 7 ticks later
 
 struct WavePlan {
     int n_ticks = 0;                           // ticks to launch
@@ -751,7 +594,7 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
         int e_prev = -1, ready_any = 0, ready_vis = 0;
         bool fr = first_reach[b] != 0;
         bool pd = pend[b] != 0 && use_vision_updater;
-        if (pd) { grow(0); P.n_rider[0] += 1; ready_vis = 1; need = std::max(need, 9); n_prep = std::max(n_prep, 1); }
+        if (pd) { grow(0); P.n_rider[0] += 1; ready_vis = 1; need = std::max(need, kRiderSpan); n_prep = std::max(n_prep, 1); }
         for (int f = t0; f < T; ++f) {
             const int c = codes[(size_t)f * B + b];
             const bool vis = c >= 1;
@@ -769,7 +612,7 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
                 grow(ride);
                 P.n_rider[ride] += 1;
                 ready_vis = ride + 1;
-                need = std::max(need, ride + 9);
+                need = std::max(need, ride + kRiderSpan);
                 n_prep = std::max(n_prep, ride + 1);
             }
             need = std::max(need, e + kRideStage + 1);
@@ -789,7 +632,7 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
     P.est_wave_us = 0.0;
     for (int k = 0; k < P.n_ticks; ++k) {
         int rows = 0;
-        for (int st = 1; st <= 9; ++st) {
+        for (int st = 1; st <= kTailStage; ++st) {
             const int e = k - st;
             if (e >= 0 && e < n_prep) rows = std::max(rows, P.n_valid[e] + P.n_rider[e]);
         }
@@ -801,17 +644,27 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
 
 int ensure_wave2_buffers(rc_ctx* ctx) {
     if (ctx->ring2_ready) return RC_OK;
-    if (int rc = ensure_sequence_buffers(ctx)) return rc;
     const size_t B = (size_t)ctx->B, Bp = (size_t)ctx->Bp;
     for (int s = 0; s < kRing; ++s) {
-        FrameBuffers f = ctx->ring[s];
+        FrameBuffers f = ctx->fb;                      // state pointers are shared; the per-frame buffers get their own slot
         int rc = RC_OK;
 #define A(ptr, n) if (!rc) rc = dev_alloc(ctx, &(ptr), (n))
-        A(f.x4l, Bp * 256); A(f.x6l, Bp * 256); A(f.frame, B); A(f.wsteps, 6 * B);
-        if (s == 0) { A(f.flags, B); A(f.flags2, B); A(f.regime, B); A(f.kconf, B); }   // slot 0 of ring[] is the context's own set
+        A(f.x2, Bp * 128); A(f.x3, Bp * 256); A(f.x4, Bp * 256); A(f.x6, Bp * 256); A(f.x78, Bp * 256); A(f.xi, Bp * 128);
+        A(f.x4l, Bp * 256); A(f.x6l, Bp * 256);
+        A(f.vr, B * 4); A(f.pc, B * 4); A(f.r6d, B * 144); A(f.contact, B * 2);
+        A(f.flags, B); A(f.flags2, B); A(f.regime, B); A(f.kconf, B); A(f.frame, B); A(f.wsteps, 6 * B);
 #undef A
         if (rc) return rc;
         ctx->ring2[s] = f;
+    }
+    for (int i = 0; i < 6; ++i)
+        if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) {
+        // device-scope release: the hand-over is between two streams of this GPU
+        const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], evf));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], evf));
     }
     ctx->ring2_ready = true;
     ctx->wave2_valid = false;
@@ -821,7 +674,6 @@ int ensure_wave2_buffers(rc_ctx* ctx) {
 // GEMM problems of every ring slot: problem q (kTick order, then the three init_net layers) working on slot sl. Rows come from
 // the slot's flag bytes as in step_impl; tile shapes and row-tile counts are filled in per tick from the plan's row counts.
 int build_wave2_problems(rc_ctx* ctx) {
-    ctx->seq_lin1_main = true;
     ctx->seq_two_streams = tune_env("RC_SEQ_STREAMS", 2) == 2;
     ctx->wave2_prob.assign((size_t)kRing * W2_PROB, GemmProblem{});
     const int B = ctx->B;
@@ -859,8 +711,8 @@ int build_wave2_problems(rc_ctx* ctx) {
 }
 
 // stage and launch group of the problems beyond kTick (init_net layers: beside linear1 / LSTM l0 / l1 of the second half)
-inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : 6 + (q - W2_INIT0); }
-inline int w2_group(int q) { return q < RC_TICK_PROB ? (kTick[q].group == 4 ? 3 : kTick[q].group) : 2; }
+inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : kInitStage + (q - W2_INIT0); }
+inline int w2_group(int q) { return q < RC_TICK_PROB ? kTick[q].group : 2; }
 
 int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0, int t_last, hipStream_t st) {
     if (int rc = ensure_wave2_buffers(ctx)) return rc;
@@ -892,8 +744,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     auto group = [&](int k, int g, hipStream_t s) -> int {                  // launch the problems of group g that have rows at tick k
         std::vector<GemmProblem> ps;
         for (int q = 0; q < W2_PROB; ++q) {
-            const int gq = q < RC_TICK_PROB && kTick[q].group == 5 ? 5 : w2_group(q);
-            if (gq != g) continue;
+            if (w2_group(q) != g) continue;
             const int e = k - w2_stage(q);
             if (e < 0 || e >= P.n_prep) continue;
             const int net = q < RC_TICK_PROB ? kTick[q].net : -1;
@@ -942,14 +793,14 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         if (k < P.n_prep) {
             wp.frame_at = ctx->frame_at_d + (size_t)k * B;
             wp.first_tick = k == 0 ? 1 : 0;
-            rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);
+            rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);   // (before the tail: it initialises the tail's target slot)
         }
-        if (cnt(P.n_valid, k - 5) > 0) rc_launch_fuse(ctx->ring2[(k - 5) % kRing], io0, prm, B, aux);
-        if (int rc = group(k, 5, aux)) return rc;
-        if (cnt(P.n_valid, k - kRideStage) > 0) {
+        if (int rc = group(k, 5, aux)) return rc;                               // linear2 of stages 4 and 8 ...
+        if (cnt(P.n_valid, k - kFuseStage) > 0) rc_launch_fuse(ctx->ring2[(k - kFuseStage) % kRing], io0, prm, B, aux);   // ... then their consumers
+        if (cnt(P.n_valid, k - kTailStage) > 0) {
             const FrameBuffers& tgt = ctx->ring2[k % kRing];
             wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
-            rc_launch_tail(ctx->ring2[(k - kRideStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt);
+            rc_launch_tail(ctx->ring2[(k - kTailStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt);
         }
         if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
         // ---- the GEMM stages of tick k (caller's stream: after the previous tick's second-stream work)
@@ -1048,9 +899,6 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     rc_default_params(live, &ctx->prm);
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0;
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
-    ctx->seq_engine = tune_env("RC_SEQ_ENGINE", 2);
-    if (ctx->seq_engine < 0 || ctx->seq_engine > 2) ctx->seq_engine = 2;
-    if (ctx->seq_engine == 2) ctx->seq_min_frames = 8;
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_US", (int)ctx->cost_tick_us);
@@ -1184,8 +1032,7 @@ int rc_finalize_weights(rc_ctx* ctx) {
     for (void* p : ctx->weight_allocs) (void)hipFree(p);
     ctx->weight_allocs.clear();
     ctx->have_weights = false;
-    ctx->tick_valid = false;             // the sequence-mode launch tables hold weight pointers
-    ctx->wave2_valid = false;
+    ctx->wave2_valid = false;            // the sequence-mode launch tables hold weight pointers
     ctx->alloc_weights = true;
     const int rc = finalize_weights_impl(ctx);
     ctx->alloc_weights = false;
@@ -1314,17 +1161,11 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     WavePlan wplan;
     int wave2_from = -1;                    // first frame of the per-row-cursor segment (it runs to the end of the call)
     // (calls shorter than min_frames are not planned at all: no pre-pass, no synchronisation, fully asynchronous)
-    if (ctx->seq_mode && !ctx->prm.live && T >= 2 &&
-        (ctx->seq_engine != 2 || T - ((flags & RC_FLAG_FIRST_FRAME) || first_tran ? 1 : 0) >= std::max(1, ctx->seq_min_frames))) {
-        // rings, second stream and tick problems are set up by the first planned call (a warm-up call pays for them), not by
-        // the first call that happens to contain a long all-visible stretch
-        if (ctx->seq_engine == 2) {
-            if (int rc = ensure_wave2_buffers(ctx)) return rc;
-            if (!ctx->wave2_valid) if (int rc = build_wave2_problems(ctx)) return rc;
-        } else if (ctx->seq_engine == 1) {
-            if (int rc = ensure_sequence_buffers(ctx)) return rc;
-            if (!ctx->tick_valid) if (int rc = build_tick_problems(ctx)) return rc;
-        }
+    const int w0 = ((flags & RC_FLAG_FIRST_FRAME) || first_tran) ? 1 : 0;   // a frame that takes first_frame / first_tran runs frame-stepped
+    if (ctx->seq_mode && !ctx->prm.live && T >= 2 && T - w0 >= std::max(1, ctx->seq_min_frames)) {
+        // ring, second stream and launch tables are set up by the first planned call (a warm-up call pays for them)
+        if (int rc = ensure_wave2_buffers(ctx)) return rc;
+        if (!ctx->wave2_valid) if (int rc = build_wave2_problems(ctx)) return rc;
         const size_t need = (size_t)B * T;
         if (need > ctx->scan_cap) {
             if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
@@ -1351,8 +1192,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
         for (int b = 0; b < B; ++b) ctx->scan_state_h[B + b] = pend_b[b];
         const bool ff = (flags & RC_FLAG_FIRST_FRAME) != 0;
         const bool imu = ctx->prm.use_imu_updater != 0, vup = ctx->prm.use_vision_updater != 0;
-        const int w0 = (ff || first_tran) ? 1 : 0;           // a frame that takes first_frame / first_tran runs frame-stepped
-        if (ctx->seq_engine == 2 && T - w0 >= std::max(1, ctx->seq_min_frames)) {
+        {
             // per-row-cursor engine on frames [w0, T): the rows' state in front of frame w0
             std::vector<int> fr(ctx->scan_state_h, ctx->scan_state_h + B), pd(ctx->scan_state_h + B, ctx->scan_state_h + 2 * B);
             if (w0) {
@@ -1366,9 +1206,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
             plan_wave(ctx->scan_codes_h, B, T, w0, fr.data(), pd.data(), imu, vup, cost, wplan);
             if (ctx->seq_mode == 2 || wplan.est_wave_us < wplan.est_stepped_us) wave2_from = w0;
         }
-        // frame-stepped marks (and, for the round-2 engine, its all-visible stretches)
-        plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h, ctx->scan_state_h + B, ff, first_tran != nullptr, imu, vup,
-                      ctx->seq_engine == 1 ? ctx->seq_min_frames : (1 << 30), mode.data());
+        plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h + B, ff, vup, mode.data());    // transition-launch marks of stepped frames
     }
     bool prep_done = false;                 // the previous frame's tail kernel already ran this frame's prep
     for (int t = 0; t < T;) {
@@ -1377,15 +1215,10 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
             io0.first_tran = nullptr;
             if (int rc = run_wave2_segment(ctx, wplan, io0, t, T - 1, st)) return rc;
             t = T;
-        } else if (mode[t] == SEQ_WAVE) {
-            int e = t;
-            while (e < T && mode[e] == SEQ_WAVE) ++e;
-            if (int rc = run_wave_segment(ctx, t, e, io_at, st)) return rc;
-            t = e;
         } else {
             // consecutive frame-stepped frames: tail(t) and prep(t + 1) are back to back on the stream and per row, so
             // one wave does both (one launch boundary and the prep kernel's start-up latency less per frame)
-            const bool chain = t + 1 < T && mode[t + 1] != SEQ_WAVE && t + 1 != wave2_from;
+            const bool chain = t + 1 < T && t + 1 != wave2_from;
             const FrameIO next = chain ? io_at(t + 1) : FrameIO{};
             if (int rc = step_impl(ctx, io_at(t), t == 0 ? flags : 0u, st, mode[t] == SEQ_STEPPED_TR, prep_done, chain ? &next : nullptr)) return rc;
             prep_done = chain;
@@ -1419,11 +1252,10 @@ int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_fr
     return RC_OK;
 }
 
-int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* first_reach, const int32_t* pend, uint32_t flags,
-                     int32_t has_first_tran, int32_t use_imu_updater, int32_t use_vision_updater, int32_t min_frames, uint8_t* mode_out) {
-    if (!codes || !first_reach || !pend || !mode_out || B < 1 || T < 0 || min_frames < 1) return RC_ERR_INVALID;
-    plan_sequence(reinterpret_cast<const signed char*>(codes), B, T, first_reach, pend, (flags & RC_FLAG_FIRST_FRAME) != 0,
-                  has_first_tran != 0, use_imu_updater != 0, use_vision_updater != 0, min_frames, mode_out);
+int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* pend, uint32_t flags, int32_t use_vision_updater,
+                     uint8_t* mode_out) {
+    if (!codes || !pend || !mode_out || B < 1 || T < 0) return RC_ERR_INVALID;
+    plan_sequence(reinterpret_cast<const signed char*>(codes), B, T, pend, (flags & RC_FLAG_FIRST_FRAME) != 0, use_vision_updater != 0, mode_out);
     return RC_OK;
 }
 

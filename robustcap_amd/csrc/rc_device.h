@@ -8,6 +8,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+// value of lane `l` (a compile-time constant) on every lane: v_readlane_b32
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
@@ -70,11 +72,40 @@ struct WaveScratch {
 
 // Body constants are read with data-dependent indices (parent chains): staging them in LDS once per workgroup turns
 // ~10 dependent global-load round trips of the tail kernel into LDS reads.
+// Two phases, so that a latency-bound kernel can request the constants together with its other reads and store them later:
+// 16-byte pieces (both sides are 16-byte aligned: hipMalloc / an aligned __shared__ object), then the few words left over.
+template <int NT>
+struct BodyStage {
+    static constexpr int n = (int)(sizeof(BodyConst) / sizeof(int)), n4 = n / 4, iters = (n4 + NT - 1) / NT;
+    int4 v[iters];
+    int tail;
+    __device__ __forceinline__ void load(const BodyConst* __restrict__ src, int tid) {
+        const int4* s4 = reinterpret_cast<const int4*>(src);
+#pragma unroll
+        for (int q = 0; q < iters; ++q) {
+            const int i = tid + q * NT;
+            v[q] = i < n4 ? s4[i] : int4{0, 0, 0, 0};
+        }
+        tail = tid < n - 4 * n4 ? reinterpret_cast<const int*>(src)[4 * n4 + tid] : 0;
+    }
+    __device__ __forceinline__ void store(BodyConst* dst, int tid) const {
+        int4* d4 = reinterpret_cast<int4*>(dst);
+#pragma unroll
+        for (int q = 0; q < iters; ++q) {
+            const int i = tid + q * NT;
+            if (i < n4) d4[i] = v[q];
+        }
+        if (tid < n - 4 * n4) reinterpret_cast<int*>(dst)[4 * n4 + tid] = tail;
+    }
+};
 __device__ __forceinline__ void stage_body(BodyConst* dst, const BodyConst* __restrict__ src, int tid, int nthreads) {
-    const int n = (int)(sizeof(BodyConst) / sizeof(int));
+    constexpr int n = (int)(sizeof(BodyConst) / sizeof(int)), n4 = n / 4;
+    const int4* s4 = reinterpret_cast<const int4*>(src);
+    int4* d4 = reinterpret_cast<int4*>(dst);
+    for (int i = tid; i < n4; i += nthreads) d4[i] = s4[i];
     const int* s = reinterpret_cast<const int*>(src);
     int* d = reinterpret_cast<int*>(dst);
-    for (int i = tid; i < n; i += nthreads) d[i] = s[i];
+    if (tid < n - 4 * n4) d[4 * n4 + tid] = s[4 * n4 + tid];
 }
 
 // joint `j` of fk(glb_pose) (net/sig_mp.py:131-135): sum of parent-rotated rest bone vectors, root -> leaf order.

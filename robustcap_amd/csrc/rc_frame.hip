@@ -25,15 +25,44 @@
 // One wave, one body. pend_in / uv_count: the row's pending-updater mark and landmark refresh counter as they stand BEFORE this
 // frame (read from the state by rc_prep_kernel, handed over in registers when the previous frame's tail runs this in the same
 // wave -- rc_tail_kernel with a next frame).
-// Returns the RC_ROW_* byte of the row (the same value on every lane); flags2_extra is OR-ed into the second flag byte.
-__device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
-                                              const int lane, const int first_frame, const int pend_in, const int uv_count,
-                                              const unsigned flags2_extra = 0u) {
+// Split in two so that a caller can request the frame's inputs long before it needs them (rc_tail_kernel asks for the NEXT
+// frame's inputs at its very top: every global read of a wave is then one latency, not a chain of them).
+struct PrepIn {
+    float x, y, cf;         // keypoint `lane` (< 33)
+    float a3[3], al;        // accelerations of IMU lane / 3 (lanes < 18) and element `lane`
+    float o3[3], ol;        // orientation column entries of IMU lane / 9 (lanes < 54) and element `lane`
+    float rv;               // lanes 0..8: root orientation (IMU 5), L139 -- broadcast by prep_compute
+};
+__device__ __forceinline__ void prep_load(PrepIn& in, const FrameIO& io, const int row, const int lane) {
     const float* kp = io.j2d + row * io.s_j2d;
     const float* acc = io.acc + row * io.s_acc;
     const float* ori = io.ori + row * io.s_ori;
-    float x = 0.f, y = 0.f, cf = 0.f;
-    if (lane < 33) { x = kp[3 * lane]; y = kp[3 * lane + 1]; cf = kp[3 * lane + 2]; }
+    in.x = 0.f; in.y = 0.f; in.cf = 0.f; in.al = 0.f; in.ol = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { in.a3[q] = 0.f; in.o3[q] = 0.f; }
+    if (lane < 33) { in.x = kp[3 * lane]; in.y = kp[3 * lane + 1]; in.cf = kp[3 * lane + 2]; }
+    if (lane < 18) {
+        const int i = lane / 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) in.a3[q] = acc[3 * i + q];
+        in.al = acc[lane];
+    }
+    if (lane < 54) {
+        const int i = lane / 9, cc = lane % 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) in.o3[q] = ori[9 * i + 3 * q + cc];
+        in.ol = ori[lane];
+    }
+    // nine wave-uniform values: one vector load by lanes 0..8 and lane broadcasts (uniform reads would become scalar loads, each a
+    // round trip of its own behind s_waitcnt lgkmcnt(0); vector loads are all in flight together)
+    in.rv = lane < 9 ? ori[45 + lane] : 0.f;
+}
+
+// Returns the RC_ROW_* byte of the row (the same value on every lane); flags2_extra is OR-ed into the second flag byte.
+__device__ __forceinline__ unsigned prep_compute(const FrameBuffers& fb, const PrepIn& in, const rc_params_dev& prm, const int row,
+                                                 const int lane, const int first_frame, const int pend_in, const int uv_count,
+                                                 const unsigned flags2_extra = 0u) {
+    const float x = in.x, y = in.y, cf = in.cf;
     const float c = wave_sum(cf) / 33.0f;                                 // L138
     const double c64 = (double)c;                                         // python-double compares
     const bool gt_lo = c64 > prm.conf_lo, is_hi = c64 >= prm.conf_hi;
@@ -42,7 +71,7 @@ __device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const Fram
     bbox_normalise(x, y, lane, xn, yn);                                   // L150-152
     float Rcr[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];                     // L139
+    for (int k = 0; k < 9; ++k) Rcr[k] = lane_bcast(in.rv, k);
     unsigned f = 0;
     const bool vis = gt_lo || first_frame;
     if (vis) f |= RC_ROW_VIS;                                             // L149
@@ -64,25 +93,22 @@ __device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const Fram
         tr[1] = 0; tr[2] = 0; tr[4] = 0; tr[5] = 0; tr[6] = 0; tr[7] = 0;
     }
     if (lane < 18) {                                                      // accr = accc . Rcr, L142
-        const int i = lane / 3, j = lane % 3;
-        const float v = (acc[3 * i] * Rcr[j] + acc[3 * i + 1] * Rcr[3 + j]) + acc[3 * i + 2] * Rcr[6 + j];
+        const int j = lane % 3;
+        const float v = (in.a3[0] * Rcr[j] + in.a3[1] * Rcr[3 + j]) + in.a3[2] * Rcr[6 + j];
         fb.x2[rc_pk(row, lane, LD_X2)] = v;
         fb.x3[rc_pk(row, lane, LD_X3)] = v;
         fb.x78[rc_pk(row, lane, LD_X78)] = v;
-        const float a = acc[lane];
-        fb.x4[rc_pk(row, lane, LD_X4)] = a;
-        fb.x6[rc_pk(row, lane, LD_X6)] = a;
+        fb.x4[rc_pk(row, lane, LD_X4)] = in.al;
+        fb.x6[rc_pk(row, lane, LD_X6)] = in.al;
     }
     if (lane < 54) {                                                      // orir = Rcr^T . oric, L143
-        const int i = lane / 9, r = (lane % 9) / 3, cc = lane % 3;
-        const float* o = ori + 9 * i;
-        const float v = (Rcr[r] * o[cc] + Rcr[3 + r] * o[3 + cc]) + Rcr[6 + r] * o[6 + cc];
+        const int r = (lane % 9) / 3;
+        const float v = (Rcr[r] * in.o3[0] + Rcr[3 + r] * in.o3[1]) + Rcr[6 + r] * in.o3[2];
         fb.x2[rc_pk(row, 18 + lane, LD_X2)] = v;
         fb.x3[rc_pk(row, 18 + lane, LD_X3)] = v;
         fb.x78[rc_pk(row, 18 + lane, LD_X78)] = v;
-        const float a = ori[lane];
-        fb.x4[rc_pk(row, 18 + lane, LD_X4)] = a;
-        fb.x6[rc_pk(row, 18 + lane, LD_X6)] = a;
+        fb.x4[rc_pk(row, 18 + lane, LD_X4)] = in.ol;
+        fb.x6[rc_pk(row, 18 + lane, LD_X6)] = in.ol;
     }
     if (lane < 33) {
         const int k = 72 + 3 * lane;
@@ -90,6 +116,13 @@ __device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const Fram
         fb.x6[rc_pk(row, k, LD_X6)] = x; fb.x6[rc_pk(row, k + 1, LD_X6)] = y; fb.x6[rc_pk(row, k + 2, LD_X6)] = cf;
     }
     return f;
+}
+__device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int row,
+                                              const int lane, const int first_frame, const int pend_in, const int uv_count,
+                                              const unsigned flags2_extra = 0u) {
+    PrepIn in;
+    prep_load(in, io, row, lane);
+    return prep_compute(fb, in, prm, row, lane, first_frame, pend_in, uv_count, flags2_extra);
 }
 
 __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, int first_frame) {
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
                                                      const BodyConst* __restrict__ body_g, int B, int first_frame, FrameIO io_next,
                                                      int has_next, WaveTail wt) {
     __shared__ WaveScratch s;
-    __shared__ BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     const int row = blockIdx.x, lane = threadIdx.x;
     int frame = 0;
     if (wt.on) {
@@ -205,17 +238,69 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         io.pose_out += (long long)frame * 216; io.tran_out += (long long)frame * 3;
     }
     const bool wave_ride = wt.on && frame != wt.t_last;                    // updater inputs ride the target slot
-    stage_body(&s_body, body_g, lane, 64);
-    const BodyConst* body = &s_body;
+    // ---- every global read of this wave, requested up front (one memory latency instead of a chain of ~10: this kernel is a
+    // dependent-latency chain, 1,560 B of I/O per body). The ~55 per-row scalars (fusion state, sub-net outputs, root orientation)
+    // are GATHERED: lane l loads word l of the list below with one vector load and the values are handed out with readlane --
+    // as wave-uniform reads they would be scalar loads, each waiting for the previous one (s_waitcnt lgkmcnt(0)).
+    // The state reads are safe to hoist: only this wave writes its row.
+    BodyStage<64> bst;
+    bst.load(body_g, lane);
     const float* ori = io.ori + row * io.s_ori;
-    float Rcr[9];
+    const float* acc = io.acc + row * io.s_acc;
+    const bool ft_given = io.first_tran != nullptr;
+    const float* gp = nullptr;
+    if (lane < 6) gp = fb.last_pfoot + row * 6 + lane;
+    else if (lane < 9) gp = fb.last_tran + row * 3 + (lane - 6);
+    else if (lane < 12) gp = fb.gravity + row * 3 + (lane - 9);
+    else if (lane < 15) gp = fb.pc + row * 4 + (lane - 12);
+    else if (lane < 18) gp = fb.vr + row * 4 + (lane - 15);
+    else if (lane < 20) gp = fb.contact + row * 2 + (lane - 18);
+    else if (lane < 38) gp = fb.floor + row * 33 + 15 + (lane - 20);              // floor samples 5..10 (L213: mean of the last six)
+    else if (lane < 47) gp = ori + 45 + (lane - 38);                               // Rcr, L139
+    else if (lane < 50) gp = ft_given ? io.first_tran + row * 3 + (lane - 47) : nullptr;
+    else if (lane < 52) gp = reinterpret_cast<const float*>(fb.kconf + row) + (lane - 50);
+    else if (lane == 52) gp = reinterpret_cast<const float*>(fb.has_last + row);
+    else if (lane == 53) gp = reinterpret_cast<const float*>(fb.n_floor + row);
+    else if (lane == 54) gp = reinterpret_cast<const float*>(fb.uv_count + row);
+    const float gv = gp ? *gp : 0.f;
+    const unsigned char* bp = lane == 0 ? fb.flags + row : (lane == 1 ? fb.regime + row : nullptr);
+    const unsigned bv = bp ? (unsigned)*bp : 0u;
+    float r6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (lane < 24) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rcr[k] = ori[45 + k];
+        for (int k = 0; k < 6; ++k) r6[k] = fb.r6d[row * 144 + 6 * lane + k];
+    }
+    const float acc_l = lane < 18 ? acc[lane] : 0.f, ori_l = lane < 54 ? ori[lane] : 0.f;   // this frame's IMU data (updater inputs)
+    PrepIn nin;
+    if (has_next) prep_load(nin, io_next, row, lane);
+    bst.store(&s_body, lane);                                             // (LDS: visible to the wave after the first barrier)
+    const BodyConst* body = &s_body;
+    float lpf[6], ltr[3], g[3], pc[3], vr[3], flr[6][3], Rcr[9], ftr[3];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) lpf[c] = lane_bcast(gv, c);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ltr[c] = lane_bcast(gv, 6 + c); g[c] = lane_bcast(gv, 9 + c); pc[c] = lane_bcast(gv, 12 + c); vr[c] = lane_bcast(gv, 15 + c);
+        ftr[c] = lane_bcast(gv, 47 + c);
+    }
+    const float ct0 = lane_bcast(gv, 18), ct1 = lane_bcast(gv, 19);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) flr[q][c] = lane_bcast(gv, 20 + 3 * q + c);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rcr[k] = lane_bcast(gv, 38 + k);
+    const double k64 = __hiloint2double(__float_as_int(lane_bcast(gv, 51)), __float_as_int(lane_bcast(gv, 50)));
+    const bool has_last = __float_as_int(lane_bcast(gv, 52)) != 0;
+    int n_floor = __float_as_int(lane_bcast(gv, 53));
+    const int uvc = __float_as_int(lane_bcast(gv, 54));
+    const unsigned flags = (unsigned)__builtin_amdgcn_readlane((int)bv, 0);
+    const int regime = __builtin_amdgcn_readlane((int)bv, 1);
 
     // L173: 6D -> global rotations (root-relative frame)
     if (lane < 24) {
         float R[9];
-        r6d_to_R(fb.r6d + row * 144 + 6 * lane, R);
+        r6d_to_R(r6, R);
 #pragma unroll
         for (int k = 0; k < 9; ++k) s.Rg[lane][k] = R[k];
     }
@@ -244,17 +329,12 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
 
     // L187-203: root translation
-    const float c0 = sigmoidf_(fb.contact[row * 2]), c1 = sigmoidf_(fb.contact[row * 2 + 1]);   // L170
+    const float c0 = sigmoidf_(ct0), c1 = sigmoidf_(ct1);                  // L170
     const float cmax = fmaxf(c0, c1);
     const int foot = c1 > c0 ? 1 : 0;
-    const bool has_last = fb.has_last[row] != 0;
     const bool use_vel = (cmax < prm.contact_threshold) || !has_last;
-    const int regime = fb.regime[row];
-    const double k64 = fb.kconf[row];
-    const float pc[3] = {fb.pc[row * 4], fb.pc[row * 4 + 1], fb.pc[row * 4 + 2]};
     float tran[3];
     {
-        const float* vr = fb.vr + row * 4;
         float v[3];
         if (use_vel) {
             mat3_vec(Rcr, vr, v);
@@ -262,10 +342,10 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             for (int c = 0; c < 3; ++c) v[c] = v[c] * 3.0f / 60.0f;        // vel_scale / 60, L188
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = fb.last_pfoot[row * 6 + 3 * foot + c] - pf[foot][c];   // L190
+            for (int c = 0; c < 3; ++c) v[c] = (foot ? lpf[3 + c] : lpf[c]) - pf[foot][c];   // L190
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tran[c] = has_last ? fb.last_tran[row * 3 + c] + v[c] : v[c];
+        for (int c = 0; c < 3; ++c) tran[c] = has_last ? ltr[c] + v[c] : v[c];
     }
     bool far = false;
     if (regime == 2) {                                                     // L196-203
@@ -282,10 +362,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         }
     }
     // L206-221: floor height along gravity
-    const float* g = fb.gravity + row * 3;
     const bool on_ground = cmax > prm.contact_threshold;
-    const bool ft_given = io.first_tran != nullptr;
-    int n_floor = fb.n_floor[row];
     float p0[3], p1[3], pick[3] = {0.f, 0.f, 0.f};
     int appended = -1;
     {
@@ -303,10 +380,11 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
     if (prm.use_flat_floor && n_floor > 10 && on_ground) {
         float m[3] = {0.f, 0.f, 0.f};
+#pragma unroll
         for (int q = 5; q < 11; ++q) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float e = (q == appended) ? pick[c] : fb.floor[row * 33 + 3 * q + c];
+                const float e = (q == appended) ? pick[c] : flr[q - 5][c];
                 m[c] = (q == 5) ? e : m[c] + e;
             }
         }
@@ -323,13 +401,11 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
     if (ft_given) {                                                        // L222-225
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tran[c] = io.first_tran[row * 3 + c];
+        for (int c = 0; c < 3; ++c) tran[c] = ftr[c];
     } else if (first_frame) {
         tran[0] = pc[0]; tran[1] = pc[1]; tran[2] = pc[2];
     }
-    const unsigned flags = fb.flags[row];
     const bool live = prm.live != 0;
-    const int uvc = fb.uv_count[row];
     const bool refresh = !live || uvc == 0;
     const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
     const int pend_next = ((flags & RC_ROW_UPD) && !wave_ride) ? 1 : 0;
@@ -408,11 +484,10 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     // L264-271: inputs of the vision updater (rnn6 on raw re-projection, rnn4 on the normalised one)
     if (flags & RC_ROW_UPD) {
         // the updater's sub-net steps run at the start of the NEXT frame: this frame's IMU data goes with them
-        const float* acc = io.acc + row * io.s_acc;
         float* const x4l = wt.on ? (wave_ride ? wt.x4l : wt.cx4l) : fb.x4l;
         float* const x6l = wt.on ? (wave_ride ? wt.x6l : wt.cx6l) : fb.x6l;
-        if (lane < 18) { x4l[rc_pk(row, lane, LD_X4)] = acc[lane]; x6l[rc_pk(row, lane, LD_X6)] = acc[lane]; }
-        if (lane < 54) { x4l[rc_pk(row, 18 + lane, LD_X4)] = ori[lane]; x6l[rc_pk(row, 18 + lane, LD_X6)] = ori[lane]; }
+        if (lane < 18) { x4l[rc_pk(row, lane, LD_X4)] = acc_l; x6l[rc_pk(row, lane, LD_X6)] = acc_l; }
+        if (lane < 54) { x4l[rc_pk(row, 18 + lane, LD_X4)] = ori_l; x6l[rc_pk(row, 18 + lane, LD_X6)] = ori_l; }
         float x = 0.f, y = 0.f, z1 = 0.f;
         if (lane < 33) {
             const float z = s.J33[lane][2];
@@ -443,7 +518,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
             fb.c2[fb.c2_layer_stride + row * 512 + e] = src[1536 + e];
         }
     }
-    if (has_next) prep_body(fb, io_next, prm, row, lane, 0, pend_next, uvc_next);
+    if (has_next) prep_compute(fb, nin, prm, row, lane, 0, pend_next, uvc_next);
 }
 
 // ================================================================================================== reset

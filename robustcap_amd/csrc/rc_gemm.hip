@@ -145,23 +145,24 @@ __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const
         for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
 }
 
-// a = hi + mid + lo exactly; each output packs 8 bf16 (element e in the low / high half of dword e / 2)
+// a = hi + mid + lo exactly; each output packs 8 bf16 (element e in the low / high half of dword e / 2).
+// Two elements per step on float2 values: the two subtractions of a pair compile to one v_pk_add_f32 each (9 VALU ops per
+// pair instead of 11: the K loop issues its VALU work beside the MFMAs at 2-3 cycles per instruction).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, u32x4& h, u32x4& m, u32x4& l) {
-    float a[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    unsigned ua[8], um[8], ul[8];
+    const f32x2 a[4] = {f32x2{x0[0], x0[1]}, f32x2{x0[2], x0[3]}, f32x2{x1[0], x1[1]}, f32x2{x1[2], x1[3]}};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        ua[e] = __float_as_uint(a[e]);
-        const float r1 = a[e] - __uint_as_float(ua[e] & 0xffff0000u);
-        um[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(um[e] & 0xffff0000u);
-        ul[e] = __float_as_uint(r2);
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {   // bytes {hi[3], hi[2], lo[3], lo[2]} of the pair = the two truncated bf16
-        h[d] = __builtin_amdgcn_perm(ua[2 * d + 1], ua[2 * d], 0x07060302u);
-        m[d] = __builtin_amdgcn_perm(um[2 * d + 1], um[2 * d], 0x07060302u);
-        l[d] = __builtin_amdgcn_perm(ul[2 * d + 1], ul[2 * d], 0x07060302u);
+    for (int d = 0; d < 4; ++d) {
+        const u32x2 ua = __builtin_bit_cast(u32x2, a[d]);
+        const f32x2 r1 = a[d] - __builtin_bit_cast(f32x2, ua & 0xffff0000u);          // a - hi, exact
+        const u32x2 um = __builtin_bit_cast(u32x2, r1);
+        const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, um & 0xffff0000u);            // a - hi - mid, exact
+        const u32x2 ul = __builtin_bit_cast(u32x2, r2);
+        // bytes {hi[3], hi[2], lo[3], lo[2]} of the pair = the two truncated bf16
+        h[d] = __builtin_amdgcn_perm(ua[1], ua[0], 0x07060302u);
+        m[d] = __builtin_amdgcn_perm(um[1], um[0], 0x07060302u);
+        l[d] = __builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u);
     }
 }
 

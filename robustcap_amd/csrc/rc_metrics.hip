@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void rc_metrics_frame_kernel(const BodyConst* _
                                                               const float* __restrict__ pose_p, const float* __restrict__ pose_t,
                                                               float* __restrict__ xf, float* __restrict__ out) {
     __shared__ WaveScratch sp, st;
-    __shared__ BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     __shared__ float kp[MET_MAXK][3], kt[MET_MAXK][3];
     const long long b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void rc_metrics_pve_kernel(const BodyConst* __
         for (int q = 0; q < MET_VPT; ++q)
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[q][k] = 0.0f;
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < 24; ++j) {
             float xj[12];
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ void rc_metrics_finish_kernel(const float* __restrict__ part, int n_s
 __global__ __launch_bounds__(64) void rc_mesh_frame_kernel(const BodyConst* __restrict__ body_g, const float* __restrict__ pose,
                                                            float* __restrict__ xf) {
     __shared__ WaveScratch s;
-    __shared__ BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     const long long b = blockIdx.x;
     const int lane = threadIdx.x;
     stage_body(&s_body, body_g, lane, 64);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void rc_body_mesh_sweep_kernel(const BodyConst
         for (int q = 0; q < MET_VPT; ++q)
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[q][k] = 0.0f;
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < 24; ++j) {
             float xj[12];
 #pragma unroll

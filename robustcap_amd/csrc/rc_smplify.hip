@@ -79,7 +79,7 @@ __device__ __forceinline__ void frame_primal(const BodyConst* body, WaveScratch&
 // ============================================================================================== forward pass
 __global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
     __shared__ WaveScratch s;
-    __shared__ BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     __shared__ float s_d[SM_DIM];
     const int t = blockIdx.x, lane = threadIdx.x;
     stage_body(&s_body, body_g, lane, 64);
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const
 
 __global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
     __shared__ WaveScratch s;
-    __shared__ BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     __shared__ float s_lam[33][3];
     __shared__ float s_M[24][9], s_m[24][3], s_o[24][3];
     __shared__ float s_dG[24 * 9 * TAN_LD], s_dP[24 * 3 * TAN_LD];

@@ -133,15 +133,11 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
     default for the TOTAL number of rows of the run, not for this rank's shard, so a row's result does not depend on
     the number of ranks (``Net.default_gemm_mode``)."""
     all_rows = rows_of(dataset) if rows is None else list(rows)
-    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    a, b = rdist.shard_range(len(all_rows), rank, world)
-    mine = all_rows[a:b]
     Tmax = max(len(dataset["pose"][i]) for i, _ in all_rows)
-    n = len(mine)
-    out_p = torch.zeros(max(n, 1), Tmax, 24, 3, 3, device=device)
-    out_t = torch.zeros(max(n, 1), Tmax, 3, device=device)
-    if n:
+    split = Net.default_gemm_mode(len(all_rows)) if gemm_mode is None else bool(gemm_mode)
+
+    def compute(mine):
+        n = len(mine)
         j2d, acc, ori, grav = camera_inputs_rows(dataset, mine, Tmax, image_size=image_size, device=device)
         ft = first_translations(dataset, mine)
         hit = None if nets is None else nets.get(n)
@@ -153,25 +149,45 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
                 nets[n] = (net, state_dict)
         else:
             net.reset_states()
-        net.set_gemm_mode(Net.default_gemm_mode(len(all_rows)) if gemm_mode is None else gemm_mode)
+        net.set_gemm_mode(split)
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)
         if run_smplify:
             _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, smplify_workers)
-    if world > 1:                                                       # the path's only collective
+        return out_p, out_t
+
+    rows_out, out_p, out_t = shard_rows(all_rows, Tmax, compute, device=device)
+    res = {}
+    for r, (i, j) in enumerate(rows_out):
+        T = len(dataset["pose"][i])
+        res[(i, j)] = (out_p[r, :T], out_t[r, :T])
+    return res
+
+
+def shard_rows(all_rows, Tmax, compute, device="cuda"):
+    """The multi-GPU shape of an evaluation (BASELINE config 3): contiguous blocks of the (sequence, camera) rows per rank
+    (``dist.shard_range``), ``compute(rows of this rank) -> (pose [n,Tmax,24,3,3], tran [n,Tmax,3])`` on this rank's
+    device, and ONE gather of the outputs -- the path's only collective (RCCL over xGMI; gloo on CPU hosts). A rank whose
+    block is empty (fewer rows than ranks) computes nothing and still joins the gather. Returns (rows in output order,
+    pose, tran) on the CPU: all rows on every rank when distributed, else this process's rows."""
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    a, b = rdist.shard_range(len(all_rows), rank, world)
+    mine = all_rows[a:b]
+    n = len(mine)
+    if n:
+        out_p, out_t = compute(mine)
+    else:
+        out_p, out_t = torch.zeros(0, Tmax, 24, 3, 3, device=device), torch.zeros(0, Tmax, 3, device=device)
+    if world > 1:
         # explicit widths: a rank whose shard is empty (rows < world) must still reach the collective
         cap_p = rdist.gather_rows(out_p[:n].reshape(n, Tmax * 216), len(all_rows))
         cap_t = rdist.gather_rows(out_t[:n].reshape(n, Tmax * 3), len(all_rows))
         out_p, out_t, rows_out = cap_p.view(-1, Tmax, 24, 3, 3), cap_t.view(-1, Tmax, 3), all_rows
     else:
         rows_out = mine
-    out_p, out_t = out_p.cpu(), out_t.cpu()                             # one D2H for everything
-    res = {}
-    for r, (i, j) in enumerate(rows_out):
-        T = len(dataset["pose"][i])
-        res[(i, j)] = (out_p[r, :T], out_t[r, :T])
-    return res
+    return rows_out, out_p.cpu(), out_t.cpu()                           # one D2H for everything
 
 
 def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, workers):

@@ -149,9 +149,18 @@ def test_shaped_body_vs_reference_vectors(ops, synth_assets):
     assert maxdiff(J, ops["fk_joint"]) > 1e-3                                              # the shape really moved the joints
     G0, J0, L0 = model.forward_kinematics(t(ops["fk_pose"]), tran=t(ops["fk_tran"]), calc_mesh=True)   # shape=None: mean body again
     assert maxdiff(J0, ops["fk_joint"]) <= 2e-6 and maxdiff(L0, ops["fk_j33"]) <= 2e-6
-    with pytest.raises(NotImplementedError):
-        two = torch.stack([beta, beta + 0.1])
-        model.forward_kinematics(t(ops["fk_pose"][:2]), shape=two)
+    # per-row shapes (model.py:209-229 takes [batch, 10]): frames of different subjects in one call -- here shaped and mean
+    # (beta = 0) frames interleaved: every frame must equal its own single-shape run
+    rows = torch.zeros(N, 10)
+    rows[::2] = beta
+    Gm, Jm, Lm = model.forward_kinematics(t(ops["fk_pose"]), shape=rows, tran=t(ops["fk_tran"]), calc_mesh=True)
+    assert torch.equal(Jm[::2], J[::2]) and torch.equal(Lm[::2], L[::2]) and torch.equal(Gm, G)
+    assert maxdiff(Jm[1::2], ops["fk_joint"][1::2]) <= 2e-6 and maxdiff(Lm[1::2], ops["fk_j33"][1::2]) <= 2e-6
+    jz, vz = model.get_zero_pose_joint_and_vertex(rows[:3])
+    assert jz.shape == (3, 24, 3) and vz.shape[0] == 3 and torch.equal(jz[0], j0) and torch.equal(jz[2], j0)
+    assert maxdiff(jz[1], model.get_zero_pose_joint_and_vertex()[0]) <= 1e-6             # beta = 0 is the mean shape
+    with pytest.raises(ValueError):
+        model.forward_kinematics(t(ops["fk_pose"][:3]), shape=rows[:2])                   # neither one row nor one per frame
 
 
 def test_body_fk_landmarks(ops, pm):

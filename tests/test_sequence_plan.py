@@ -1,67 +1,46 @@
-"""Launch planner of rc_sequence (host logic of librobustcap_hip.so, no GPU): which frames may run on the wavefront
-engine, which frame-stepped frames need the three transition launches. Reference semantics: the vision updater fires
-at c <= lo (net/sig_mp.py:264-271), init_net once at the first c >= hi frame (L178-183)."""
+"""Frame-stepped launch planner of rc_sequence (host logic of librobustcap_hip.so, no GPU): which frames need the three
+transition launches. Reference semantics: the vision updater fires at c <= lo (net/sig_mp.py:264-271); its two sub-net
+steps are deferred to the next frame and need their own launches only when the row steps on camera keypoints there
+(c > lo, or first_frame: L149-156). (The wavefront engine's planner is tests/test_wave_plan.py.)"""
 import ctypes as C
 
 import numpy as np
-import pytest
 
 from robustcap_amd import _lib
 
-STEP_TR, STEP, WAVE = 0, 1, 2
+STEP_TR, STEP = 0, 1
 
 
-def plan(codes, first_reach=None, pend=None, first_frame=False, first_tran=False, imu=True, vis=True, min_frames=4):
+def plan(codes, pend=None, first_frame=False, vis=True):
     lib = _lib.load()
     codes = np.ascontiguousarray(np.asarray(codes, np.int8))
     T, B = codes.shape
-    fr = np.ascontiguousarray(np.ones(B, np.int32) if first_reach is None else np.asarray(first_reach, np.int32))
     pd = np.ascontiguousarray(np.zeros(B, np.int32) if pend is None else np.asarray(pend, np.int32))
     out = np.full(T, 255, np.uint8)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = lib.rc_plan_sequence(p(codes), B, T, p(fr), p(pd), 1 if first_frame else 0, int(first_tran), int(imu), int(vis), min_frames, p(out))
+    rc = lib.rc_plan_sequence(p(codes), B, T, p(pd), 1 if first_frame else 0, int(vis), p(out))
     assert rc == 0
     return out.tolist()
 
 
-def test_all_high_after_the_reach_frame_is_one_wave_segment():
-    codes = np.full((12, 3), 2)
-    assert plan(codes) == [STEP] + [WAVE] * 11                           # frame 0: every row fires init_net
-    assert plan(codes, first_reach=[0, 0, 0]) == [WAVE] * 12
-    assert plan(codes, first_reach=[0, 0, 0], first_tran=True) == [STEP] + [WAVE] * 11
-    assert plan(codes, first_reach=[0, 0, 0], first_frame=True) == [STEP] + [WAVE] * 11
-    assert plan(codes, imu=False) == [WAVE] * 12                        # use_imu_updater off: no reach event at all
+def test_visible_rows_never_need_transition_launches():
+    assert plan(np.full((12, 3), 2)) == [STEP] * 12
+    assert plan(np.full((12, 3), 1), first_frame=True) == [STEP] * 12
 
 
-def test_mid_frames_ride_along_and_late_reach_splits_the_segment():
-    codes = np.full((14, 2), 1)
-    codes[6:, 1] = 2                                                     # row 1 first reaches c >= hi at frame 6
-    assert plan(codes) == [WAVE] * 6 + [STEP] + [WAVE] * 7
-    codes[6:, 0] = 2                                                     # both rows reach at frame 6: still one stepped frame
-    assert plan(codes) == [WAVE] * 6 + [STEP] + [WAVE] * 7
-
-
-def test_occlusion_forces_stepped_frames_and_marks_transitions():
+def test_occlusion_marks_the_frame_after_it():
     codes = np.full((16, 2), 2)
     codes[5:8, 0] = 0                                                    # row 0 occluded on frames 5..7
-    got = plan(codes, first_reach=[0, 0])
-    # frames 5..7: not all visible; frame 8: row 0 carries a pending updater step INTO a visible frame -> transition
-    assert got == [WAVE] * 5 + [STEP, STEP, STEP, STEP_TR] + [WAVE] * 7
-    assert plan(codes, first_reach=[0, 0], vis=False) == [WAVE] * 5 + [STEP] * 3 + [WAVE] * 8   # no updater -> nothing pends
+    # frame 8: row 0 carries a pending updater step INTO a visible frame -> transition launches
+    assert plan(codes) == [STEP] * 8 + [STEP_TR] + [STEP] * 7
+    assert plan(codes, vis=False) == [STEP] * 16                         # no updater -> nothing pends
     # pending state carried in from the previous call
-    assert plan(np.full((6, 2), 2), first_reach=[0, 0], pend=[1, 0]) == [STEP_TR] + [WAVE] * 5
+    assert plan(np.full((6, 2), 2), pend=[1, 0]) == [STEP_TR] + [STEP] * 5
     # an occluded row with a pending step and no camera step: merged launch, no transition
     codes = np.zeros((3, 1))
-    assert plan(codes, first_reach=[0], pend=[1]) == [STEP, STEP, STEP]
-    assert plan(codes, first_reach=[0], pend=[1], first_frame=True) == [STEP_TR, STEP, STEP]      # first_frame steps rnn4 anyway
-
-
-def test_short_stretches_stay_frame_stepped():
-    codes = np.full((9, 1), 2)
-    codes[4, 0] = 0
-    assert plan(codes, first_reach=[0], min_frames=5) == [STEP] * 5 + [STEP_TR] + [STEP] * 3
-    assert plan(codes, first_reach=[0], min_frames=4) == [WAVE] * 4 + [STEP] + [STEP_TR] + [STEP] * 3
-    assert plan(np.zeros((0, 1)), min_frames=1) == []
+    assert plan(codes, pend=[1]) == [STEP, STEP, STEP]
+    assert plan(codes, pend=[1], first_frame=True) == [STEP_TR, STEP, STEP]      # first_frame steps rnn4 anyway
+    assert plan(np.zeros((0, 1))) == []
 
 
 def test_random_plans_respect_the_invariants():
@@ -69,18 +48,10 @@ def test_random_plans_respect_the_invariants():
     for _ in range(50):
         T, B = int(rng.integers(1, 60)), int(rng.integers(1, 6))
         codes = rng.choice([0, 1, 2], size=(T, B), p=[0.15, 0.25, 0.6])
-        fr, pd = rng.integers(0, 2, B), rng.integers(0, 2, B)
-        got = plan(codes, first_reach=fr, pend=pd, min_frames=3)
-        pend, first = pd.copy(), fr.copy()
+        pd = rng.integers(0, 2, B)
+        got = plan(codes, pend=pd)
+        pend = pd.copy()
         for t in range(T):
-            reach = bool(((first == 1) & (codes[t] == 2)).any())
             need_tr = bool(((pend == 1) & (codes[t] >= 1)).any())
-            if got[t] == WAVE:
-                assert (codes[t] >= 1).all() and not reach and not pend.any()
-            else:
-                assert got[t] == (STEP_TR if need_tr else STEP)
-            first = np.where(codes[t] == 2, 0, first)
+            assert got[t] == (STEP_TR if need_tr else STEP)
             pend = (codes[t] == 0).astype(int)
-        runs = "".join(str(m) for m in got).split("0")
-        for seg in "".join("w" if m == WAVE else "." for m in got).split("."):
-            assert len(seg) == 0 or len(seg) >= 3

@@ -14,8 +14,8 @@ import pytest
 from robustcap_amd import _lib
 
 # stage of every (net, launch kind) of a frame: linear1, LSTM l0, LSTM l1, linear2 (rc_api.cpp: kTick)
-FIRST = {"rnn2": 1, "rnn4": 1, "rnn6": 6, "rnn3": 6, "rnn7": 6, "rnn8": 6}
-FUSE, TAIL, RING = 5, 10, 16
+FIRST = {"rnn2": 1, "rnn4": 1, "rnn6": 5, "rnn3": 5, "rnn7": 5, "rnn8": 5}
+FUSE, TAIL, RING = 4, 8, 16                                             # fuse / tail follow linear2 within stage 4 / 8
 
 
 def plan(codes, t0=0, first_reach=None, pend=None, imu=True, vis=True):
@@ -115,7 +115,7 @@ def test_all_visible_rows_never_wait():
     fa, nt, cnt, est = plan(codes, first_reach=[0, 0, 0])
     assert fa.shape[0] == 12 and nt == 12 + TAIL and (fa == np.arange(12)[:, None]).all()
     replay(codes, fa, nt, cnt, 0, [0, 0, 0], [0, 0, 0])
-    # init_net on frame 0 of every row: frame 1 starts once the tail has written rnn2's state (stage 10 -> tick 9 + l0 at +2)
+    # init_net on frame 0 of every row: frame 1 starts once the tail has written rnn2's state (tail at tick 8, l0 = stage 2)
     fa, nt, cnt, _ = plan(codes)
     assert (fa[0] == 0).all() and (fa[1:TAIL - 1] == -1).all() and (fa[TAIL - 1] == 1).all()
     replay(codes, fa, nt, cnt, 0, [1, 1, 1], [0, 0, 0])
@@ -123,7 +123,7 @@ def test_all_visible_rows_never_wait():
     assert nt2 == 12 + TAIL
 
 
-def test_an_occlusion_costs_the_row_ten_ticks_once():
+def test_an_occlusion_costs_the_row_the_pipeline_depth_once():
     codes = np.full((30, 2), 2)
     codes[5:9, 0] = 0                                                    # row 0 occluded on frames 5..8
     fa, nt, cnt, _ = plan(codes, first_reach=[0, 0])
@@ -131,7 +131,7 @@ def test_an_occlusion_costs_the_row_ten_ticks_once():
     assert (e[1] == np.arange(30)).all()                                 # row 1 is never held up by row 0
     assert (e[0, :9] == np.arange(9)).all()                              # occluded frames follow each other tick by tick
     assert e[0, 9] == e[0, 8] + TAIL + 1 and (np.diff(e[0, 9:]) == 1).all()
-    assert nt == 29 + 10 + TAIL + 1
+    assert nt == 29 + TAIL + TAIL + 1
     # updater switched off: nothing to wait for
     fa, nt, cnt, _ = plan(codes, first_reach=[0, 0], vis=False)
     assert nt == 30 + TAIL
@@ -147,8 +147,8 @@ def test_pending_step_from_before_the_segment_rides_slot_zero():
     fa, nt, cnt, _ = plan(codes, first_reach=[0], pend=[1])
     assert fa[:4, 0].tolist() == [0, 1, 2, 3]                            # an occluded frame shares the slot with the rider
     replay(codes, fa, nt, cnt, 0, [0], [1])
-    # the last frame's updater stays pending: riders of frames 0..2 only, the last at tick 2 + 10 -> rnn6 l1 at + 8
-    assert nt == 2 + TAIL + 8 + 1
+    # the last frame's updater stays pending: riders of frames 0..2 only, the last at tick 2 + TAIL -> rnn6 l1 at + 7
+    assert nt == 2 + TAIL + FIRST["rnn6"] + 2 + 1
 
 
 def test_segment_after_a_frame_stepped_first_frame():
