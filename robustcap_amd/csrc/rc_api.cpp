@@ -372,7 +372,11 @@ GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     return p;
 }
 
-int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st, bool fp32 = false) {
+// stop: event to be signalled by this launch's completion (used only when the launch is not being timed); *launched tells the
+// caller whether a kernel went out at all
+int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st, bool fp32 = false,
+                    hipEvent_t stop = nullptr, bool* launched = nullptr) {
+    if (launched) *launched = false;
     if (ps.empty()) return RC_OK;
     GemmLaunch L{};
     L.B = ctx->B;
@@ -405,7 +409,8 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
         rc_launch_gemm(L, base, st);
         HIP_TRY(ctx, hipEventRecord(ev.second, st));
     } else {
-        rc_launch_gemm(L, base, st);
+        rc_launch_gemm(L, base, st, stop);
+        if (launched && stop) *launched = true;
     }
     HIP_TRY(ctx, hipGetLastError());
     return RC_OK;
@@ -712,7 +717,14 @@ int build_wave2_problems(rc_ctx* ctx) {
 
 // stage and launch group of the problems beyond kTick (init_net layers: beside linear1 / LSTM l0 / l1 of the second half)
 inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : kInitStage + (q - W2_INIT0); }
-inline int w2_group(int q) { return q < RC_TICK_PROB ? kTick[q].group : 2; }
+// merge_h512: the H = 512 nets' eight layer steps and the six linear1 share ONE launch (512 equal 64 x 128 tiles = two rounds, then
+// the linear1 tiles) instead of two launches of one round each; init_net then rides with rnn6
+// merge_big (experiment): rnn6's and rnn4's layer steps share one launch as well (rnn6's longer tiles first)
+inline int w2_group(int q, bool merge_h512, bool merge_big) {
+    int g = q >= RC_TICK_PROB ? (merge_h512 ? 1 : 2) : ((merge_h512 && kTick[q].group == 3) ? 2 : kTick[q].group);
+    if (merge_big && g == 1) g = 0;
+    return g;
+}
 
 int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0, int t_last, hipStream_t st) {
     if (int rc = ensure_wave2_buffers(ctx)) return rc;
@@ -740,11 +752,18 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
+    static const bool narrow_fill = tune_env("RC_SEQ_NARROW_FILL", 1) != 0;
+    static const bool lin1_wide = tune_env("RC_SEQ_LIN1_WIDE", 1) != 0;
+    static const bool merge_h512 = tune_env("RC_SEQ_MERGE_H512", 1) != 0;
+    static const bool merge_big = tune_env("RC_SEQ_MERGE_BIG", 0) != 0;
+    const int last_group = merge_h512 ? 2 : 3;
     auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
-    auto group = [&](int k, int g, hipStream_t s) -> int {                  // launch the problems of group g that have rows at tick k
+    static const bool ext_events = tune_env("RC_SEQ_EXT_EVENTS", 1) != 0;   // tick hand-over events carried by the last dispatch itself (+0.5 %)
+    auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {   // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
-        for (int q = 0; q < W2_PROB; ++q) {
-            if (w2_group(q) != g) continue;
+        for (int qi = 0; qi < W2_PROB; ++qi) {
+            const int q = (merge_big && qi < 4) ? (qi ^ 2) : qi;               // rnn6 (kTick 2, 3) in front of rnn4 (0, 1): longest tiles first
+            if (w2_group(q, merge_h512, merge_big) != g) continue;
             const int e = k - w2_stage(q);
             if (e < 0 || e >= P.n_prep) continue;
             const int net = q < RC_TICK_PROB ? kTick[q].net : -1;
@@ -765,6 +784,12 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
                 p.mr = mr; p.nc = nc; p.n_tiles = n.H / (4 * nc);
             } else if (kind == 0 || kind == 4) {
                 if (rows <= 16) { p.mr = 1; p.nc = 1; p.n_tiles = (p.N + 15) / 16; }
+                else if (kind == 0 && lin1_wide && B >= RC_SPLIT_MIN_BATCH && rows >= 128) {
+                    // linear1 rides in the last wide launch behind its 256 LSTM tiles: as 544 tiles of 32 x 64 (K = 128 / 256: two
+                    // k-blocks, i.e. all prologue and epilogue) it added two rounds, ~18 us of a 245 us tick; 136 tiles of 64 x 128 add one
+                    const int np = round_up(p.N, 64);
+                    if (np % 128 == 0) { p.mr = 4; p.nc = 8; p.n_tiles = np / 128; }
+                }
             }
             p.m_tiles = (rows + 16 * p.mr - 1) / (16 * p.mr);
             if (rows == B && kind != 4) {                                      // every row: no compaction needed
@@ -775,7 +800,16 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             }
             ps.push_back(p);
         }
-        return launch_problems(ctx, ps, nullptr, s, g == 5);               // linear2 on the fp32-input kernel, as in run_stage
+        // Filling and draining ticks (and ticks of lagging rows) carry fewer problems per launch: when the launch would leave
+        // half of the CUs without a tile, the 64 x 128 tiles are cut to 64 x 64 (twice the tiles, half as long each).
+        if (g < 4 && narrow_fill) {
+            int total = 0;
+            for (const GemmProblem& p : ps) total += p.n_tiles * p.m_tiles;
+            if (total > 0 && total <= 128)
+                for (GemmProblem& p : ps)
+                    if (p.epi == RC_EPI_LSTM && p.mr == 4 && p.nc == 8) { p.nc = 4; p.n_tiles *= 2; }
+        }
+        return launch_problems(ctx, ps, nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
     };
     WavePrep wp{};
     for (int i = 0; i < 6; ++i) wp.steps[i] = ctx->net[i].steps;
@@ -797,17 +831,20 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         }
         if (int rc = group(k, 5, aux)) return rc;                               // linear2 of stages 4 and 8 ...
         if (cnt(P.n_valid, k - kFuseStage) > 0) rc_launch_fuse(ctx->ring2[(k - kFuseStage) % kRing], io0, prm, B, aux);   // ... then their consumers
+        bool aux_signalled = false;
         if (cnt(P.n_valid, k - kTailStage) > 0) {
             const FrameBuffers& tgt = ctx->ring2[k % kRing];
             wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
-            rc_launch_tail(ctx->ring2[(k - kTailStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt);
+            aux_signalled = two && ext_events;
+            rc_launch_tail(ctx->ring2[(k - kTailStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt, aux_signalled ? ctx->ev_aux[e] : nullptr);
         }
-        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
+        if (two && !aux_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
         // ---- the GEMM stages of tick k (caller's stream: after the previous tick's second-stream work)
         if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-        for (int g = 0; g < 4; ++g)
-            if (int rc = group(k, g, st)) return rc;
-        if (two) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
+        bool main_signalled = false;
+        for (int g = 0; g <= last_group; ++g)
+            if (int rc = group(k, g, st, (g == last_group && two && ext_events) ? ctx->ev_main[e] : nullptr, g == last_group ? &main_signalled : nullptr)) return rc;
+        if (two && !main_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
         ctx->stat_ticks += 1;
     }
     if (two && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(P.n_ticks - 1) & 3], 0));

@@ -11,6 +11,7 @@
 // the 219-float output row and ~3 KB of padded sub-net input rows -- these kernels are latency-, not
 // bandwidth-bound, which is why they are kept to three launches.
 #include "rc_internal.h"
+#include <hip/hip_ext.h>
 
 #define LD_X2 128
 #define LD_X3 256
@@ -821,9 +822,13 @@ void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
     hipLaunchKernelGGL(rc_fuse_kernel, dim3((B * 24 + 255) / 256), dim3(256), 0, st, fb, io, prm, B);
 }
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
-                    int first_frame, hipStream_t st, const FrameIO* io_next, const WaveTail* wt) {
-    hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0,
-                       wt ? *wt : WaveTail{});
+                    int first_frame, hipStream_t st, const FrameIO* io_next, const WaveTail* wt, hipEvent_t stop) {
+    if (stop)
+        hipExtLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, nullptr, stop, 0, fb, io, prm, body, B, first_frame, io_next ? *io_next : io,
+                              io_next ? 1 : 0, wt ? *wt : WaveTail{});
+    else
+        hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0,
+                           wt ? *wt : WaveTail{});
 }
 void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t st) {
     hipLaunchKernelGGL(rc_prep_wave_kernel, dim3(B), dim3(64), 0, st, slot, io0, prm, B, w);

@@ -17,6 +17,7 @@
 // Row selection is stateless: every workgroup derives the compacted list of active rows from the per-row flag
 // bytes itself (one ballot per wave), so masked sub-steps (vision branch on/off) cost only the rows they touch.
 #include "rc_internal.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -646,19 +647,22 @@ bool rc_gemm_is_mid(const GemmLaunch& L) {
     return mid;
 }
 
-void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s) {
+// stop: optional event signalled by THIS dispatch's completion (hipExtLaunchKernelGGL: no separate marker packet in the queue)
+void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop) {
     const dim3 g(total_wg), b(RC_NW * 64);
+#define RC_GO(K) do { if (stop) hipExtLaunchKernelGGL(K, g, b, 0, s, nullptr, stop, 0, L); else hipLaunchKernelGGL(K, g, b, 0, s, L); } while (0)
     if (rc_gemm_is_small(L)) {
         bool single_reader = L.live != 0;      // a live frame's launch (rc_api.cpp: launch_problems)
         for (int q = 0; q < L.n; ++q) single_reader = single_reader && L.p[q].m_tiles == 1;
-        if (L.split) hipLaunchKernelGGL(rc_gemm_small_split_kernel, g, b, 0, s, L);
-        else if (single_reader) hipLaunchKernelGGL(rc_gemm_small_nt_kernel, g, b, 0, s, L);
-        else hipLaunchKernelGGL(rc_gemm_small_kernel, g, b, 0, s, L);
+        if (L.split) RC_GO(rc_gemm_small_split_kernel);
+        else if (single_reader) RC_GO(rc_gemm_small_nt_kernel);
+        else RC_GO(rc_gemm_small_kernel);
     } else if (rc_gemm_is_mid(L)) {
-        if (L.split) hipLaunchKernelGGL(rc_gemm_mid_split_kernel, g, b, 0, s, L);
-        else hipLaunchKernelGGL(rc_gemm_mid_kernel, g, b, 0, s, L);
+        if (L.split) RC_GO(rc_gemm_mid_split_kernel);
+        else RC_GO(rc_gemm_mid_kernel);
     } else {
-        if (L.split) hipLaunchKernelGGL(rc_gemm_split_kernel, g, b, 0, s, L);
-        else hipLaunchKernelGGL(rc_gemm_kernel, g, b, 0, s, L);
+        if (L.split) RC_GO(rc_gemm_split_kernel);
+        else RC_GO(rc_gemm_kernel);
     }
+#undef RC_GO
 }

@@ -14,7 +14,7 @@
 #endif
 #define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
 #define RC_KALIGN 128     // padded K granularity (>= 2 * RC_KC * RC_NW: an even number of chunks per wave)
-#define RC_MAX_PROB 12    // problems fused in one launch (GemmLaunch travels as a kernel argument: 12 x 224 B)
+#define RC_MAX_PROB 14    // problems fused in one launch (GemmLaunch travels as a kernel argument: 14 x 232 B = 3.2 KB; no scratch copy: checked in the ISA)
 
 // Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
 // wave's A load is one contiguous 1 KiB piece, exactly like the packed weights: for 16-row block row / 16 and
@@ -160,7 +160,7 @@ struct rc_params_dev {
     float smooth;
 };
 
-void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s);
+void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);
 void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t s);
 bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_gemm_small_kernel (16-row tiles only)
@@ -168,7 +168,7 @@ void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
                     int first_frame, hipStream_t s, const FrameIO* io_next = nullptr,    // io_next: also the next frame's prep
-                    const WaveTail* wt = nullptr);
+                    const WaveTail* wt = nullptr, hipEvent_t stop = nullptr);   // stop: event signalled by this dispatch
 void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t s);
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
@@ -238,6 +238,14 @@ struct SmplifyArgs {
     int T;
 };
 void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t s);
+// vector kernels of the device-resident L-BFGS (rc_smplify.hip)
+#define RC_LBFGS_MAX_PAIRS 32
+struct VecComb { const float* v[2 * RC_LBFGS_MAX_PAIRS + 1]; float c[2 * RC_LBFGS_MAX_PAIRS + 1]; int n_vec; };
+struct VecJob { const float* a; const float* b; int op; int pad_; };     // op 0: sum a b, 1: max |a|, 2: sum |a|
+void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t s);
+void rc_launch_vec_pair(const float* g_new, const float* g_old, const float* d, float t, float* y, float* sv, long long n, hipStream_t s);
+void rc_launch_vec_comb(const VecComb& c, float* out, long long n, hipStream_t s);
+void rc_launch_vec_dots(const VecJob* jobs_dev, int n_jobs, long long n, double* partial, hipStream_t s);
 
 // narrow view of the context for rc_smplify_api.cpp (the struct itself lives in rc_api.cpp)
 struct rc_ctx;

@@ -316,3 +316,70 @@ void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t 
     hipLaunchKernelGGL(rc_smplify_fwd_kernel, dim3(A.T), dim3(64), 0, st, A, body);
     hipLaunchKernelGGL(rc_smplify_grad_kernel, dim3(A.T), dim3(128), 0, st, A, body);
 }
+
+// ================================================================= vector kernels of the device-resident L-BFGS
+// (rc_smplify_api.cpp: minimize_on_device). The optimiser's vectors -- parameters, gradients of the bracket points, the
+// curvature pairs -- never leave the device; what the host reads back per step is a handful of inner products.
+__global__ void rc_vec_axpy_kernel(const float* x, const float* __restrict__ d, float t, float* out, long long n) {   // out may be x
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] + t * d[i];
+}
+// curvature pair of an iteration: y = g_new - g_old, s = t d  (torch.optim.LBFGS: y = flat_grad.sub(prev_flat_grad), s = d.mul(t))
+__global__ void rc_vec_pair_kernel(const float* __restrict__ g_new, const float* __restrict__ g_old, const float* __restrict__ d, float t,
+                                   float* __restrict__ y, float* __restrict__ s, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { y[i] = g_new[i] - g_old[i]; s[i] = d[i] * t; }
+}
+// out = sum_k c[k] v[k]  (the search direction as a combination of the curvature pairs and the gradient)
+__global__ void rc_vec_comb_kernel(VecComb c, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int k = 0; k < c.n_vec; ++k) acc += c.c[k] * c.v[k][i];
+    out[i] = acc;
+}
+// partial[job][block] of job (a, b, op): op 0 sum a_i b_i, 1 max |a_i|, 2 sum |a_i| -- float64 accumulation, one partial per
+// 4,096-element block; the host adds the partials of a job in block order (deterministic).
+__global__ __launch_bounds__(256) void rc_vec_dots_kernel(const VecJob* __restrict__ jobs, long long n, int n_blocks, double* __restrict__ partial) {
+    __shared__ double s_red[4];
+    const VecJob jb = jobs[blockIdx.y];
+    const long long lo = (long long)blockIdx.x * 4096;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int q = 0; q < 16; ++q) {
+        const long long i = lo + q * 256 + threadIdx.x;
+        if (i < n) {
+            const double a = jb.a[i];
+            if (jb.op == 0) acc += a * (double)jb.b[i];
+            else if (jb.op == 1) acc = fmax(acc, fabs(a));
+            else acc += fabs(a);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(acc, off);
+        acc = jb.op == 1 ? fmax(acc, o) : acc + o;
+    }
+    if (lane == 0) s_red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = s_red[0];
+        for (int w = 1; w < 4; ++w) r = jb.op == 1 ? fmax(r, s_red[w]) : r + s_red[w];
+        partial[(long long)blockIdx.y * n_blocks + blockIdx.x] = r;
+    }
+}
+
+void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_vec_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d, t, out, n);
+}
+void rc_launch_vec_pair(const float* g_new, const float* g_old, const float* d, float t, float* y, float* s, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_vec_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_new, g_old, d, t, y, s, n);
+}
+void rc_launch_vec_comb(const VecComb& c, float* out, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(rc_vec_comb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, out, n);
+}
+void rc_launch_vec_dots(const VecJob* jobs_dev, int n_jobs, long long n, double* partial, hipStream_t st) {
+    if (n_jobs <= 0) return;
+    const int nb = (int)((n + 4095) / 4096);
+    hipLaunchKernelGGL(rc_vec_dots_kernel, dim3((unsigned)nb, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, n, nb, partial);
+}

@@ -9,7 +9,9 @@
 #include "rc_internal.h"
 #include "rc_lbfgs.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,10 +28,18 @@ struct SmplifyState {
     float *h_x = nullptr, *h_grad = nullptr, *h_terms = nullptr, *h_res = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double device_ms = 0.0;
+    // device-resident L-BFGS (minimize_on_device): vectors of the optimiser, job table and partial sums of the inner products
+    int64_t lb_cap = 0;                                               // frames the buffers below hold
+    int lb_pairs = 0;                                                 // curvature pairs they hold
+    float *xt = nullptr, *dir = nullptr, *gslot = nullptr, *Sv = nullptr, *Yv = nullptr;   // [n], [n], [6][n], [pairs][n] x 2
+    VecJob *jobs_d = nullptr, *jobs_h = nullptr;                      // device / pinned
+    double *part_d = nullptr, *part_h = nullptr;
     const float* ref3d_override = nullptr;                            // rc_smplify_set_ref3d: caller-owned [T,33,3], next run only
 };
 
 namespace {
+
+typedef float (*cubic_fn)(float, float, float, float, float, float, bool, float, float);
 
 #define SM_TRY(ctx, expr)                                                                                   \
     do {                                                                                                    \
@@ -44,6 +54,13 @@ void free_work(SmplifyState* s) {
     for (float** p : {&s->h_x, &s->h_grad, &s->h_terms, &s->h_res})
         if (*p) { (void)hipHostFree(*p); *p = nullptr; }
     s->cap = 0;
+    for (float** p : {&s->xt, &s->dir, &s->gslot, &s->Sv, &s->Yv})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (s->jobs_d) { (void)hipFree(s->jobs_d); s->jobs_d = nullptr; }
+    if (s->part_d) { (void)hipFree(s->part_d); s->part_d = nullptr; }
+    if (s->jobs_h) { (void)hipHostFree(s->jobs_h); s->jobs_h = nullptr; }
+    if (s->part_h) { (void)hipHostFree(s->part_h); s->part_h = nullptr; }
+    s->lb_cap = 0; s->lb_pairs = 0;
 }
 
 int state_of(rc_ctx* ctx, SmplifyState** out) {
@@ -106,6 +123,274 @@ double total_loss(const float* terms, int64_t T) {
     double f = 0.0, imu = 0.0, sm = 0.0;
     for (int64_t t = 0; t < T; ++t) { f += terms[t]; imu += terms[T + t]; sm += terms[2 * T + t]; }
     return f + (double)T * imu + sm;
+}
+
+// ---------------------------------------------------------------------------------- L-BFGS with device-resident vectors
+// The same algorithm object as rc_lbfgs.h (torch.optim.LBFGS(max_iter, strong_wolfe), temporal_smplify.py:141-147) with the
+// vectors left on the device. Per closure evaluation the host reads back the per-frame loss terms and four inner products
+// (g.d, |g|_inf, |g|_1, |d|_inf: one kernel of partial sums); per iteration the inner products of the new curvature pair and of
+// the gradient with the pairs kept so far, from which the two-loop recursion runs in COEFFICIENT space -- the direction is
+// d = sum_i a_i s_i + b_i y_i + c g and only its (2m + 1) coefficients are computed on the host (float64), then one kernel
+// forms d. No parameter or gradient vector crosses PCIe; round 2 moved 2 x 180 KB per evaluation and ran the recursion over
+// 45,000-element host vectors (10 of the 13.8 ms per 600-frame row).
+const int kSlots = 6, kSlotJobs = 4;
+
+int reserve_lbfgs(rc_ctx* ctx, SmplifyState* s, int64_t T, int pairs) {
+    if (T <= s->lb_cap && pairs <= s->lb_pairs) return RC_OK;
+    for (float** p : {&s->xt, &s->dir, &s->gslot, &s->Sv, &s->Yv})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (s->jobs_d) { (void)hipFree(s->jobs_d); s->jobs_d = nullptr; }
+    if (s->part_d) { (void)hipFree(s->part_d); s->part_d = nullptr; }
+    if (s->jobs_h) { (void)hipHostFree(s->jobs_h); s->jobs_h = nullptr; }
+    if (s->part_h) { (void)hipHostFree(s->part_h); s->part_h = nullptr; }
+    s->lb_cap = 0; s->lb_pairs = 0;
+    const size_t n = (size_t)T * 75, nb = (n + 4095) / 4096;
+    const size_t max_jobs = (size_t)kSlots * kSlotJobs + 6 * (size_t)pairs + 8;
+    SM_TRY(ctx, hipMalloc((void**)&s->xt, n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->dir, n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->gslot, kSlots * n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->Sv, (size_t)pairs * n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->Yv, (size_t)pairs * n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->jobs_d, max_jobs * sizeof(VecJob)));
+    SM_TRY(ctx, hipMalloc((void**)&s->part_d, max_jobs * nb * sizeof(double)));
+    SM_TRY(ctx, hipHostMalloc((void**)&s->jobs_h, max_jobs * sizeof(VecJob)));
+    SM_TRY(ctx, hipHostMalloc((void**)&s->part_h, max_jobs * nb * sizeof(double)));
+    s->lb_cap = T; s->lb_pairs = pairs;
+    return RC_OK;
+}
+
+struct DevResult { int n_iter = 0, n_eval = 0; float first_loss = 0, loss = 0; };
+
+// x (device, s->x) is updated in place. kp / K / ref3d / imu_aa as for the closure.
+int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, const float* kp, const float* K, int64_t T, float lr,
+                       int max_iter, hipStream_t st, DevResult& res) {
+    const size_t n = (size_t)T * 75;
+    const int nb = (int)((n + 4095) / 4096);
+    const int M = std::min(max_iter, RC_LBFGS_MAX_PAIRS);
+    if (int rc = reserve_lbfgs(ctx, s, T, M)) return rc;
+    const int max_eval = max_iter * 5 / 4;
+    const float tolerance_grad = 1e-7f, tolerance_change = 1e-9f;
+    const unsigned long long ign = rc_ctx_ign_mask(ctx);
+    auto slot = [&](int k) { return s->gslot + (size_t)k * n; };
+    // fixed part of the job table: per gradient slot {g.d, max |g|, sum |g|, max |d|}
+    for (int k = 0; k < kSlots; ++k) {
+        s->jobs_h[k * kSlotJobs + 0] = VecJob{slot(k), s->dir, 0, 0};
+        s->jobs_h[k * kSlotJobs + 1] = VecJob{slot(k), nullptr, 1, 0};
+        s->jobs_h[k * kSlotJobs + 2] = VecJob{slot(k), nullptr, 2, 0};
+        s->jobs_h[k * kSlotJobs + 3] = VecJob{s->dir, nullptr, 1, 0};
+    }
+    const int var0 = kSlots * kSlotJobs;                                // first job of the per-iteration (Gram) part
+    SM_TRY(ctx, hipMemcpyAsync(s->jobs_d, s->jobs_h, (size_t)var0 * sizeof(VecJob), hipMemcpyHostToDevice, st));
+    auto job_sum = [&](int job, bool is_max) {
+        const double* p = s->part_h + (size_t)job * nb;
+        double r = p[0];
+        for (int b = 1; b < nb; ++b) r = is_max ? std::max(r, p[b]) : r + p[b];
+        return r;
+    };
+    struct Eval { float f, gtd, gmax, gsum, dmax; };
+    hipError_t herr = hipSuccess;
+    // closure at x + t d into gradient slot k (t == 0: at x itself; the direction-dependent products are then meaningless)
+    auto eval = [&](float t, int k, Eval& e) -> bool {
+        const float* xp = s->x;
+        if (t != 0.0f) { rc_launch_vec_axpy(s->x, s->dir, t, s->xt, (long long)n, st); xp = s->xt; }
+        const SmplifyArgs A = make_args(s, xp, kp, s->ref3d, s->imu_aa, K, slot(k), T, ign);
+        herr = hipEventRecord(s->ev0, st);
+        rc_launch_smplify(A, body, st);
+        if (herr == hipSuccess) herr = hipEventRecord(s->ev1, st);
+        rc_launch_vec_dots(s->jobs_d + k * kSlotJobs, kSlotJobs, (long long)n, s->part_d + (size_t)k * kSlotJobs * nb, st);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(s->part_h + (size_t)k * kSlotJobs * nb, s->part_d + (size_t)k * kSlotJobs * nb,
+                                                      (size_t)kSlotJobs * nb * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(s->h_terms, s->terms, (size_t)T * 3 * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+        if (herr == hipSuccess) herr = hipGetLastError();
+        if (herr != hipSuccess) return false;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->device_ms += ms;
+        e.f = (float)total_loss(s->h_terms, T);
+        e.gtd = (float)job_sum(k * kSlotJobs + 0, false);
+        e.gmax = (float)job_sum(k * kSlotJobs + 1, true);
+        e.gsum = (float)job_sum(k * kSlotJobs + 2, false);
+        e.dmax = (float)job_sum(k * kSlotJobs + 3, true);
+        return true;
+    };
+#define LB_FAIL() return rc_ctx_fail(ctx, RC_ERR_HIP, (std::string("smplify L-BFGS: ") + hipGetErrorString(herr)).c_str())
+
+    int base = 0;                                                       // slot of the gradient at x
+    Eval e0;
+    if (!eval(0.0f, base, e0)) LB_FAIL();
+    float loss = e0.f, gmax = e0.gmax, gsum = e0.gsum;
+    res.first_loss = res.loss = loss;
+    int evals = 1;
+    if (gmax <= tolerance_grad) { res.n_eval = evals; return RC_OK; }
+
+    // inner products among the basis {s_0.., y_0.., g}: index i -> s_i, M + i -> y_i, 2M -> g
+    const int NB = 2 * M + 1;
+    std::vector<double> G((size_t)NB * NB, 0.0), ro(M, 0.0), al(M, 0.0), delta(NB, 0.0);
+    auto Gat = [&](int a, int b) -> double& { return G[(size_t)a * NB + b]; };
+    int m = 0;                                                          // curvature pairs kept
+    double H_diag = 1.0;
+    float t = 0.0f, prev_loss = loss, gtd = 0.0f, d_max = 0.0f;
+    int prev_base = base;
+    int n_iter = 0;
+    cubic_fn cubic = rc::Lbfgs<float>::cubic;
+    while (n_iter < max_iter) {
+        ++n_iter;
+        VecComb comb{};
+        if (n_iter == 1) {
+            comb.n_vec = 1; comb.v[0] = slot(base); comb.c[0] = -1.0f;     // d = -g
+        } else {
+            // candidate pair m: y = g - prev_g, s = t d
+            float* yv = s->Yv + (size_t)m * n;
+            float* sv = s->Sv + (size_t)m * n;
+            if (m < M) rc_launch_vec_pair(slot(base), slot(prev_base), s->dir, t, yv, sv, (long long)n, st);
+            // inner products: the candidate against the basis, the gradient against the basis
+            struct Want { int a, b; };
+            std::vector<Want> want;
+            const int mc = m < M ? m + 1 : m;                             // pairs incl. the candidate
+            if (m < M) {
+                for (int j = 0; j <= m; ++j) { want.push_back({m, j}); want.push_back({m, M + j}); want.push_back({M + m, M + j}); }
+                for (int j = 0; j < m; ++j) want.push_back({M + m, j});
+            }
+            for (int j = 0; j < mc; ++j) { want.push_back({2 * M, j}); want.push_back({2 * M, M + j}); }
+            want.push_back({2 * M, 2 * M});
+            auto vec_of = [&](int idx) -> const float* {
+                return idx == 2 * M ? slot(base) : (idx >= M ? s->Yv + (size_t)(idx - M) * n : s->Sv + (size_t)idx * n);
+            };
+            for (size_t q = 0; q < want.size(); ++q) s->jobs_h[var0 + q] = VecJob{vec_of(want[q].a), vec_of(want[q].b), 0, 0};
+            herr = hipMemcpyAsync(s->jobs_d + var0, s->jobs_h + var0, want.size() * sizeof(VecJob), hipMemcpyHostToDevice, st);
+            rc_launch_vec_dots(s->jobs_d + var0, (int)want.size(), (long long)n, s->part_d + (size_t)var0 * nb, st);
+            if (herr == hipSuccess) herr = hipMemcpyAsync(s->part_h + (size_t)var0 * nb, s->part_d + (size_t)var0 * nb,
+                                                          want.size() * nb * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+            if (herr != hipSuccess) LB_FAIL();
+            for (size_t q = 0; q < want.size(); ++q) {
+                const double v = job_sum(var0 + (int)q, false);
+                Gat(want[q].a, want[q].b) = v; Gat(want[q].b, want[q].a) = v;
+            }
+            if (m < M) {
+                const double ys = Gat(m, M + m);
+                if ((float)ys > 1e-10f) {                                 // keep the pair (torch: ys > 1e-10)
+                    H_diag = ys / Gat(M + m, M + m);
+                    ro[m] = 1.0 / ys;
+                    ++m;
+                }
+            }
+            // two-loop recursion on coefficients: q = sum_k delta[k] basis[k], starting from q = -g
+            std::fill(delta.begin(), delta.end(), 0.0);
+            delta[2 * M] = -1.0;
+            auto dot_q = [&](int idx) {
+                double r = delta[2 * M] * Gat(2 * M, idx);
+                for (int i = 0; i < m; ++i) r += delta[i] * Gat(i, idx) + delta[M + i] * Gat(M + i, idx);
+                return r;
+            };
+            for (int i = m - 1; i >= 0; --i) { al[i] = dot_q(i) * ro[i]; delta[M + i] -= al[i]; }
+            for (double& v : delta) v *= H_diag;
+            for (int i = 0; i < m; ++i) { const double be = dot_q(M + i) * ro[i]; delta[i] += al[i] - be; }
+            comb.n_vec = 0;
+            for (int i = 0; i < m; ++i) {
+                comb.v[comb.n_vec] = s->Sv + (size_t)i * n; comb.c[comb.n_vec++] = (float)delta[i];
+                comb.v[comb.n_vec] = s->Yv + (size_t)i * n; comb.c[comb.n_vec++] = (float)delta[M + i];
+            }
+            comb.v[comb.n_vec] = slot(base); comb.c[comb.n_vec++] = (float)delta[2 * M];
+            gtd = (float)dot_q(2 * M);
+        }
+        rc_launch_vec_comb(comb, s->dir, (long long)n, st);
+        prev_base = base;
+        prev_loss = loss;
+        if (n_iter == 1) {
+            t = std::min(1.0f, 1.0f / gsum) * lr;
+            // g.d of d = -g: the base slot's table entry pairs it with d (one more small readback, once per run)
+            rc_launch_vec_dots(s->jobs_d + base * kSlotJobs, 1, (long long)n, s->part_d + (size_t)base * kSlotJobs * nb, st);
+            herr = hipMemcpyAsync(s->part_h + (size_t)base * kSlotJobs * nb, s->part_d + (size_t)base * kSlotJobs * nb, (size_t)nb * sizeof(double),
+                                  hipMemcpyDeviceToHost, st);
+            if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+            if (herr != hipSuccess) LB_FAIL();
+            gtd = (float)job_sum(base * kSlotJobs, false);
+        } else t = lr;
+        if (gtd > -tolerance_change) break;
+
+        // ---- strong-Wolfe line search (rc_lbfgs.h: strong_wolfe) on gradient slots ------------------------------------
+        struct Pt { float t, f, gtd; int k; };
+        const int max_ls = max_eval - evals;
+        auto free_slot = [&](std::initializer_list<int> live) {
+            for (int k = 0; k < kSlots; ++k) { bool used = false; for (int v : live) used = used || v == k; if (!used) return k; }
+            return -1;
+        };
+        const float c1 = 1e-4f, c2 = 0.9f;
+        Pt cur{t, 0, 0, free_slot({base})};
+        Eval ev;
+        if (!eval(cur.t, cur.k, ev)) LB_FAIL();
+        int ls_evals = 1;
+        cur.f = ev.f; cur.gtd = ev.gtd; d_max = ev.dmax;
+        Pt prev{0, loss, gtd, base};
+        Pt br[2] = {prev, prev};
+        int n_br = 0, ls_iter = 0;
+        bool done = false;
+        while (ls_iter < max_ls) {
+            if (cur.f > (loss + c1 * cur.t * gtd) || (ls_iter > 1 && cur.f >= prev.f)) { br[0] = prev; br[1] = cur; n_br = 2; break; }
+            if (std::fabs(cur.gtd) <= -c2 * gtd) { br[0] = cur; n_br = 1; done = true; break; }
+            if (cur.gtd >= 0) { br[0] = prev; br[1] = cur; n_br = 2; break; }
+            const float min_step = cur.t + 0.01f * (cur.t - prev.t), max_step = cur.t * 10;
+            const float tn = cubic(prev.t, prev.f, prev.gtd, cur.t, cur.f, cur.gtd, true, min_step, max_step);
+            prev = cur;
+            cur.t = tn;
+            cur.k = free_slot({base, prev.k});
+            if (!eval(tn, cur.k, ev)) LB_FAIL();
+            cur.f = ev.f; cur.gtd = ev.gtd;
+            ++ls_evals;
+            ++ls_iter;
+        }
+        if (ls_iter == max_ls) { br[0] = Pt{0, loss, gtd, base}; br[1] = cur; n_br = 2; }
+        bool insuf = false;
+        int lo = 0, hi = 1;
+        if (n_br == 2 && !(br[0].f <= br[1].f)) { lo = 1; hi = 0; }
+        while (!done && ls_iter < max_ls) {
+            if (std::fabs(br[1].t - br[0].t) * d_max < tolerance_change) break;
+            float tn = cubic(br[0].t, br[0].f, br[0].gtd, br[1].t, br[1].f, br[1].gtd, false, 0, 0);
+            const float bmax = std::max(br[0].t, br[1].t), bmin = std::min(br[0].t, br[1].t);
+            const float eps = 0.1f * (bmax - bmin);
+            if (std::min(bmax - tn, tn - bmin) < eps) {
+                if (insuf || tn >= bmax || tn <= bmin) {
+                    tn = (std::fabs(tn - bmax) < std::fabs(tn - bmin)) ? bmax - eps : bmin + eps;
+                    insuf = false;
+                } else insuf = true;
+            } else insuf = false;
+            cur.t = tn;
+            cur.k = free_slot({base, br[0].k, br[1].k});
+            if (!eval(tn, cur.k, ev)) LB_FAIL();
+            cur.f = ev.f; cur.gtd = ev.gtd;
+            ++ls_evals;
+            ++ls_iter;
+            if (cur.f > (loss + c1 * tn * gtd) || cur.f >= br[lo].f) {
+                br[hi] = cur;
+                if (br[0].f <= br[1].f) { lo = 0; hi = 1; } else { lo = 1; hi = 0; }
+            } else {
+                if (std::fabs(cur.gtd) <= -c2 * gtd) done = true;
+                else if (cur.gtd * (br[hi].t - br[lo].t) >= 0) br[hi] = br[lo];
+                br[lo] = cur;
+            }
+        }
+        if (n_br == 1) lo = 0;
+        t = br[lo].t;
+        loss = br[lo].f;
+        base = br[lo].k;                                                  // gradient at the accepted point
+        rc_launch_vec_axpy(s->x, s->dir, t, s->x, (long long)n, st);      // x += t d (element-wise, in place)
+        // |g|_inf of the accepted point: its slot's partial sums are still in the pinned table unless the slot is the old base
+        gmax = base == prev_base ? gmax : (float)job_sum(base * kSlotJobs + 1, true);
+        const bool opt_cond = gmax <= tolerance_grad;
+        evals += ls_evals;
+
+        if (n_iter == max_iter) break;
+        if (evals >= max_eval) break;
+        if (opt_cond) break;
+        if (d_max * std::fabs(t) <= tolerance_change) break;
+        if (std::fabs(loss - prev_loss) < tolerance_change) break;
+    }
+#undef LB_FAIL
+    res.n_iter = n_iter;
+    res.n_eval = evals;
+    res.loss = loss;
+    return RC_OK;
 }
 
 }  // namespace
@@ -222,6 +507,29 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
 
     using L = rc::Lbfgs<float>;
     const size_t n = (size_t)T * 75;
+    const char* hv = std::getenv("RC_SMPLIFY_HOST_LBFGS");            // read per call: tests flip it
+    const bool host_vectors = hv && std::atoi(hv) != 0;
+    if (!host_vectors) {
+        // the optimiser's vectors stay on the device (minimize_on_device); s->x is updated in place
+        DevResult dr;
+        if (int rc = minimize_on_device(ctx, s, body, kp, K, T, lr, max_iter, st, dr)) return rc;
+        rc_launch_aa2R(s->x, pose_out, T * 24, st);
+        SM_TRY(ctx, hipMemcpyAsync(tran_out, s->x + T * 72, (size_t)T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc_launch_residual(body, pose_out, tran_out, kp, s->Kd, 100.0f, rc_ctx_ign_mask(ctx), s->res1, T, st);
+        SM_TRY(ctx, hipMemcpyAsync(s->h_res + T * 33, s->res1, (size_t)T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
+        SM_TRY(ctx, hipStreamSynchronize(st));
+        SM_TRY(ctx, hipGetLastError());
+        for (int64_t t = 0; t < T; ++t) update[t] = frame_mean(s->h_res + (T + t) * 33) < frame_mean(s->h_res + t * 33) ? 1 : 0;
+        info->status = 1;
+        info->n_iter = dr.n_iter;
+        info->n_eval = dr.n_eval;
+        info->first_loss = dr.first_loss;
+        info->final_loss = dr.loss;
+        info->device_ms = s->device_ms;
+        info->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return RC_OK;
+    }
+    // RC_SMPLIFY_HOST_LBFGS=1: round 2's formulation (vectors on the host, rc_lbfgs.h run as is) for A/B runs
     L::Vec x(s->h_x, s->h_x + n);
     int hip_rc = RC_OK;
     const SmplifyArgs A = make_args(s, s->x, kp, s->ref3d, s->imu_aa, K, s->grad, T, rc_ctx_ign_mask(ctx));

@@ -257,6 +257,35 @@ def cal_mpjpe(model, pose, gt_pose, j_regressor=None, cal_pampjpe=False):
     return mean if cal_pampjpe else mean[:2]
 
 
+def dataset_metrics(model, dataset, results, device="cuda"):
+    """``cal_mpjpe`` (evaluate.py:120-133: MPJPE over the regressor joints, PVE, PA-MPJPE, translation zero) of EVERY
+    (sequence, camera) row of ``results`` = {(i, j): (pose [T,24,3,3], tran)} in ONE metric call: the reference runs it row by
+    row inside its loop (evaluate.py:95-100); here all rows' frames are concatenated, the ground-truth rotations are built
+    once per sequence (their root is then turned into each camera's frame, evaluate.py:46-48) and the per-row means are cut
+    out of the per-frame result. Returns ({(i, j): [mpjpe, pve, pa_mpjpe]}, their mean over the rows)."""
+    dev = torch.device(device)
+    rows = list(results)
+    if not rows:
+        return {}, [float("nan")] * 3
+    seq_R, P, G, lens = {}, [], [], []
+    for (i, j) in rows:
+        if i not in seq_R:
+            seq_R[i] = _body.axis_angle_to_rotation_matrix(torch.as_tensor(dataset["pose"][i]).reshape(-1, 3), device).view(-1, 24, 3, 3)
+        Rcw = torch.as_tensor(dataset["cam_T"][i][j], dtype=torch.float32)[:3, :3].to(dev)
+        gt = seq_R[i].clone()
+        gt[:, 0] = Rcw @ gt[:, 0]
+        pose = results[(i, j)][0].to(dev)
+        n = min(pose.shape[0], gt.shape[0])
+        P.append(pose[:n]), G.append(gt[:n]), lens.append(n)
+    per_frame, _ = model.mesh_metrics(torch.cat(P), torch.cat(G))
+    pf = per_frame.cpu().double()
+    out, a = {}, 0
+    for (i, j), n in zip(rows, lens):
+        out[(i, j)] = [float(v) for v in pf[a:a + n].mean(0)]
+        a += n
+    return out, [float(v) for v in np.mean(list(out.values()), axis=0)]
+
+
 def evaluate(dataset, state_dict, body, device="cuda", **kw):
     """Full loop: run all rows, return per-row metrics and their mean (rank-local when not distributed)."""
     res = run_dataset(dataset, state_dict, body, device=device, **kw)

@@ -181,3 +181,32 @@ def test_procrustes_and_position_error_match_reference_capture(synth_assets):
     pf = pf.cpu().numpy()
     for c in range(3):
         assert np.abs(pf[:, c] - want[c]).max() <= 3e-6
+
+
+def test_dataset_metrics_in_one_call_equal_the_row_by_row_loop(synth_assets):
+    """evaluate.dataset_metrics (all rows' frames in ONE rc_mesh_metrics call, ground-truth rotations built once per
+    sequence) == cal_mpjpe row by row as the reference's loop runs it (evaluate.py:95-100, 120-133)."""
+    from robustcap_amd import synth
+    from robustcap_amd import evaluate as ev
+    from robustcap_amd.body import ParametricModel
+    body = synth_assets["body"]
+    ds = synth.make_dataset(8, 3, 20, body, n_cam=2)
+    for k in ("pose", "tran", "imu_ori", "imu_acc"):
+        ds[k][1] = ds[k][1][:13]                                                     # ragged
+    ds["joint2d_mp"][1] = ds["joint2d_mp"][1][:, :13]
+    g = torch.Generator().manual_seed(3)
+    res = {}
+    for (i, j) in ev.rows_of(ds):                                                    # "predictions": perturbed labels
+        pt, tt = ev.labels(ds, i, j)
+        noise = 0.1 * torch.randn(pt.shape[0], 24, 3, generator=g)
+        from robustcap_amd import body as B
+        res[(i, j)] = (pt @ B.axis_angle_to_rotation_matrix(noise.view(-1, 3)).view(-1, 24, 3, 3).cpu(), tt)
+    model = ParametricModel(body=body)
+    model.set_regressor(synth.make_j_regressor(4), 14)
+    per_row, mean = ev.dataset_metrics(model, ds, res)
+    assert sorted(per_row) == sorted(res)
+    for (i, j), (pose, _) in res.items():
+        pt, _ = ev.labels(ds, i, j)
+        one = model.mesh_metrics(pose, pt)[1]
+        assert max(abs(a - b) for a, b in zip(one, per_row[(i, j)])) < 1e-6
+    assert all(v > 1e-3 for v in mean)

@@ -139,6 +139,26 @@ def test_runner_against_reference_run(g, runner, synth_assets):
     assert float((pose @ pose.transpose(-1, -2) - eye).abs().max()) < 1e-5
 
 
+def test_device_resident_lbfgs_against_the_host_formulation(g, runner, monkeypatch):
+    """rc_smplify_run keeps the optimiser's vectors on the device and runs the two-loop recursion on coefficients (float64 inner
+    products); RC_SMPLIFY_HOST_LBFGS=1 selects round 2's formulation (rc_lbfgs.h on host vectors, pinned against torch in
+    tests/test_lbfgs_host.py). Same algorithm, different rounding: same evaluation budget, the same first closure value, end
+    states in the same range."""
+    from robustcap_amd.smplify import smplify_runner
+    T = int(g["run_T"])
+    args = (t(g["run_pose0"]), t(g["run_tran0"]), t(g["run_kp"]), t(g["run_imu_ori"]), T, t(g["run_K"]))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RC_SMPLIFY_HOST_LBFGS", mode)
+        smplify_runner(*args, lr=0.001, runner=runner)
+        out[mode] = dict(runner.last_info)
+    dev, host = out["0"], out["1"]
+    assert dev["status"] == host["status"] == 1 and dev["n_eval"] == host["n_eval"] == 26 and dev["n_iter"] == host["n_iter"]
+    assert dev["first_loss"] == host["first_loss"]                                  # the same closure on the same point
+    assert abs(dev["final_loss"] - host["final_loss"]) < 0.1 * host["first_loss"]
+    assert dev["final_loss"] < 0.45 * dev["first_loss"]
+
+
 def test_runner_gate_and_errors(g, runner, synth_assets):
     from robustcap_amd import _lib
     from robustcap_amd.smplify import TemporalSMPLify, smplify_runner

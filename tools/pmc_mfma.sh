@@ -4,8 +4,8 @@ set -e
 out=$PWD/gpurun_out/pmc_mfma
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc MfmaUtil --kernel-trace -d $out/util -o pmc -- python $OLDPWD/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-variants > $out/util.log 2>&1 || echo "pass MfmaUtil failed"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/raw -o pmc -- python $OLDPWD/bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-variants > $out/raw.log 2>&1 || echo "pass raw failed"
+rocprofv3 --pmc MfmaUtil --kernel-trace -d $out/util -o pmc -- python $OLDPWD/bench.py --steps 128 --warmup 16 --reps 1 --no-cpu-baseline --no-variants > $out/util.log 2>&1 || echo "pass MfmaUtil failed"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/raw -o pmc -- python $OLDPWD/bench.py --steps 128 --warmup 16 --reps 1 --no-cpu-baseline --no-variants > $out/raw.log 2>&1 || echo "pass raw failed"
 cd $OLDPWD
 python - <<'PY'
 import sqlite3, glob, collections, json
