@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="bodies per GPU (weak) or in total (strong)")
     ap.add_argument("--conf", default="mixed", choices=["mixed", "high", "occ"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--gemm-mode", default="auto", choices=["auto", "split", "fp32"],
+                    help="product arithmetic of the GEMMs (auto: split-bf16 products from 80 bodies in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the variants (other schedules / configs)")
     args = ap.parse_args()
@@ -317,7 +319,7 @@ def main():
     strong_total = bodies_total if (args.scaling == "strong" and world > 1 and args.batch % world) else None
     # The product arithmetic follows the TOTAL workload, not this rank's shard: the same rows give the same bits on 1 or N GPUs.
     from robustcap_amd.net.sig_mp import Net
-    split_total = Net.default_gemm_mode(bodies_total)
+    split_total = Net.default_gemm_mode(bodies_total) if args.gemm_mode == "auto" else args.gemm_mode == "split"
     long_frames = LONG_FRAMES if (not args.no_variants and K < LONG_FRAMES) else 0
 
     main_w = Workload(sd, body, args.conf, B, W, max(K, long_frames), rank, world, split=split_total)

@@ -12,7 +12,8 @@
  *     (hipStream_t is passed as void*). The library owns only its context (packed weights, recurrent state,
  *     scratch). No call synchronises the device except rc_create / rc_finalize_weights / rc_set_body / rc_set_mesh /
  *     rc_shape_body / rc_get_state / rc_get_trace / rc_destroy; rc_sequence synchronises `stream` ONCE per call when its
- *     launch planner is on (rc_set_sequence_mode; the default), rc_camera_inputs_rows once (constant upload), the
+ *     launch planner is on AND the call has at least min_frames frames (rc_set_sequence_mode; shorter calls and mode 0 are
+ *     fully asynchronous), rc_camera_inputs_rows once (constant upload), the
  *     *_host-mean variants of the metric calls and rc_smplify_* as documented with them.
  *   - Every function returns 0 on success or a negative rc_status; rc_last_error() gives a message. Nothing
  *     throws across the boundary. A context is not re-entrant; distinct contexts on distinct streams are
@@ -71,7 +72,8 @@ int rc_set_params(rc_ctx* ctx, const rc_params* p);
 /* Replaces Net.load_state_dict (evaluate.py:58): one call per state_dict entry, key names and shapes as in
  * the reference ("rnn2.rnn.weight_ih_l0", "rnn4.linear1.bias", "rnn2.init_net.4.weight", ...).
  * `host` points to numel float32 values in HOST memory (torch layout). rc_finalize_weights repacks everything
- * to the kernel layout and uploads; it fails if a key is missing. */
+ * to the kernel layout and uploads; it fails if a key is missing. The library keeps NO host copy afterwards (254 MB per
+ * context otherwise): a later reload -- also of a single tensor -- passes every tensor again before the next finalize. */
 int rc_load_weight(rc_ctx* ctx, const char* key, const float* host, int64_t numel);
 int rc_finalize_weights(rc_ctx* ctx);
 
@@ -112,11 +114,12 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
  *           of the partial products down to 2^-16 of it (what is dropped is below 2^-23 of a product, i.e. below the
  *           rounding of the running fp32 sum); operands, accumulators, gates and state stay fp32. Same accuracy class as
  *           mode 0 (parity with the reference: tests), 2.7x fewer MFMA cycles per product.
- * Default: mode 1 for contexts of batch >= 192 (MFMA-bound), mode 0 below (bound by the launch chain and by weight
- * streaming: 6 B instead of 4 B per weight would slow them). Within one mode a row's result does not depend on the batch, the tile shape or the engine
+ * Default: mode 1 for contexts of batch >= 80, mode 0 below (weight-streaming bound: 6 B instead of 4 B per weight would
+ * slow them). Within one mode a row's result does not depend on the batch, the tile shape or the engine
  * (bitwise); between the two modes results differ by fp32 rounding noise. rc_get_gemm_mode returns the mode. */
 int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode);
 int rc_get_gemm_mode(const rc_ctx* ctx);
+int rc_default_gemm_mode(int32_t total_rows);   /* the default of a context of that many rows: sharded runs pin every shard to the TOTAL's */
 
 /* Sequence mode of rc_sequence (on by default). With mode >= 1 every rc_sequence call of T >= 2 frames first classifies
  * each (frame, row) on the device (the arithmetic of the per-frame prep kernel), reads the codes back -- ONE

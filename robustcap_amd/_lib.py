@@ -52,6 +52,7 @@ SIGNATURES = {
     "rc_sequence": (_I32, [_P, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _U32, _P, _I64, _P, _I64, _P]),
     "rc_set_gemm_mode": (_I32, [_P, _I32]),
     "rc_get_gemm_mode": (_I32, [_P]),
+    "rc_default_gemm_mode": (_I32, [_I32]),
     "rc_set_sequence_mode": (_I32, [_P, _I32, _I32]),
     "rc_get_sequence_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "rc_plan_sequence": (_I32, [_P, _I32, _I32, _P, _U32, _I32, _P]),

@@ -23,10 +23,13 @@
 #include <string>
 #include <vector>
 
-// From this batch on a context defaults to the split-bf16 products and to 64-row tiles for its full-batch stages. Below it
-// the frame is bound by its launch chain and by weight streaming (6 B per weight would slow it: measured 165k vs 193k
-// body-frames/s at batch 32, 442k vs 461k at 128; at 256 the split wins 770k vs 685k).
-#define RC_SPLIT_MIN_BATCH 192
+// From this batch on a context defaults to the split-bf16 products. Round 2 (frame-stepped launches only) put the break-even
+// at 192 rows; with the wavefront engine a tick is two merged launches that fill the chip at any batch, and the split wins
+// from ~80 rows (mixed, 256-frame calls, body-frames/s, split vs fp32 MFMA: batch 64 387k vs 428k, 96 633k vs 434k, 128 691k
+// vs 476k, 160 784k vs 595k). 64-row tiles for the FRAME-STEPPED full-batch stages stay tied to 192 rows (below that they
+// leave CUs without a tile).
+#define RC_SPLIT_MIN_BATCH 80
+#define RC_TILE64_MIN_BATCH 192
 
 #ifndef RC_NC1280
 #define RC_NC1280 10      // 16-column blocks per rnn4 LSTM tile (probe builds: 8 lets two workgroups share a CU's LDS)
@@ -139,7 +142,8 @@ struct rc_ctx {
     int* frame_at_d = nullptr;           // [cap] host plan: frame every row starts at every tick
     int* frame_at_h = nullptr;           // pinned
     size_t frame_at_cap = 0;
-    double cost_tick_us = 235.0, cost_tick_small_us = 115.0, cost_frame_us = 300.0, cost_tr_us = 60.0;   // engine choice (plan_wave)
+    double cost_tick_us = 1.0, cost_tick_small_us = 13.0, cost_frame_us = 285.0, cost_tr_us = 55.0;   // engine choice (plan_wave): scale of the
+                                                         // per-layer tick estimate, hand-over per tick, frame-stepped frame, its transition launches
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
 };
@@ -349,7 +353,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     p.epi = RC_EPI_LSTM;
     int mr, nc;
     pick_tile(n.H, s.rows_hint < 0 ? c->B : s.rows_hint, &mr, &nc);
-    if (s.rows_hint < 0 && c->B >= RC_SPLIT_MIN_BATCH) {   // below that, 64-row tiles leave CUs without a tile
+    if (s.rows_hint < 0 && c->B >= RC_TILE64_MIN_BATCH) {  // below that, 64-row tiles leave CUs without a tile
         // Second stage of a frame {rnn6, rnn3, rnn7, rnn8}: 64-row tiles. 128 CUs run the 128 rnn6 tiles (64 x 128) while
         // the other 128 run the 3 x 128 tiles (64 x 64) of the H = 512 nets in three rounds of a third of that length each,
         // instead of one round of 32 x 128 tiles followed by three rounds of 32 x 64 tiles: half as many tile prologues /
@@ -632,16 +636,27 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
     P.frame_at.assign((size_t)n_prep * B, -1);
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < n_frames; ++i) P.frame_at[(size_t)entry[(size_t)b * n_frames + i] * B + b] = t0 + i;
-    // cost model for the engine choice: a tick whose busiest stage has >= 96 rows costs a full tick, other ticks stream the
-    // weights through small tiles; a frame-stepped frame costs a frame (+ the transition launches where a row needs them)
+    // cost model for the engine choice. A tick = the stream hand-over + its layer steps: a layer step with >= 96 rows costs its
+    // round of wide tiles (rnn4 43 us, rnn6 27.5 us, an H = 512 net 8 us: profiles/r03_timeline_mixed.txt), with fewer rows it
+    // streams its weights through small tiles (~0.45 of that); cost[0] scales the whole estimate (1.0 = these figures).
     P.est_wave_us = 0.0;
-    for (int k = 0; k < P.n_ticks; ++k) {
-        int rows = 0;
-        for (int st = 1; st <= kTailStage; ++st) {
-            const int e = k - st;
-            if (e >= 0 && e < n_prep) rows = std::max(rows, P.n_valid[e] + P.n_rider[e]);
+    {
+        const double layer_us[3] = {43.0, 27.5, 8.0};                     // rnn4 | rnn6 | H = 512 net, per layer step
+        for (int k = 0; k < P.n_ticks; ++k) {
+            double t = cost[1];
+            auto add = [&](int stage, double us, bool big_nets) {
+                const int e = k - stage;
+                if (e < 0 || e >= n_prep) return;
+                const int rows = big_nets ? P.n_vis[e] + P.n_rider[e] : P.n_valid[e];
+                if (rows > 0) t += rows >= 96 ? us : 0.45 * us;
+            };
+            for (int l = 0; l < 2; ++l) {
+                add(2 + l, layer_us[0], true);  add(2 + l, layer_us[2], false);                  // rnn4, rnn2
+                add(6 + l, layer_us[1], true);  add(6 + l, 3 * layer_us[2], false);              // rnn6, rnn3 + rnn7 + rnn8
+            }
+            add(1, 3.0, false); add(5, 3.0, false);                                              // linear1 tiles
+            P.est_wave_us += t * cost[0];
         }
-        P.est_wave_us += rows >= 96 ? cost[0] : (rows > 0 ? cost[1] : 25.0);
     }
     P.est_stepped_us = 0.0;
     for (int i = 0; i < n_frames; ++i) P.est_stepped_us += cost[2] + (tr_frame[i] ? cost[3] : 0.0);
@@ -719,7 +734,9 @@ int build_wave2_problems(rc_ctx* ctx) {
 inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : kInitStage + (q - W2_INIT0); }
 // merge_h512: the H = 512 nets' eight layer steps and the six linear1 share ONE launch (512 equal 64 x 128 tiles = two rounds, then
 // the linear1 tiles) instead of two launches of one round each; init_net then rides with rnn6
-// merge_big (experiment): rnn6's and rnn4's layer steps share one launch as well (rnn6's longer tiles first)
+// merge_big: rnn6's and rnn4's layer steps share one launch as well (rnn6's longer tiles first): two launches per tick.
+// Measured on one box (mixed 512 frames, body-frames/s): 4 launches 1.005 M, H = 512 merged 1.037 M, both merged 1.066 M;
+// 20-frame calls 0.890 -> 0.913 M (every launch boundary of a tick is a drain + ramp of all 256 CUs)
 inline int w2_group(int q, bool merge_h512, bool merge_big) {
     int g = q >= RC_TICK_PROB ? (merge_h512 ? 1 : 2) : ((merge_h512 && kTick[q].group == 3) ? 2 : kTick[q].group);
     if (merge_big && g == 1) g = 0;
@@ -755,7 +772,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     static const bool narrow_fill = tune_env("RC_SEQ_NARROW_FILL", 1) != 0;
     static const bool lin1_wide = tune_env("RC_SEQ_LIN1_WIDE", 1) != 0;
     static const bool merge_h512 = tune_env("RC_SEQ_MERGE_H512", 1) != 0;
-    static const bool merge_big = tune_env("RC_SEQ_MERGE_BIG", 0) != 0;
+    static const bool merge_big = tune_env("RC_SEQ_MERGE_BIG", 1) != 0;
     const int last_group = merge_h512 ? 2 : 3;
     auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
     static const bool ext_events = tune_env("RC_SEQ_EXT_EVENTS", 1) != 0;   // tick hand-over events carried by the last dispatch itself (+0.5 %)
@@ -775,7 +792,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (kind == 1 || kind == 2) {
                 const NetDev& n = ctx->net[net];
                 int mr, nc;
-                if (B >= RC_SPLIT_MIN_BATCH && rows >= 128) {
+                if (ctx->gemm_split && rows >= 128) {                          // (split products: the K loop is operand-bound, 64-row tiles)
                     const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
                     mr = t[0]; nc = t[1];
                 } else {
@@ -784,7 +801,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
                 p.mr = mr; p.nc = nc; p.n_tiles = n.H / (4 * nc);
             } else if (kind == 0 || kind == 4) {
                 if (rows <= 16) { p.mr = 1; p.nc = 1; p.n_tiles = (p.N + 15) / 16; }
-                else if (kind == 0 && lin1_wide && B >= RC_SPLIT_MIN_BATCH && rows >= 128) {
+                else if (kind == 0 && lin1_wide && ctx->gemm_split && rows >= 128) {
                     // linear1 rides in the last wide launch behind its 256 LSTM tiles: as 544 tiles of 32 x 64 (K = 128 / 256: two
                     // k-blocks, i.e. all prologue and epilogue) it added two rounds, ~18 us of a 245 us tick; 136 tiles of 64 x 128 add one
                     const int np = round_up(p.N, 64);
@@ -840,6 +857,9 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         }
         if (two && !aux_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
         // ---- the GEMM stages of tick k (caller's stream: after the previous tick's second-stream work)
+        // (The wait cannot move behind the first launch of the tick although only linear1 / init_net READ what the second stream
+        // wrote: the first launch WRITES h of rnn4 / rnn6 at the parity linear2 of the previous tick -- second stream -- still
+        // reads, the state being double-buffered by step parity. Tried: +1-3 %, three all-visible parity tests red.)
         if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
         bool main_signalled = false;
         for (int g = 0; g <= last_group; ++g)
@@ -938,8 +958,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
-    ctx->cost_tick_us = tune_env("RC_COST_TICK_US", (int)ctx->cost_tick_us);
-    ctx->cost_tick_small_us = tune_env("RC_COST_TICK_SMALL_US", (int)ctx->cost_tick_small_us);
+    ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
+    ctx->cost_tick_small_us = tune_env("RC_COST_HANDOVER_US", (int)ctx->cost_tick_small_us);
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
     ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
@@ -1242,6 +1262,9 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
             const double cost[4] = {ctx->cost_tick_us, ctx->cost_tick_small_us, ctx->cost_frame_us, ctx->cost_tr_us};
             plan_wave(ctx->scan_codes_h, B, T, w0, fr.data(), pd.data(), imu, vup, cost, wplan);
             if (ctx->seq_mode == 2 || wplan.est_wave_us < wplan.est_stepped_us) wave2_from = w0;
+            static const bool dbg = tune_env("RC_SEQ_DEBUG", 0) != 0;
+            if (dbg) std::fprintf(stderr, "rc_sequence plan: T=%d ticks=%d lag_max=%d est_wave=%.0f us est_stepped=%.0f us -> %s\n", T, wplan.n_ticks,
+                                  wplan.lag_max, wplan.est_wave_us, wplan.est_stepped_us, wave2_from >= 0 ? "wavefront" : "frame-stepped");
         }
         plan_sequence(ctx->scan_codes_h, B, T, ctx->scan_state_h + B, ff, vup, mode.data());    // transition-launch marks of stepped frames
     }
@@ -1273,6 +1296,7 @@ int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode) {
     return RC_OK;
 }
 int rc_get_gemm_mode(const rc_ctx* ctx) { return ctx ? (ctx->gemm_split ? 1 : 0) : RC_ERR_INVALID; }
+int rc_default_gemm_mode(int32_t total_rows) { return total_rows >= RC_SPLIT_MIN_BATCH ? 1 : 0; }
 
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames) {
     if (!ctx || mode < 0 || mode > 2 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1|2, min_frames >= 1") : RC_ERR_INVALID;
@@ -1301,7 +1325,7 @@ int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const in
                  int32_t* n_prep, int32_t* counts, double* est_us) {
     if (!codes || !first_reach || !pend || !n_ticks || !n_prep || B < 1 || T < 1 || t0 < 0 || t0 >= T) return RC_ERR_INVALID;
     WavePlan P;
-    const double cost[4] = {235.0, 115.0, 300.0, 60.0};
+    const double cost[4] = {1.0, 13.0, 285.0, 55.0};
     plan_wave(reinterpret_cast<const signed char*>(codes), B, T, t0, first_reach, pend, use_imu_updater != 0, use_vision_updater != 0, cost, P);
     *n_ticks = P.n_ticks;
     *n_prep = P.n_prep;

@@ -89,9 +89,10 @@ def test_chunked_calls_and_short_segments(synth_assets):
         assert torch.equal(net.get_state(n)[0], ref.get_state(n)[0])
 
 
-@pytest.mark.parametrize("B,conf", [(37, "high"), (256, "high"), (64, "mixed"), (256, "mixed"), (200, "occ"), (24, "low")])
+@pytest.mark.parametrize("B,conf", [(37, "high"), (256, "high"), (64, "mixed"), (256, "mixed"), (200, "occ"), (24, "low"), (1024, "occ")])
 def test_batched_wavefront_equals_frame_stepped(B, conf, synth_assets):
-    """Ragged and full batches in every confidence schedule: rows wait for their own feedback steps only."""
+    """Ragged and full batches in every confidence schedule: rows wait for their own feedback steps only. (1024, "occ") is
+    BASELINE config 4 at its stated size: batch 1024 with occlusion-masked keypoints."""
     import bench
     T = 96
     m = bench.make_inputs(synth_assets["body"], B, T, conf, seed=5)

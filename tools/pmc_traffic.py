@@ -41,7 +41,7 @@ if wide and wide in res.get("WRITE_SIZE", {}):
     w, _ = res["WRITE_SIZE"][wide]
     out = {"batch": batch, "conf": conf, "kernel": wide,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in three separate passes with --kernel-trace only "
-                     "(tools/pmc_traffic.sh: bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-variants), per-launch average over "
+                     "(tools/pmc_traffic.sh: bench.py --steps 128 --warmup 16 --reps 1 --no-cpu-baseline --no-variants), per-launch average over "
                      "%d launches of %s" % (n, wide),
            "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
            "traffic_bytes_per_launch": (2 * f + w) * 1024,
