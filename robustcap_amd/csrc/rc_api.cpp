@@ -1,15 +1,16 @@
 // C ABI of librobustcap_hip.so (see include/robustcap_hip.h): context, weight repacking, per-frame launch plan.
 //
-// Host logic only; all arithmetic runs in the .hip files. The launch plan of one frame mirrors the data flow of
-// Net.forward_online (net/sig_mp.py:113-274), with the vision updater of frame t-1 executed at the start of frame t:
+// Host logic only; all arithmetic runs in the .hip files. The frame-stepped launch plan of one frame (step_impl) mirrors the
+// data flow of Net.forward_online (net/sig_mp.py:113-274), with the vision updater of frame t-1 executed at the start of frame t:
 //   prep -> {rnn6, rnn4} transition steps of rows whose deferred updater step must precede this frame's own step
 //                                          (3 fused launches: linear1, LSTM l0, LSTM l1; usually a handful of rows)
 //        -> {rnn4 (+ rows whose deferred step merges into it), rnn2}          (4 fused launches: + linear2)
 //        -> [first frame: rnn6 on every row, L155-156]
 //        -> fuse -> {rnn6 (+ merged deferred rows), rnn3, rnn7, rnn8, rnn2.init_net}          (4 fused launches)
 //        -> tail (fusion logic, FK, landmarks; marks the rows whose updater step is now pending)
-// Independent sub-nets share a launch ("problems" of one gate-GEMM grid) so the chip sees 500-1300 workgroups per
-// LSTM launch instead of 128-640. 14 kernel launches per frame, no host synchronisation.
+// Independent sub-nets share a launch ("problems" of one gate-GEMM grid). 8-14 kernel launches per frame, no host
+// synchronisation. rc_sequence runs whole calls on the per-row-cursor wavefront engine instead (run_wave2_segment below): the
+// same stages skewed over consecutive ticks and a ring of slots, two merged wide launches per tick.
 #include "../../include/robustcap_hip.h"
 #include "rc_internal.h"
 
@@ -58,7 +59,7 @@ struct NetDev {
     float* Wl[2] = {nullptr, nullptr};   // LSTM layers, K' = 2H, N' = 4H (tile-interleaved gates)
     void* Wls[2] = {nullptr, nullptr};   // their split-bf16 planes
     float* bl[2] = {nullptr, nullptr};
-    float* h = nullptr;                  // [layer][parity][B][H]
+    float* h = nullptr;                  // [layer][copy of RC_HBUF][B][H]
     float* c = nullptr;                  // [layer][B][H]
     int* steps = nullptr;                // [B]
     float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
@@ -346,9 +347,9 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     GemmProblem p{};
     if (layer == 0) p.seg[0] = seg(n.x1, n.H, n.H);
     else p.seg[0] = seg(n.h, n.H, n.H, RC_PAR_DST, BH);                     // h of layer 0, just written
-    p.seg[1] = seg(n.h + layer * 2 * BH, n.H, n.H, RC_PAR_SRC, BH);         // own h, previous step
+    p.seg[1] = seg(n.h + layer * RC_HBUF * BH, n.H, n.H, RC_PAR_SRC, BH);   // own h, previous step
     p.W = n.Wl[layer]; p.Ws = n.Wls[layer]; p.bias = n.bl[layer];
-    p.hstate = n.h + layer * 2 * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
+    p.hstate = n.h + layer * RC_HBUF * BH; p.cstate = n.c + layer * (long long)c->B * n.H; p.h_par_stride = BH; p.H = n.H;
     p.steps = n.steps; p.flags = s.flags ? s.flags : c->fb.flags; p.flag_bit = s.flag_bit;
     p.epi = RC_EPI_LSTM;
     int mr, nc;
@@ -370,7 +371,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     const NetDev& n = c->net[s.net];
     const long long BH = (long long)c->Bp * n.H;
-    GemmProblem p = dense_problem(c, n.lin2, seg(n.h + 2 * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit,
+    GemmProblem p = dense_problem(c, n.lin2, seg(n.h + RC_HBUF * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit,
                                   s.flags ? s.flags : c->fb.flags, n.steps, false);
     p.out_flags = c->fb.flags; p.out_bit = s.out_bit;
     return p;
@@ -774,6 +775,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     static const bool merge_h512 = tune_env("RC_SEQ_MERGE_H512", 1) != 0;
     static const bool merge_big = tune_env("RC_SEQ_MERGE_BIG", 1) != 0;
     const int last_group = merge_h512 ? 2 : 3;
+    static const bool late_wait = tune_env("RC_SEQ_LATE_WAIT", 1) != 0;
     auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
     static const bool ext_events = tune_env("RC_SEQ_EXT_EVENTS", 1) != 0;   // tick hand-over events carried by the last dispatch itself (+0.5 %)
     auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {   // problems of group g with rows at tick k
@@ -857,13 +859,20 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         }
         if (two && !aux_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[e], aux));
         // ---- the GEMM stages of tick k (caller's stream: after the previous tick's second-stream work)
-        // (The wait cannot move behind the first launch of the tick although only linear1 / init_net READ what the second stream
-        // wrote: the first launch WRITES h of rnn4 / rnn6 at the parity linear2 of the previous tick -- second stream -- still
-        // reads, the state being double-buffered by step parity. Tried: +1-3 %, three all-visible parity tests red.)
-        if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+        // Of the caller's-stream launches only linear1 (and init_net) READ what the second stream wrote in the previous tick, and
+        // with the groups merged they sit in the LAST launch: the wait goes in front of that one (late_wait), and the first launch
+        // of the tick follows the previous tick's last one without a barrier packet in between (+1-3 %). What made this illegal
+        // with two copies of the hidden state -- the first launch WRITES h of rnn4 / rnn6 where linear2 of the previous tick, on
+        // the second stream, still reads -- is what the third copy is for (RC_HBUF).
+        bool init_now = false;
+        for (int q = W2_INIT0; q < W2_PROB; ++q) init_now = init_now || cnt(P.n_reach, k - w2_stage(q)) > 0;
+        const bool late = late_wait && merge_h512 && !init_now;
+        if (two && k > 0 && !late) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
         bool main_signalled = false;
-        for (int g = 0; g <= last_group; ++g)
+        for (int g = 0; g <= last_group; ++g) {
+            if (two && k > 0 && late && g == last_group) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
             if (int rc = group(k, g, st, (g == last_group && two && ext_events) ? ctx->ev_main[e] : nullptr, g == last_group ? &main_signalled : nullptr)) return rc;
+        }
         if (two && !main_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
         ctx->stat_ticks += 1;
     }
@@ -985,7 +994,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
         // rnn4 layer) and coarsen the row compaction of masked stages (bench 535k vs 573k body-frames/s): not used.
         n.mr = 2;
         n.nc = n.H == 1280 ? 10 : (n.H == 1024 ? 8 : 4);
-        A(n.h, 4 * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
+        A(n.h, 2 * RC_HBUF * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
     }
     A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);
     A(fb.x2, Bp * 128); A(fb.x3, Bp * 256); A(fb.x4, Bp * 256); A(fb.x6, Bp * 256); A(fb.x78, Bp * 256);
@@ -998,7 +1007,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
 #undef A
     if (rc) { g_create_error = ctx->err; rc_destroy(ctx); return rc; }
     fb.h2 = ctx->net[N2].h; fb.c2 = ctx->net[N2].c; fb.steps2 = ctx->net[N2].steps;
-    fb.h2_par_stride = (long long)Bp * 512; fb.h2_layer_stride = 2ll * Bp * 512; fb.c2_layer_stride = (long long)B * 512;
+    fb.h2_par_stride = (long long)Bp * 512; fb.h2_layer_stride = (long long)RC_HBUF * Bp * 512; fb.c2_layer_stride = (long long)B * 512;
     std::vector<float> g(B * 3);
     for (size_t b = 0; b < B; ++b) { g[3 * b] = -0.0029f; g[3 * b + 1] = 0.9980f; g[3 * b + 2] = -0.0273f; }   // sig_mp.py:36
     std::vector<int> ones(B, 1);
@@ -1204,6 +1213,18 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
     if (int rc = check_ready(ctx)) return rc;
     ctx->live_prev_known = false;
     if (T < 0 || !j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_sequence: bad argument");
+    // Very long calls are planned in pieces: the plan's tables (regime codes, frame_at) grow with batch x frames, and a piece
+    // boundary costs one pipeline drain (8 of 4,096 ticks) and one more read-back.
+    const int32_t kMaxPlanFrames = std::max(8, tune_env("RC_SEQ_MAX_PLAN_FRAMES", 4096));     // (read per call: tests shrink it)
+    if (T > kMaxPlanFrames && ctx->seq_mode && !ctx->prm.live) {
+        for (int32_t a = 0; a < T; a += kMaxPlanFrames) {
+            const int32_t n = std::min(kMaxPlanFrames, T - a);
+            if (int rc = rc_sequence(ctx, n, j2dc + (int64_t)a * 99, rs_j2d, accc + (int64_t)a * 18, rs_acc, oric + (int64_t)a * 54, rs_ori,
+                                     a == 0 ? first_tran : nullptr, a == 0 ? flags : 0u, pose_out + (int64_t)a * 216, rs_pose,
+                                     tran_out + (int64_t)a * 3, rs_tran, stream)) return rc;
+        }
+        return RC_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     auto io_at = [&](int t) {
         return FrameIO{j2dc + (int64_t)t * 99, accc + (int64_t)t * 18, oric + (int64_t)t * 54, t == 0 ? first_tran : nullptr,
@@ -1786,14 +1807,14 @@ int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, voi
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     const NetDev& n = ctx->net[ni];
     const size_t B = ctx->B, Bp = ctx->Bp, H = n.H;
-    std::vector<float> h(4 * Bp * H);
+    std::vector<float> h(2 * RC_HBUF * Bp * H);
     std::vector<int> steps(B);
     HIP_TRY(ctx, hipMemcpy(h.data(), n.h, h.size() * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(steps.data(), n.steps, B * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(c_host, n.c, 2 * B * H * 4, hipMemcpyDeviceToHost));
     for (size_t l = 0; l < 2; ++l)
         for (size_t b = 0; b < B; ++b) {
-            const float* src = h.data() + (l * 2 + (steps[b] & 1)) * Bp * H;
+            const float* src = h.data() + (l * RC_HBUF + (steps[b] % RC_HBUF)) * Bp * H;
             for (size_t e = 0; e < H; ++e) h_host[(l * B + b) * H + e] = src[rc_pk((long long)b, (int)e, (int)H)];
         }
     return RC_OK;

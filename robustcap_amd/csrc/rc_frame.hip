@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
     // L181-183: rnn2 state <- init_net(j3dr); takes effect from the next frame
     if (flags & RC_ROW_REACH) {
-        const int cur = (wt.on ? fb.wsteps[row] : fb.steps2[row]) & 1;      // parity of the rnn2 step this frame took
+        const int cur = (wt.on ? fb.wsteps[row] : fb.steps2[row]) % RC_HBUF;   // copy the rnn2 step of this frame wrote
         const float* src = fb.init_out + row * 2048;
         for (int e = lane; e < 512; e += 64) {
             fb.h2[cur * fb.h2_par_stride + rc_pk(row, e, 512)] = src[e];
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 struct ResetArgs {
     float* h[6];
     float* c[6];
-    long long h_elems[6];   // elements of h per (layer, parity) = round_up(B, 32) * H   (rc_pk order)
+    long long h_elems[6];   // elements of h per (layer, copy) = round_up(B, 32) * H   (rc_pk order)
     long long c_elems[6];   // elements of c per layer = B * H                            (row-major)
     int H[6];
 };
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void rc_reset_kernel(FrameBuffers fb, ResetArg
         const int H = a.H[n];
         for (int e = threadIdx.x; e < H; e += 256) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a.h[n][q * a.h_elems[n] + rc_pk(row, e, H)] = 0.0f;   // 2 layers x 2 parities
+            for (int q = 0; q < 2 * RC_HBUF; ++q) a.h[n][q * a.h_elems[n] + rc_pk(row, e, H)] = 0.0f;   // 2 layers x RC_HBUF copies
             a.c[n][(long long)row * H + e] = 0.0f;
             a.c[n][a.c_elems[n] + (long long)row * H + e] = 0.0f;
         }

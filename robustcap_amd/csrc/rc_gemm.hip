@@ -306,7 +306,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #pragma unroll
         for (int sgi = 0; sgi < 2; ++sgi) {
             const GemmSeg& sg = P.seg[sgi];
-            const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) & 1) : (sg.par_mode == RC_PAR_DST ? (st & 1) : 0);
+            const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) % RC_HBUF) : (sg.par_mode == RC_PAR_DST ? (st % RC_HBUF) : 0);
             const float* base = sg.base;
             if (sgi == 0 && P.sel_bit && !(P.sel_flags[row] & P.sel_bit)) base = P.alt_base;
             pp[sgi] = base + (long long)par * sg.par_stride + rc_pk(row, 4 * kq, sg.ld);
@@ -470,7 +470,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             for (int w = 1; w < RC_NW; ++w) g4 += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + 4 * u]);
             g4 += *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * u]);
             const int r2 = s_rows[rr];
-            const int dst = (st_row[k] + P.step_off) & 1;
+            const int dst = (st_row[k] + P.step_off) % RC_HBUF;
             const long long ci = (long long)r2 * P.H + unit;
             const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]);
             const float gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);

@@ -14,6 +14,9 @@
 #endif
 #define RC_KC 16          // k per chunk: one dwordx4 (4 consecutive k) per lane per operand block
 #define RC_KALIGN 128     // padded K granularity (>= 2 * RC_KC * RC_NW: an even number of chunks per wave)
+#define RC_HBUF 3          // copies of every hidden state h: step s writes copy s % 3 and reads copy (s - 1) % 3. Two would do for the
+                           // recurrence; the third lets the first wide launch of a wavefront tick (which writes copy (s + 2) % 3)
+                           // start while linear2 of the previous tick -- second stream -- still reads copy s % 3
 #define RC_MAX_PROB 14    // problems fused in one launch (GemmLaunch travels as a kernel argument: 14 x 232 B = 3.2 KB; no scratch copy: checked in the ISA)
 
 // Every GEMM A operand (sub-net inputs, relu(linear1), hidden states) is stored in MFMA A-fragment order so that a
@@ -45,7 +48,7 @@ enum { RC_PAR_NONE = 0, RC_PAR_SRC = 1, RC_PAR_DST = 2 };
 
 struct GemmSeg {
     const float* base;      // activation matrix [rows, ld] in rc_pk order
-    long long par_stride;   // elements between the two parity copies (0 if not double-buffered)
+    long long par_stride;   // elements between the RC_HBUF copies (0 if not multi-buffered)
     int ld;
     int K;                  // padded length of this K segment (multiple of RC_KALIGN; 0 = absent)
     int par_mode;           // RC_PAR_*
@@ -60,7 +63,7 @@ struct GemmProblem {
     float* out;             // dense: out[row * ldo + col0 + n], or rc_pk(row, col0 + n, ldo) if out_packed
     float* hstate;          // lstm: h[parity][row][H]
     float* cstate;          // lstm: c[row][H]
-    int* steps;             // per-row step counter of this net (parity = steps & 1)
+    int* steps;             // per-row step counter of this net (copy = steps % RC_HBUF)
     const unsigned char* flags;
     const float* alt_base;  // seg[0] of rows WITHOUT sel_bit in sel_flags reads here (deferred updater input)
     const unsigned char* sel_flags;

@@ -157,3 +157,24 @@ def test_row_strided_inputs_need_no_copy(synth_assets):
         torch.cuda.synchronize()
         outs.append((p, tr))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_very_long_calls_are_planned_in_pieces(synth_assets, monkeypatch):
+    """rc_sequence plans calls of more than RC_SEQ_MAX_PLAN_FRAMES (4,096) frames piece by piece (one drain and one read-back
+    per piece); with the limit shrunk to 24 frames a 100-frame call is five pieces -- same bits as one plan."""
+    import bench
+    B, T = 48, 100
+    m = bench.make_inputs(synth_assets["body"], B, T, "mixed", seed=11)
+    outs = []
+    for limit in ("24", "4096"):
+        monkeypatch.setenv("RC_SEQ_MAX_PLAN_FRAMES", limit)
+        net = _net(synth_assets, B, True)
+        net.gravityc = t(m["gravityc"])
+        p, tr = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_tran=t(m["first_tran"]))
+        torch.cuda.synchronize()
+        outs.append((p, tr, net.sequence_stats(), net.get_state("rnn4"), net.get_state("rnn6")))
+    (pa, ta, sa, a4, a6), (pb, tb, sb, b4, b6) = outs
+    assert torch.equal(pa, pb) and torch.equal(ta, tb)
+    assert torch.equal(a4[0], b4[0]) and torch.equal(a6[1], b6[1])
+    assert sb[0] == T - 1 and sa[0] + sa[1] == T and sa[1] <= 1 + 7              # (a last piece shorter than min_frames is frame-stepped)
+    assert sa[2] > sb[2] + 2 * 8                                                 # every piece drains its pipeline
