@@ -123,6 +123,7 @@ struct rc_ctx {
     // sequence mode of rc_sequence: launch planner + per-row-cursor wavefront engine (run_wave2_segment)
     bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
     bool live_launch = false;            // set while a live frame is captured / launched (GemmLaunch.live)
+    unsigned live_nt_mask = 63u;         // sub-nets (bit = kNets index) whose weights a live frame streams with non-temporal loads
     int seq_mode = 1;                    // 0 = always frame-stepped, 1 = plan per call (cost estimate), 2 = wavefront whenever long enough
     int seq_min_frames = 8;              // calls shorter than this are neither planned nor skewed (no pre-pass, no synchronisation)
     float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
@@ -339,6 +340,7 @@ GemmProblem lin1_problem(const rc_ctx* c, const Stage& s) {
     }
     if (s.rows_hint >= 0 && s.rows_hint < c->B) p.m_tiles = (s.rows_hint + 16 * p.mr - 1) / (16 * p.mr);
     p.alt_base = s.x_alt; p.sel_flags = c->fb.flags; p.sel_bit = s.x_alt ? s.sel_bit : 0;
+    p.nt = (c->live_nt_mask >> s.net) & 1u;
     return p;
 }
 GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
@@ -366,6 +368,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
     }
     const int rows = s.rows_hint < 0 ? c->B : (s.rows_hint < c->B ? s.rows_hint : c->B);
     p.n_tiles = n.H / (4 * nc); p.m_tiles = (rows + 16 * mr - 1) / (16 * mr); p.Kp = 2 * n.H; p.nc = nc; p.mr = mr;
+    p.nt = (c->live_nt_mask >> s.net) & 1u;
     return p;
 }
 GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
@@ -374,6 +377,7 @@ GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     GemmProblem p = dense_problem(c, n.lin2, seg(n.h + RC_HBUF * BH, n.H, 0, RC_PAR_DST, BH), s.y, false, s.flag_bit,
                                   s.flags ? s.flags : c->fb.flags, n.steps, false);
     p.out_flags = c->fb.flags; p.out_bit = s.out_bit;
+    p.nt = 1;
     return p;
 }
 
@@ -754,8 +758,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // the plan's table: frame every row starts at every tick
     const size_t need = (size_t)P.n_prep * B;
     if (need > ctx->frame_at_cap) {
-        if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
-    if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
+        HIP_TRY(ctx, hipStreamSynchronize(st));                             // nothing in flight may still read the old table
+        if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
         if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
         ctx->frame_at_d = nullptr; ctx->frame_at_h = nullptr; ctx->frame_at_cap = 0;
         const size_t cap = need + need / 4 + 4096;
@@ -965,6 +969,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     rc_default_params(live, &ctx->prm);
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0;
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
+    ctx->live_nt_mask = (unsigned)tune_env("RC_LIVE_NT_MASK", 63);
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
@@ -1034,6 +1039,7 @@ int rc_destroy(rc_ctx* ctx) {
     if (ctx->scan_codes_d) (void)hipFree(ctx->scan_codes_d);
     if (ctx->scan_codes_h) (void)hipHostFree(ctx->scan_codes_h);
     if (ctx->scan_state_h) (void)hipHostFree(ctx->scan_state_h);
+    if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
     if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
     if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -616,8 +616,14 @@ __device__ __forceinline__ void small_tiles(const GemmLaunch& L, float* s_mem) {
     int pi, m_tile, n_tile;
     if (!locate_tile(L, pi, m_tile, n_tile)) return;
     const GemmProblem& P = L.p[pi];
-    if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT, true, NTW>(P, L.B, m_tile, n_tile, s_mem);
-    else gemm_tile<1, 1, 8, true, SPLIT, true, NTW>(P, L.B, m_tile, n_tile, s_mem);
+    if constexpr (NTW) {       // per problem: weights that should stay in the Infinity Cache for the next frame use ordinary loads
+        if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT, true, true>(P, L.B, m_tile, n_tile, s_mem);
+        else if (P.nt) gemm_tile<1, 1, 8, true, SPLIT, true, true>(P, L.B, m_tile, n_tile, s_mem);
+        else gemm_tile<1, 1, 8, true, SPLIT, true, false>(P, L.B, m_tile, n_tile, s_mem);
+    } else {
+        if (P.nc == 2) gemm_tile<1, 2, 4, true, SPLIT, true, false>(P, L.B, m_tile, n_tile, s_mem);
+        else gemm_tile<1, 1, 8, true, SPLIT, true, false>(P, L.B, m_tile, n_tile, s_mem);
+    }
 }
 __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];

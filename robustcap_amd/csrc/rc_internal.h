@@ -79,6 +79,7 @@ struct GemmProblem {
     int nc;                 // 16-column blocks per tile
     int mr;                 // 16-row blocks per tile (2 or 4); (mr, nc) must be one of the instantiated shapes
     int trace_base;         // first record slot of this launch (read by -DRC_TRACE_TILES builds only)
+    int nt;                 // live frames: stream THIS problem's weights with non-temporal loads (rc_gemm_small_nt_kernel)
     int step_off;           // added to steps[row] wherever the step parity is formed. Frame-stepped launches: 0 (linear1
                             // has already incremented the counter). Sequence mode: 1 + (frame - first frame of the
                             // segment), with open_step = 0: the counters stand still while stages of several frames are in
