@@ -19,6 +19,29 @@ def _free_port():
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
+def _spawn(fn, args, nprocs, budget_s=240):
+    """mp.spawn with a deadline and ONE retry on a fresh port: a rendezvous that never completes (port stolen between
+    _free_port() and the bind, a starved host) must not hang the CPU suite. args[1] is the port."""
+    import time
+    for attempt in range(2):
+        ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+        t0 = time.time()
+        done = False
+        while time.time() - t0 < budget_s:
+            if ctx.join(timeout=1.0):
+                done = True
+                break
+        if done:
+            return
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.terminate()
+        for pr in ctx.processes:
+            pr.join(10)
+        args = (args[0], _free_port()) + tuple(args[2:])
+    raise RuntimeError("gloo workers did not finish within the deadline (twice)")
+
+
 
 def _run_rows(sd, body, m, a, b, T):
     from oracle import sig_mp_oracle as O
@@ -73,7 +96,7 @@ def _worker(rank, world, port, B, T, out_dir):
 def test_sharded_equals_unsharded_world2(tmp_path):
     B, T, world = 3, 4, 2                                    # uneven shards: 2 + 1 rows
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, B, T, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, (world, port, B, T, str(tmp_path)), world)
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     m = synth.make_motion(44, B, T, body, conf="mixed")
     ref_p, ref_t = [], []

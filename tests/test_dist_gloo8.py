@@ -22,6 +22,29 @@ def _free_port():
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
+def _spawn(fn, args, nprocs, budget_s=240):
+    """mp.spawn with a deadline and ONE retry on a fresh port: a rendezvous that never completes (port stolen between
+    _free_port() and the bind, a starved host) must not hang the CPU suite. args[1] is the port."""
+    import time
+    for attempt in range(2):
+        ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+        t0 = time.time()
+        done = False
+        while time.time() - t0 < budget_s:
+            if ctx.join(timeout=1.0):
+                done = True
+                break
+        if done:
+            return
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.terminate()
+        for pr in ctx.processes:
+            pr.join(10)
+        args = (args[0], _free_port()) + tuple(args[2:])
+    raise RuntimeError("gloo workers did not finish within the deadline (twice)")
+
+
 
 def _dataset(body):
     ds = synth.make_dataset(31, N_SEQ, T + 1, body, n_cam=N_CAM, conf="mixed")
@@ -77,7 +100,7 @@ def _worker(rank, world, port, out_dir):
 
 def test_config3_partition_72_rows_over_8_ranks(tmp_path):
     port = _free_port()
-    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    _spawn(_worker, (WORLD, port, str(tmp_path)), WORLD)
     got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(WORLD)]
     for r in range(1, WORLD):                                           # every rank holds the same full result
         assert torch.equal(got[0][0], got[r][0]) and torch.equal(got[0][1], got[r][1])
