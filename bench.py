@@ -167,10 +167,12 @@ class Workload:
         self.sync()
         t0 = time.perf_counter()
         if world > 1:
-            # The path's only exchange: the outputs go to rank 0 (RCCL over xGMI). The K steps are enqueued in 4 chunks
-            # and each chunk's gather starts as soon as its kernels are queued, so all but the last transfer hide
-            # behind compute. Row blocks may differ by one row under strong scaling: gather_rows pads.
-            edges = [W + (K * c) // 4 for c in range(5)]
+            # The path's only exchange: the outputs go to rank 0 (RCCL over xGMI). The K steps are enqueued in up to 4 chunks
+            # of at least 16 frames (a chunk is one planned rc_sequence call: shorter ones would fall back to the
+            # frame-stepped launches) and each chunk's gather starts as soon as its kernels are queued, so all but the last
+            # transfer hide behind compute. Row blocks may differ by one row under strong scaling: gather_rows pads.
+            n_chunks = max(1, min(4, K // 16))
+            edges = [W + (K * c) // n_chunks for c in range(n_chunks + 1)]
             parts = []
             for ci, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
                 if hi > lo:
