@@ -780,9 +780,10 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     static const bool merge_big = tune_env("RC_SEQ_MERGE_BIG", 1) != 0;
     const int last_group = merge_h512 ? 2 : 3;
     static const bool late_wait = tune_env("RC_SEQ_LATE_WAIT", 1) != 0;
+    static const bool merge_fill = tune_env("RC_SEQ_MERGE_FILL", 0) != 0;    // measured: 20-frame calls 907-914k with, 918-925k without
     auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
     static const bool ext_events = tune_env("RC_SEQ_EXT_EVENTS", 1) != 0;   // tick hand-over events carried by the last dispatch itself (+0.5 %)
-    auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {   // problems of group g with rows at tick k
+    auto collect = [&](int k, int g) -> std::vector<GemmProblem> {            // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
             const int q = (merge_big && qi < 4) ? (qi ^ 2) : qi;               // rnn6 (kTick 2, 3) in front of rnn4 (0, 1): longest tiles first
@@ -832,7 +833,10 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
                 for (GemmProblem& p : ps)
                     if (p.epi == RC_EPI_LSTM && p.mr == 4 && p.nc == 8) { p.nc = 4; p.n_tiles *= 2; }
         }
-        return launch_problems(ctx, ps, nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
+        return ps;
+    };
+    auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {
+        return launch_problems(ctx, collect(k, g), nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
     };
     WavePrep wp{};
     for (int i = 0; i < 6; ++i) wp.steps[i] = ctx->net[i].steps;
@@ -870,12 +874,30 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         // the second stream, still reads -- is what the third copy is for (RC_HBUF).
         bool init_now = false;
         for (int q = W2_INIT0; q < W2_PROB; ++q) init_now = init_now || cnt(P.n_reach, k - w2_stage(q)) > 0;
-        const bool late = late_wait && merge_h512 && !init_now;
-        if (two && k > 0 && !late) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-        bool main_signalled = false;
+        std::vector<GemmProblem> gp[4];
+        size_t n_prob = 0;
+        long long n_tiles = 0;
         for (int g = 0; g <= last_group; ++g) {
-            if (two && k > 0 && late && g == last_group) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-            if (int rc = group(k, g, st, (g == last_group && two && ext_events) ? ctx->ev_main[e] : nullptr, g == last_group ? &main_signalled : nullptr)) return rc;
+            gp[g] = collect(k, g);
+            n_prob += gp[g].size();
+            for (const GemmProblem& p : gp[g]) n_tiles += (long long)p.n_tiles * p.m_tiles;
+        }
+        bool main_signalled = false;
+        hipEvent_t stop_ev = (two && ext_events) ? ctx->ev_main[e] : nullptr;
+        if (merge_fill && n_prob > 0 && n_prob <= RC_MAX_PROB && n_tiles <= 512) {
+            // a filling / draining tick (or one of lagging rows): everything fits two rounds of one launch -- no boundary at all, but
+            // the stream wait is back in front of the tick's first launch: a wash (off by default)
+            if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            std::vector<GemmProblem> all;
+            for (int g = 0; g <= last_group; ++g) all.insert(all.end(), gp[g].begin(), gp[g].end());
+            if (int rc = launch_problems(ctx, all, nullptr, st, false, stop_ev, &main_signalled)) return rc;
+        } else {
+            const bool late = late_wait && merge_h512 && !init_now;
+            if (two && k > 0 && !late) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            for (int g = 0; g <= last_group; ++g) {
+                if (two && k > 0 && late && g == last_group) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+                if (int rc = launch_problems(ctx, gp[g], nullptr, st, false, g == last_group ? stop_ev : nullptr, g == last_group ? &main_signalled : nullptr)) return rc;
+            }
         }
         if (two && !main_signalled) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], st));
         ctx->stat_ticks += 1;
