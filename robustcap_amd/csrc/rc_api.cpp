@@ -684,7 +684,16 @@ int ensure_wave2_buffers(rc_ctx* ctx) {
     }
     for (int i = 0; i < 6; ++i)
         if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    {
+        // RC_SEQ_AUX_PRIO: -1 lowest / +1 highest queue priority for the second stream (0: default) -- its short kernels share the
+        // CUs with the wide tiles of the caller's stream
+        const int want = tune_env("RC_SEQ_AUX_PRIO", 0);
+        int lo = 0, hi = 0;
+        if (want != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, want < 0 ? lo : hi));
+        else
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    }
     for (int i = 0; i < 8; ++i) {
         // device-scope release: the hand-over is between two streams of this GPU
         const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;

@@ -122,15 +122,30 @@ __device__ __forceinline__ void bone_chain(const BodyConst* body, const float (*
     }
 }
 
+// Block-wide barrier, or -- in kernels that give every row its own wave AND its own LDS scratch (several rows per workgroup) --
+// a wave-local one: the LDS operations of one wave execute in issue order, so all that is needed is that the compiler keeps
+// them in program order across this point.
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void rc_sync() {
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // ParametricModel.forward_kinematics(calc_mesh=True) restricted to 33 landmarks + sync_mp3d
 // (articulate/model.py:229-241, net/sig_mp.py:287-299). Expects s.Rl filled and synced; one wave.
+template <bool WAVE_LOCAL = false>
 __device__ __forceinline__ void wave_body_fk(const BodyConst* body, WaveScratch& s, const float* tran, int lane) {
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) s.G[0][k] = s.Rl[0][k];
         s.P[0][0] = s.P[0][1] = s.P[0][2] = 0.0f;
     }
-    __syncthreads();
+    rc_sync<WAVE_LOCAL>();
     const int lvl = lane < 24 ? body->level[lane] : -1;
     for (int l = 1; l < 10; ++l) {
         if (lvl == l) {
@@ -143,7 +158,7 @@ __device__ __forceinline__ void wave_body_fk(const BodyConst* body, WaveScratch&
 #pragma unroll
             for (int k = 0; k < 3; ++k) s.P[lane][k] = pb[k] + s.P[p][k];
         }
-        __syncthreads();
+        rc_sync<WAVE_LOCAL>();
     }
     if (lane < 24) {
         float gj[3];
@@ -151,7 +166,7 @@ __device__ __forceinline__ void wave_body_fk(const BodyConst* body, WaveScratch&
 #pragma unroll
         for (int k = 0; k < 3; ++k) s.T[lane][k] = s.P[lane][k] - gj[k];
     }
-    __syncthreads();
+    rc_sync<WAVE_LOCAL>();
     if (lane < 33) {
         float out[3];
         const int oj = body->override_joint[lane];
@@ -180,7 +195,7 @@ __device__ __forceinline__ void wave_body_fk(const BodyConst* body, WaveScratch&
 #pragma unroll
         for (int k = 0; k < 3; ++k) s.J33[lane][k] = out[k];
     }
-    __syncthreads();
+    rc_sync<WAVE_LOCAL>();
 }
 
 // bbox-normalised keypoints of lane `lane` (< 33): xy / max(width, height), rows != 23 relative to row 23.

@@ -12,6 +12,7 @@
 // bandwidth-bound, which is why they are kept to three launches.
 #include "rc_internal.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 #define LD_X2 128
 #define LD_X3 256
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(64) void rc_prep_kernel(FrameBuffers fb, FrameIO io
 // that the stages of several frames of a row can be in flight while the row's counters move on. On the first tick of a
 // segment a deferred updater step left pending by the frames before it (fb.pend) becomes a rider of this slot: its inputs are
 // copied from the context's own buffers and the row joins the slot's rnn4 / rnn6 launches (net/sig_mp.py:264-271).
-__global__ __launch_bounds__(64) void rc_prep_wave_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, WavePrep w) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+// Four rows per workgroup, a wave each (no LDS, no barrier): the kernel runs beside the wide GEMM tiles, whose 512-register waves
+// need a whole CU -- a one-wave workgroup parked on one SIMD keeps the other three idle and the next tile waiting.
+template <int RPB>
+__global__ __launch_bounds__(64 * RPB) void rc_prep_wave_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B, WavePrep w) {
+    const int row = blockIdx.x * RPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
     const int f = w.frame_at[row];
     const bool rider = w.first_tick && prm.use_vision_updater && fb.pend[row] != 0;
     unsigned fl = 0;
@@ -225,12 +230,26 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
 // kernels are back to back on the stream anyway, and the row's state they share travels in registers.
 // wt.on: ring slot of the per-row-cursor engine -- the row's frame index comes from the slot (bubbles exit), and the vision
 // updater's inputs go to the slot that starts at this tick (see WaveTail).
-__global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
-                                                     const BodyConst* __restrict__ body_g, int B, int first_frame, FrameIO io_next,
-                                                     int has_next, WaveTail wt) {
-    __shared__ WaveScratch s;
+// RPB rows per workgroup, a wave each. 1: the frame-stepped launches (256 workgroups spread over the chip: shortest latency).
+// 4: the wavefront engine, where the kernel runs beside the wide GEMM tiles (see rc_prep_wave_kernel); the body constants are
+// staged once per workgroup behind its only block-wide barrier, after which the rows are independent (own wave, own scratch,
+// wave-local synchronisation) and a bubble row's wave simply leaves.
+template <int RPB>
+__global__ __launch_bounds__(64 * RPB) void rc_tail_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm,
+                                                           const BodyConst* __restrict__ body_g, int B, int first_frame, FrameIO io_next,
+                                                           int has_next, WaveTail wt) {
+    constexpr bool WL = RPB > 1;
+    __shared__ WaveScratch s_all[RPB];
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
-    const int row = blockIdx.x, lane = threadIdx.x;
+    const int row = blockIdx.x * RPB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    WaveScratch& s = s_all[threadIdx.x >> 6];
+    if constexpr (WL) {
+        BodyStage<64 * RPB> bsa;
+        bsa.load(body_g, threadIdx.x);
+        bsa.store(&s_body, threadIdx.x);
+        __syncthreads();
+        if (row >= B) return;
+    }
     int frame = 0;
     if (wt.on) {
         frame = fb.frame[row];
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     // as wave-uniform reads they would be scalar loads, each waiting for the previous one (s_waitcnt lgkmcnt(0)).
     // The state reads are safe to hoist: only this wave writes its row.
     BodyStage<64> bst;
-    bst.load(body_g, lane);
+    if constexpr (!WL) bst.load(body_g, lane);
     const float* ori = io.ori + row * io.s_ori;
     const float* acc = io.acc + row * io.s_acc;
     const bool ft_given = io.first_tran != nullptr;
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     const float acc_l = lane < 18 ? acc[lane] : 0.f, ori_l = lane < 54 ? ori[lane] : 0.f;   // this frame's IMU data (updater inputs)
     PrepIn nin;
     if (has_next) prep_load(nin, io_next, row, lane);
-    bst.store(&s_body, lane);                                             // (LDS: visible to the wave after the first barrier)
+    if constexpr (!WL) bst.store(&s_body, lane);                          // (LDS: visible to the wave after the first barrier)
     const BodyConst* body = &s_body;
     float lpf[6], ltr[3], g[3], pc[3], vr[3], flr[6][3], Rcr[9], ftr[3];
 #pragma unroll
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
 #pragma unroll
         for (int k = 0; k < 9; ++k) s.Rg[lane][k] = R[k];
     }
-    __syncthreads();
+    rc_sync<WL>();
     // L174-175: local rotations, root replaced by the pelvis IMU orientation
     if (lane < 24) {
         float R[9];
@@ -410,7 +429,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     const bool refresh = !live || uvc == 0;
     const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
     const int pend_next = ((flags & RC_ROW_UPD) && !wave_ride) ? 1 : 0;
-    __syncthreads();   // all lanes have read the per-row state; lane 0 may now overwrite it
+    rc_sync<WL>();   // all lanes have read the per-row state; lane 0 may now overwrite it
     if (lane == 0) {                                                       // L227, L273
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
     }
 
     // L228-242: mesh landmarks from the LOCAL pose chained from the camera-frame root
-    wave_body_fk(body, s, tran, lane);
+    wave_body_fk<WL>(body, s, tran, lane);
     if (live && (prm.use_reproj_opt || prm.use_vision_updater)) {
         if (lane < 33) {
 #pragma unroll
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
                 else s.J33[lane][c] = fb.j_temp[row * 99 + 3 * lane + c];
             }
         }
-        __syncthreads();
+        rc_sync<WL>();
     }
 
     // L245-261 (use_reproj_opt, default off): closed-form refinement of the translation from the 2D residual
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(64) void rc_tail_kernel(FrameBuffers fb, FrameIO io
         const float dz = bz / az;
         tran[0] = (tran[0] + dx) + 0.0f; tran[1] = (tran[1] + dy) + 0.0f; tran[2] = (tran[2] + 0.0f) + dz;
         if (on) { s.J33[lane][0] = jx; s.J33[lane][1] = jy; s.J33[lane][2] = (jz + 0.0f) + dz; }
-        __syncthreads();
+        rc_sync<WL>();
     }
     if (lane == 0) {                                                       // L273 (after the optional refinement)
 #pragma unroll
@@ -692,42 +711,6 @@ __global__ __launch_bounds__(128) void rc_camera_inputs_rows_kernel(const float*
     }
 }
 
-// Full-mesh linear-blend skinning (articulate/model.py:235-241): one workgroup per frame; wave 0 chains the 24 joint
-// transforms into LDS, then all 256 threads sweep the V vertices (blend the 3x4 transforms, then apply). HBM-bound
-// sweep: 12 B out per vertex; v_template (83 KB) and the [V,24] weights (661 KB) stay in L2 across frames.
-__global__ __launch_bounds__(256) void rc_body_mesh_kernel(const BodyConst* __restrict__ body, const float* __restrict__ vt,
-                                                           const float* __restrict__ w, int V, const float* pose,
-                                                           const float* tran, float* vert) {
-    __shared__ WaveScratch s;
-    const long long b = blockIdx.x;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 216; e += 256) s.Rl[e / 9][e % 9] = pose[b * 216 + e];
-    const float t[3] = {tran[b * 3], tran[b * 3 + 1], tran[b * 3 + 2]};
-    __syncthreads();
-    // wave_body_fk synchronises with __syncthreads: every wave runs it (lanes >= 64 do no joint work)
-    wave_body_fk(body, s, t, tid < 64 ? tid : 64);
-    for (int v = tid; v < V; v += 256) {
-        float A[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) A[k] = 0.0f;
-        const float* wv = w + (long long)v * 24;
-        for (int j = 0; j < 24; ++j) {
-            const float wj = wv[j];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                A[4 * r + 0] += wj * s.G[j][3 * r + 0];
-                A[4 * r + 1] += wj * s.G[j][3 * r + 1];
-                A[4 * r + 2] += wj * s.G[j][3 * r + 2];
-                A[4 * r + 3] += wj * s.T[j][r];
-            }
-        }
-        const float x = vt[3 * v] - body->jroot[0], y = vt[3 * v + 1] - body->jroot[1], z = vt[3 * v + 2] - body->jroot[2];
-        float* o = vert + (b * V + v) * 3;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) o[r] = (((A[4 * r] * x + A[4 * r + 1] * y) + A[4 * r + 2] * z) + A[4 * r + 3]) + t[r];
-    }
-}
-
 // smplify forward residual: conf^2 * sum_xy gmof(K (j/z) - kp), sigma^2 d^2 / (sigma^2 + d^2)
 // (net/smplify/losses.py:6-12, 36-37, 43-46; ignored landmarks temporal_smplify.py:92,204)
 __global__ __launch_bounds__(64) void rc_residual_kernel(const BodyConst* __restrict__ body, const float* pose, const float* tran,
@@ -797,6 +780,12 @@ __global__ void rc_advance_steps_kernel(StepPtrs sp, int n_frames, int B) {
 }
 
 // ================================================================================================ launchers
+// rows per workgroup of the wavefront engine's per-row kernels (RC_SEQ_ROWS_PER_WG = 1: one-wave workgroups, A/B runs)
+static int rc_wave_rows_per_wg() {
+    static const int v = [] { const char* e = std::getenv("RC_SEQ_ROWS_PER_WG"); return (e && std::atoi(e) == 1) ? 1 : 4; }();
+    return v;
+}
+
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes,
                          hipStream_t st) {
     const long long items = (long long)B * T;
@@ -823,15 +812,21 @@ void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
 }
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
                     int first_frame, hipStream_t st, const FrameIO* io_next, const WaveTail* wt, hipEvent_t stop) {
-    if (stop)
-        hipExtLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, nullptr, stop, 0, fb, io, prm, body, B, first_frame, io_next ? *io_next : io,
-                              io_next ? 1 : 0, wt ? *wt : WaveTail{});
-    else
-        hipLaunchKernelGGL(rc_tail_kernel, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, io_next ? *io_next : io, io_next ? 1 : 0,
-                           wt ? *wt : WaveTail{});
+    const WaveTail w = wt ? *wt : WaveTail{};
+    const FrameIO nx = io_next ? *io_next : io;
+    const int has_next = io_next ? 1 : 0;
+    if (w.on && rc_wave_rows_per_wg() == 4) {              // wavefront engine: four rows per workgroup
+        const dim3 g((B + 3) / 4), b(256);
+        if (stop) hipExtLaunchKernelGGL(rc_tail_kernel<4>, g, b, 0, st, nullptr, stop, 0, fb, io, prm, body, B, first_frame, nx, has_next, w);
+        else hipLaunchKernelGGL(rc_tail_kernel<4>, g, b, 0, st, fb, io, prm, body, B, first_frame, nx, has_next, w);
+    } else {
+        if (stop) hipExtLaunchKernelGGL(rc_tail_kernel<1>, dim3(B), dim3(64), 0, st, nullptr, stop, 0, fb, io, prm, body, B, first_frame, nx, has_next, w);
+        else hipLaunchKernelGGL(rc_tail_kernel<1>, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, nx, has_next, w);
+    }
 }
 void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t st) {
-    hipLaunchKernelGGL(rc_prep_wave_kernel, dim3(B), dim3(64), 0, st, slot, io0, prm, B, w);
+    if (rc_wave_rows_per_wg() == 4) hipLaunchKernelGGL(rc_prep_wave_kernel<4>, dim3((B + 3) / 4), dim3(256), 0, st, slot, io0, prm, B, w);
+    else hipLaunchKernelGGL(rc_prep_wave_kernel<1>, dim3(B), dim3(64), 0, st, slot, io0, prm, B, w);
 }
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t st) {
@@ -876,11 +871,6 @@ void rc_launch_body_fk(const BodyConst* body, const float* pose, const float* tr
                        long long n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(rc_body_fk_kernel, dim3((unsigned)n), dim3(64), 0, st, body, pose, tran, grot, joint, j33);
-}
-void rc_launch_body_mesh(const BodyConst* body, const float* vt, const float* w, int V, const float* pose, const float* tran,
-                         float* vert, long long n, hipStream_t st) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(rc_body_mesh_kernel, dim3((unsigned)n), dim3(256), 0, st, body, vt, w, V, pose, tran, vert);
 }
 void rc_launch_residual(const BodyConst* body, const float* pose, const float* tran, const float* kp, const float* K, float sigma,
                         unsigned long long ign_mask, float* loss, long long T, hipStream_t st) {

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void rc_imu_frame_kernel(const BodyConst* __res
 #pragma unroll
         for (int c = 0; c < 3; ++c) joint[(b * 24 + lane) * 3 + c] = s.P[lane][c] + t[c];
     }
-    if (lane < 6) {                                                   // same arithmetic as rc_body_mesh_kernel
+    if (lane < 6) {                                                   // same arithmetic as the full-mesh sweep (rc_metrics.hip)
         const int v = pick.vid[lane];
         float A[12];
 #pragma unroll
