@@ -120,10 +120,14 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef RC_SPLIT_W32
+#define RC_SPLIT_W32 0        // 1: the weights stream as fp32 too (the fp32 packing, 4 B instead of 6 B per weight) and are split in the K
+#endif                        // loop like the activations: fewer operand bytes per MFMA for 36 more VALU per column block and k-block
+#define RC_WPL (RC_SPLIT_W32 ? 2 : 3)          // 1-KiB pieces per column block and k-block: two fp32 chunks, or three bf16 planes
 template <int MR, int NC>
 struct FragS {                // one k-block (32 k): fp32 activations (two float4 per row block), three weight planes per column block
     f32x4 a0[MR], a1[MR];
-    u32x4 b[NC][3];
+    u32x4 b[NC][RC_WPL];
 };
 
 template <int MR, int NC>
@@ -143,7 +147,7 @@ __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+        for (int p = 0; p < RC_WPL; ++p) f.b[j][p] = pb[j * bstride + p * 64];
 }
 
 // a = hi + mid + lo exactly; each output packs 8 bf16 (element e in the low / high half of dword e / 2).
@@ -172,7 +176,7 @@ __device__ __forceinline__ void load_kblock_b(FragS<MR, NC>& f, const u32x4* pb,
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+        for (int p = 0; p < RC_WPL; ++p) f.b[j][p] = pb[j * bstride + p * 64];
 }
 template <int MR, int NC>
 __device__ __forceinline__ void load_kblock_a(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff) {
@@ -185,6 +189,15 @@ __device__ __forceinline__ void load_kblock_a(FragS<MR, NC>& f, const float* con
 
 template <int MR, int NC>
 __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[MR][NC]) {
+    u32x4 wp[3][NC];              // the column blocks' planes: hi, mid, lo
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+#if RC_SPLIT_W32
+        split3(__builtin_bit_cast(f32x4, f.b[j][0]), __builtin_bit_cast(f32x4, f.b[j][1]), wp[0][j], wp[1][j], wp[2][j]);
+#else
+        wp[0][j] = f.b[j][0]; wp[1][j] = f.b[j][1]; wp[2][j] = f.b[j][2];
+#endif
+    }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         u32x4 uh, um, ul;
@@ -197,7 +210,7 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
         // small terms first; consecutive MFMAs go to different accumulators (NC of them between two uses of one)
 #define RC_PROD(AV, PL)                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < NC; ++j)                                                                        \
-        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AV, __builtin_bit_cast(bf16x8, f.b[j][PL]), acc[r][j], 0, 0, 0);
+        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AV, __builtin_bit_cast(bf16x8, wp[PL][j]), acc[r][j], 0, 0, 0);
 #if RC_SPLIT_PRODUCTS == 9
         RC_PROD(al, 2) RC_PROD(am, 2) RC_PROD(al, 1)
 #endif
@@ -291,12 +304,13 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     // activation pointers are formed (a tile waits ~3 us for its first weights: profiles/r02_kloop_ablation.txt)
     FragS<MR, NC> fa = {}, fb = {};
     const int Qs = P.Kp / 32, Qws = Qs / RC_NW;                     // k-blocks per wave (K' % 128 == 0 -> >= 1)
-    const long long bs = (long long)Qs * 192;                       // uint4 between consecutive 16-column blocks (3 planes x 64 lanes)
-    const u32x4* pbs = reinterpret_cast<const u32x4*>(P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * 192 + lane;
-    constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 12) * 3 + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
+    constexpr int KBU = RC_WPL * 64;                                // uint4 per column block and k-block (planes, or fp32 chunks, x 64 lanes)
+    const long long bs = (long long)Qs * KBU;                       // uint4 between consecutive 16-column blocks
+    const u32x4* pbs = reinterpret_cast<const u32x4*>(RC_SPLIT_W32 ? (const void*)P.W : P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
+    constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 4 * RC_WPL) * 3 + (RC_SPLIT_W32 ? NC * 12 : 0) + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
     if constexpr (SPLIT && !(RC_ABL_SPLIT & 9)) {
         load_kblock_b<MR, NC>(fa, pbs, bs);
-        if constexpr (DEEP) load_kblock_b<MR, NC>(fb, pbs + (long long)min(1, Qws - 1) * 192, bs);
+        if constexpr (DEEP) load_kblock_b<MR, NC>(fb, pbs + (long long)min(1, Qws - 1) * KBU, bs);
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -352,8 +366,8 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define LOADS(F, QI)                                                                                                \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * 192, bs);              \
-        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * 192, bs);               \
+        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * KBU, bs);              \
+        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * KBU, bs);               \
     } while (0)
         // With the MFMA time cut 2.7x the K loop is bound by what a wave keeps in flight (one k-block = 23 KiB for a 64 x 80
         // tile; 4 waves x 23 KiB / ~2 us of L2 / fabric latency = the 47 GB/s per CU the two-buffer loop was measured at):
