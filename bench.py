@@ -217,12 +217,18 @@ class Workload:
         self.run(W, W + K, W == 0)
         torch.cuda.synchronize()
         ms, launches = net.gemm_timing_read()
+        busy_ms = net.gemm_timing_busy()
         net.gemm_timing(0)
-        if launches <= 0 or ms <= 0:
+        if launches <= 0 or ms <= 0 or busy_ms <= 0:
             raise RuntimeError("no gate-GEMM launch was timed")
         flop_per_launch = B * (C.FLOPS_PER_BODY_FRAME - C.FLOPS_LINEAR2_PER_BODY_FRAME) * K / launches
         avg_s = ms * 1e-3 / launches
-        ach = flop_per_launch / avg_s / 1e12
+        # The wavefront engine issues the two wide launches of a tick on two streams: they share the chip, so a launch's own
+        # duration covers time in which the other one holds part of the CUs. The kernel's rate is its FLOPs over the time during
+        # which it runs at all (union of the launch intervals); the per-launch figure is kept beside it (it is what a rocprofv3
+        # kernel summary shows: avg_launch_us there = avg_launch_us here).
+        ach = flop_per_launch * launches / (busy_ms * 1e-3) / 1e12
+        ach_launch = flop_per_launch / avg_s / 1e12
         path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
         traffic, src = pmc_traffic(B, self.conf)
         issued_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if self.split else PEAK_FP32_MFMA_TFLOPS
@@ -236,11 +242,16 @@ class Workload:
                                  f"(profiles/{src})" if src else
                                  "no PMC pass committed for this batch/schedule (profiles/*pmc_traffic*.json are keyed by batch + conf)"),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches, "launches_per_step": round(launches / K, 2),
+                "busy_ms": round(busy_ms, 3), "concurrency": round(ms / busy_ms, 3),
+                "per_launch": {"achieved": round(ach_launch, 2), "frac": round(ach_launch / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "frac_issued": round(ach_launch / issued_peak, 4)},
                 "flop_per_launch": flop_per_launch,
                 "path_achieved": round(path, 2), "path_frac": round(path / PEAK_FP32_MFMA_TFLOPS, 4),
                 "products": PRODUCTS_SPLIT if self.split else PRODUCTS_FP32,
                 "engine": {"wavefront_frames": wave, "frame_stepped_frames": stepped, "ticks": ticks},
-                "note": "frac: the wide-tile gate-GEMM kernel alone (its algorithmic fp32 FLOPs / its HIP-event time) against the "
+                "note": "frac: the wide-tile gate-GEMM kernel alone (its algorithmic fp32 FLOPs / the HIP-event time during which at "
+                        "least one of its launches runs: the engine's two launches of a tick overlap on two streams, concurrency = sum "
+                        "of the launch durations / that time; per_launch = the same FLOPs over each launch's own duration) against the "
                         "dense fp32-input MFMA peak, the peak of the type the path computes in; frac_issued: the same rate against "
                         "the roof of the instructions the kernel actually issues (split mode: dense bf16 MFMA peak / 6 partial "
                         "products = 416.7 TFLOP/s fp32-equivalent) -- the figure to read as MFMA utilisation; path_frac: whole "

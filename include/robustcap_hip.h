@@ -339,6 +339,9 @@ int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream);
  * launches run on rc_gemm_small_kernel), 0 stops; rc_gemm_timing_read returns total milliseconds and launch count so far. */
 int rc_gemm_timing(rc_ctx* ctx, int32_t enable);
 int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches);
+/* Time (ms) during which at least one of the launches read so far was running: the wavefront engine issues the two wide launches
+ * of a tick on two streams, so their durations overlap and the sum above counts that time twice. Valid after rc_gemm_timing_read. */
+int rc_gemm_timing_busy(rc_ctx* ctx, double* busy_ms);
 
 #ifdef __cplusplus
 }

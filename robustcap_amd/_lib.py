@@ -99,6 +99,7 @@ SIGNATURES = {
     "rc_get_trace": (_I32, [_P, _P, _P]),
     "rc_gemm_timing": (_I32, [_P, _I32]),
     "rc_gemm_timing_read": (_I32, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "rc_gemm_timing_busy": (_I32, [_P, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@
 //        -> tail (fusion logic, FK, landmarks; marks the rows whose updater step is now pending)
 // Independent sub-nets share a launch ("problems" of one gate-GEMM grid). 8-14 kernel launches per frame, no host
 // synchronisation. rc_sequence runs whole calls on the per-row-cursor wavefront engine instead (run_wave2_segment below): the
-// same stages skewed over consecutive ticks and a ring of slots, two merged wide launches per tick.
+// same stages skewed over consecutive ticks and a ring of slots, two merged wide launches per tick (on two streams from 48 rows).
 #include "../../include/robustcap_hip.h"
 #include "rc_internal.h"
 
@@ -29,6 +29,7 @@
 // from ~80 rows (mixed, 256-frame calls, body-frames/s, split vs fp32 MFMA: batch 64 387k vs 428k, 96 633k vs 434k, 128 691k
 // vs 476k, 160 784k vs 595k). 64-row tiles for the FRAME-STEPPED full-batch stages stay tied to 192 rows (below that they
 // leave CUs without a tile).
+#define RC_SPLIT_MAIN_MIN_BATCH 48  // wavefront engine: the tick's two wide launches on two streams from this many rows
 #define RC_SPLIT_MIN_BATCH 80
 #define RC_TILE64_MIN_BATCH 192
 
@@ -119,6 +120,7 @@ struct rc_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double timed_ms = 0.0;
+    double timed_busy_ms = 0.0;          // time with at least one timed launch running (launches on two streams overlap)
     long long timed_launches = 0;
     // sequence mode of rc_sequence: launch planner + per-row-cursor wavefront engine (run_wave2_segment)
     bool gemm_split = false;             // products of every GEMM as split-bf16 partial products (rc_set_gemm_mode)
@@ -130,7 +132,9 @@ struct rc_ctx {
     int tile6[2] = {0, 0}, tile378[2] = {0, 0}, tile2[2] = {0, 0}, tile4[2] = {0, 0};   // LSTM tile shapes of full-batch stages (0 = pick_tile)
     bool seq_two_streams = true;         // tuning: per-row kernels + linear2 on the second stream (else everything on the caller's)
     hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
-    hipEvent_t ev_main[8] = {}, ev_aux[8] = {};
+    hipStream_t h512_stream = nullptr;   // the tick's {H = 512 nets, linear1} launch, beside the {rnn6, rnn4} launch on the caller's stream
+    hipEvent_t ev_main[8] = {}, ev_aux[8] = {}, ev_h512[4] = {};
+    float* x1_alt2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // third relu(linear1) buffer per net (h512_stream runs a tick ahead)
     signed char* scan_codes_d = nullptr; // [cap] regime code per (frame, row)
     signed char* scan_codes_h = nullptr; // pinned
     int* scan_state_h = nullptr;         // pinned: first_reach[B] then pend[B] (as ints)
@@ -682,8 +686,11 @@ int ensure_wave2_buffers(rc_ctx* ctx) {
         if (rc) return rc;
         ctx->ring2[s] = f;
     }
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 6; ++i) {
         if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
+        if (int rc = dev_alloc(ctx, &ctx->x1_alt2[i], Bp * ctx->net[i].H)) return rc;
+    }
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->h512_stream, hipStreamNonBlocking));
     {
         // RC_SEQ_AUX_PRIO: -1 lowest / +1 highest queue priority for the second stream (0: default) -- its short kernels share the
         // CUs with the wide tiles of the caller's stream
@@ -699,6 +706,7 @@ int ensure_wave2_buffers(rc_ctx* ctx) {
         const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], evf));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], evf));
+        if (i < 4) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h512[i], evf));
     }
     ctx->ring2_ready = true;
     ctx->wave2_valid = false;
@@ -792,6 +800,16 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     static const bool merge_fill = tune_env("RC_SEQ_MERGE_FILL", 0) != 0;    // measured: 20-frame calls 907-914k with, 918-925k without
     auto cnt = [&](const std::vector<int>& v, int tick) { return tick >= 0 && tick < P.n_prep ? v[tick] : 0; };
     static const bool ext_events = tune_env("RC_SEQ_EXT_EVENTS", 1) != 0;   // tick hand-over events carried by the last dispatch itself (+0.5 %)
+    // The two wide launches of a tick on two streams: {H = 512 nets, linear1} only needs the second stream's work of the previous tick
+    // and its own predecessor, {rnn6, rnn4} only the previous linear1 -- so the former may run up to a tick ahead, its tiles filling
+    // the CUs the latter's last round leaves idle, and no launch waits behind the drain of the other (a 6-7 us gap each, on one stream)
+    // Measured (same box, body-frames/s, one stream vs two): batch 256 mixed 980k -> 1,031k, all-visible 1,204k -> 1,264k, 20-frame
+    // calls 862k -> 917k, fp32 MFMA 662k -> 725k, batch 1024 970k -> 1,012k, 128: 613k -> 631k, 64: 398k -> 418k; batch 32: 329k ->
+    // 299k, 16: 214k -> 178k (a tick there is launch latency, and a third stream adds two hand-overs to it): from 48 rows.
+    static const int split_main_env = tune_env("RC_SEQ_SPLIT_MAIN", -1);      // 0 / 1 force, default: by batch
+    const bool split_main = (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 && merge_big &&
+                            !merge_fill && ext_events;
+    hipStream_t s2 = ctx->h512_stream;
     auto collect = [&](int k, int g) -> std::vector<GemmProblem> {            // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
@@ -805,6 +823,10 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             const int rows = kind == 4 ? P.n_reach[e] : ((net == N4 || net == N6) ? P.n_vis[e] + riders : P.n_valid[e]);
             if (rows <= 0) continue;
             GemmProblem p = ctx->wave2_prob[(size_t)(e % kRing) * W2_PROB + q];
+            if (kind == 0 || kind == 1) {                                      // relu(linear1) of the frame started at tick e: one of three buffers
+                float* x1 = e % 3 == 0 ? ctx->net[net].x1 : (e % 3 == 1 ? ctx->x1_alt[net] : ctx->x1_alt2[net]);
+                if (kind == 0) p.out = x1; else p.seg[0].base = x1;
+            }
             if (kind == 1 || kind == 2) {
                 const NetDev& n = ctx->net[net];
                 int mr, nc;
@@ -856,10 +878,12 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     wt.cx4l = ctx->fb.x4l; wt.cx6l = ctx->fb.x6l;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));                    // the second stream joins (also: the table upload)
     if (two) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
+    if (split_main) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_main[7], 0));
     for (int k = 0; k < P.n_ticks; ++k) {
         const int e = k & 3, ep = (k + 3) & 3;
         // ---- per-row kernels and linear2 of tick k (second stream: after the previous tick's wide launches)
         if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
+        if (split_main && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_h512[ep], 0));
         if (k < P.n_prep) {
             wp.frame_at = ctx->frame_at_d + (size_t)k * B;
             wp.first_tick = k == 0 ? 1 : 0;
@@ -893,7 +917,23 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         }
         bool main_signalled = false;
         hipEvent_t stop_ev = (two && ext_events) ? ctx->ev_main[e] : nullptr;
-        if (merge_fill && n_prob > 0 && n_prob <= RC_MAX_PROB && n_tiles <= 512) {
+        if (split_main) {
+            // {H = 512 nets, linear1} (reads what the second stream wrote in tick k - 1) on its own stream ...
+            bool sig2 = false, sig0 = false;
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_aux[ep], 0));
+            if (int rc = launch_problems(ctx, gp[last_group], nullptr, s2, false, ctx->ev_h512[e], &sig2)) return rc;
+            if (!sig2) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s2));
+            // ... {rnn6, rnn4 (+ init_net)} behind the previous tick's linear1 (init_net also reads the previous tick's fuse)
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h512[ep], 0));
+            if (k > 0 && init_now) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            for (int g = 0; g < last_group; ++g)
+                if (!gp[g].empty()) {
+                    bool sig = false;
+                    if (int rc = launch_problems(ctx, gp[g], nullptr, st, false, sig0 ? nullptr : ctx->ev_main[e], &sig)) return rc;
+                    sig0 = sig0 || sig;
+                }
+            main_signalled = sig0;
+        } else if (merge_fill && n_prob > 0 && n_prob <= RC_MAX_PROB && n_tiles <= 512) {
             // a filling / draining tick (or one of lagging rows): everything fits two rounds of one launch -- no boundary at all, but
             // the stream wait is back in front of the tick's first launch: a wash (off by default)
             if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
@@ -912,6 +952,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         ctx->stat_ticks += 1;
     }
     if (two && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(P.n_ticks - 1) & 3], 0));
+    if (split_main && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h512[(P.n_ticks - 1) & 3], 0));
     HIP_TRY(ctx, hipGetLastError());
     ctx->stat_wave_frames += t_last - t0 + 1;
     return RC_OK;
@@ -1063,6 +1104,8 @@ int rc_destroy(rc_ctx* ctx) {
     for (void* p : ctx->weight_allocs) (void)hipFree(p);
     if (ctx->eager_ev) (void)hipEventDestroy(ctx->eager_ev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->h512_stream) (void)hipStreamDestroy(ctx->h512_stream);
+    for (hipEvent_t e : ctx->ev_h512) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 8; ++i) {
         if (ctx->ev_main[i]) (void)hipEventDestroy(ctx->ev_main[i]);
         if (ctx->ev_aux[i]) (void)hipEventDestroy(ctx->ev_aux[i]);
@@ -1868,22 +1911,39 @@ int rc_gemm_timing(rc_ctx* ctx, int32_t enable) {
     if (!ctx) return RC_ERR_INVALID;
     ctx->timing = enable != 0;
     if (enable) ctx->timing_mode = enable == 2 ? 2 : 1;
-    if (enable) { ctx->ev_used = 0; ctx->timed_ms = 0.0; ctx->timed_launches = 0; }
+    if (enable) { ctx->ev_used = 0; ctx->timed_ms = 0.0; ctx->timed_launches = 0; ctx->timed_busy_ms = 0.0; }
     return RC_OK;
 }
-
 int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches) {
     if (!ctx || !total_ms || !launches) return RC_ERR_INVALID;
+    // The wavefront engine runs the two wide launches of a tick on two streams: their durations overlap. Beside the sum, the time
+    // during which AT LEAST ONE timed launch was running (union of the intervals, against the first event as the common origin).
+    std::vector<std::pair<double, double>> iv;
+    iv.reserve(ctx->ev_used);
     for (size_t i = 0; i < ctx->ev_used; ++i) {
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pool[i].second));
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        if (i > 0) HIP_TRY(ctx, hipEventElapsedTime(&t0, ctx->ev_pool[0].first, ctx->ev_pool[i].first));
+        iv.emplace_back((double)t0, (double)t0 + ms);
         ctx->timed_ms += ms;
         ctx->timed_launches += 1;
     }
+    std::sort(iv.begin(), iv.end());
+    double lo = 0.0, hi = -1.0;
+    for (const auto& x : iv) {
+        if (hi < lo || x.first > hi) { if (hi > lo) ctx->timed_busy_ms += hi - lo; lo = x.first; hi = x.second; }
+        else if (x.second > hi) hi = x.second;
+    }
+    if (hi > lo) ctx->timed_busy_ms += hi - lo;
     ctx->ev_used = 0;
     *total_ms = ctx->timed_ms;
     *launches = ctx->timed_launches;
+    return RC_OK;
+}
+int rc_gemm_timing_busy(rc_ctx* ctx, double* busy_ms) {
+    if (!ctx || !busy_ms) return RC_ERR_INVALID;
+    *busy_ms = ctx->timed_busy_ms;
     return RC_OK;
 }
 

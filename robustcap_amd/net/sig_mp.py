@@ -316,6 +316,12 @@ class Net:
         _lib.check(self._ctx, self._lib.rc_gemm_timing_read(self._ctx, C.byref(ms), C.byref(n)), "rc_gemm_timing_read")
         return ms.value, n.value
 
+    def gemm_timing_busy(self):
+        """ms with at least one of the timed launches running (launches on two streams overlap); after gemm_timing_read()."""
+        ms = C.c_double()
+        _lib.check(self._ctx, self._lib.rc_gemm_timing_busy(self._ctx, C.byref(ms)), "rc_gemm_timing_busy")
+        return ms.value
+
     def __del__(self):
         ctx = self.__dict__.get("_ctx")
         if ctx:

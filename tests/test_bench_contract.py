@@ -65,6 +65,9 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     assert "error" not in roof and 0 < roof["frac"] < 1 and roof["bound"] == "mfma"
     assert roof["traffic"] is None or roof["traffic"] > 0
     assert roof["frac_issued"] <= roof["frac"] and roof["peak_issued"] > roof["peak"]      # split products: the bf16 roof / 6
+    # launches on two streams overlap: the kernel's busy time is at most the sum of the launch durations, at least half of it
+    assert 1.0 <= roof["concurrency"] <= 2.01 and roof["per_launch"]["frac"] <= roof["frac"] + 1e-4
+    assert abs(roof["avg_launch_us"] * roof["launches"] * 1e-3 - roof["busy_ms"] * roof["concurrency"]) < 0.02 * roof["busy_ms"]
     tm = d["timing"]
     assert tm["reps"] >= 5 and tm["min_call_ms"] <= tm["call_ms"] <= tm["max_call_ms"]
     assert abs(tm["call_ms"] - d["ms_per_step"] * d["steps"]) < 0.01 * tm["call_ms"]        # value = the median repetition
