@@ -126,8 +126,10 @@ int rc_default_gemm_mode(int32_t total_rows);   /* the default of a context of t
  * synchronisation of `stream` per call -- and plans the launches on the host:
  *   - the PER-ROW-CURSOR WAVEFRONT engine runs every frame but one that takes first_frame / first_tran: the stages of a
  *     frame (prep | linear1 | LSTM l0 | l1 | linear2 of {rnn2, rnn4} + fuse | the same four of {rnn6, rnn3, rnn7, rnn8} +
- *     tail) are skewed over consecutive ticks and a 16-slot ring, four gate-GEMM launches per tick carry the stages of up
- *     to eight frames, the per-row kernels run beside them on a context-owned second stream. Rows are independent, so each
+ *     tail) are skewed over consecutive ticks and a 16-slot ring, two merged gate-GEMM launches per tick carry the stages of
+ *     up to eight frames -- one on `stream`, the other (from 48 rows) on a context-owned stream -- and the per-row kernels
+ *     run beside them on another context-owned stream; all of it is joined back into `stream` before the call returns, so
+ *     the caller sees ordinary stream order. Rows are independent, so each
  *     row has its own frame cursor: the vision updater's feedback (net/sig_mp.py:264-271) and the one-shot init_net
  *     (L178-183) make only THAT row wait (8 / 6 ticks, once per occlusion / once per sequence) while the batch keeps
  *     ticking; the updater's rnn6 / rnn4 steps ride the launches of the ring slot that starts when the frame's tail runs.

@@ -62,7 +62,9 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     assert d["config"]["batch_per_gpu"] == 256 and "batch 256" in d["config"]["workload"]
     assert d["scaling"] == ("strong" if extra else "weak")
     roof = d["roofline"]
-    assert "error" not in roof and 0 < roof["frac"] < 1 and roof["bound"] == "mfma"
+    # (against the fp32-input roof, which the bf16 MFMAs the split kernel issues do not have: an all-visible run on a fast box
+    # reaches 1.0; the mixed default stays near 0.8 -- frac_issued is the utilisation figure)
+    assert "error" not in roof and 0 < roof["frac"] < 1.2 and roof["frac_issued"] < 1 and roof["bound"] == "mfma"
     assert roof["traffic"] is None or roof["traffic"] > 0
     assert roof["frac_issued"] <= roof["frac"] and roof["peak_issued"] > roof["peak"]      # split products: the bf16 roof / 6
     # launches on two streams overlap: the kernel's busy time is at most the sum of the launch durations, at least half of it
