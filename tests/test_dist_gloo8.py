@@ -22,11 +22,11 @@ def _free_port():
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
-def _spawn(fn, args, nprocs, budget_s=240):
-    """mp.spawn with a deadline and ONE retry on a fresh port: a rendezvous that never completes (port stolen between
+def _spawn(fn, args, nprocs, budget_s=150):
+    """mp.spawn with a deadline (a normal run takes 10-30 s) and two retries on a fresh port: a rendezvous that never completes (port stolen between
     _free_port() and the bind, a starved host) must not hang the CPU suite. args[1] is the port."""
     import time
-    for attempt in range(2):
+    for attempt in range(3):
         ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
         t0 = time.time()
         done = False
@@ -42,7 +42,7 @@ def _spawn(fn, args, nprocs, budget_s=240):
         for pr in ctx.processes:
             pr.join(10)
         args = (args[0], _free_port()) + tuple(args[2:])
-    raise RuntimeError("gloo workers did not finish within the deadline (twice)")
+    raise RuntimeError("gloo workers did not finish within the deadline (three attempts)")
 
 
 
