@@ -518,18 +518,19 @@ int flush_pending(rc_ctx* ctx, hipStream_t st) {
 // Stages of a frame in the wavefront engine below (stage s of the ring slot started at tick e runs at tick e + s):
 //   0 prep | 1 linear1{rnn2,rnn4} | 2,3 LSTM l0,l1 {rnn2,rnn4} | 4 linear2{rnn2,rnn4} then fuse |
 //   5 linear1{rnn6,rnn3,rnn7,rnn8} (+ init_net layer 0) | 6,7 LSTM l0,l1 (+ init_net layers 1, 2) | 8 linear2 then tail
-// linear2, fuse and tail are consecutive kernels of ONE tick on the second stream (a dependent chain of ~35 us beside the
-// ~220 us of wide launches), so a frame is 9 ticks deep, not 11 as in round 2.
-// Launch groups of a tick: four wide launches on the caller's stream, grouped by TILE DURATION instead of by data
-// dependence -- {rnn4 l0, l1}, {rnn6 l0, l1}, {rnn2 l0, l1, rnn3 l0, l1 + init_net}, {rnn7 l0, l1, rnn8 l0, l1 + the six
-// linear1}: each a whole number of rounds of equal tiles at batch 256 (rnn4 64 x 80, rnn6 and the H = 512 nets 64 x 128) --
-// and linear2 (16-row tiles, fp32-input kernel) with the per-row kernels on a context-owned second stream; the two streams
-// hand over once per tick. (Weight-streaming launches BESIDE the wide ones stretch those: linear1 rides in a wide launch.)
+// linear2, fuse and tail are consecutive kernels of ONE tick on the second stream (a dependent chain of ~150 us beside the
+// ~245 us of wide launches), so a frame is 9 ticks deep, not 11 as in round 2.
+// Launch groups of a tick (kTick.group names round 2's four groups by TILE DURATION; w2_group merges them): G0 = {rnn6 l0, l1,
+// rnn4 l0, l1 + init_net} and G2 = {the H = 512 nets' eight layer steps + the six linear1} -- each a whole number of rounds of
+// equal tiles at batch 256 (rnn4 64 x 80, rnn6 and the H = 512 nets 64 x 128) -- and linear2 (16-row tiles, fp32-input kernel)
+// with the per-row kernels on a context-owned second stream. From RC_SPLIT_MAIN_MIN_BATCH rows G0 runs on the caller's stream and
+// G2 on a third stream, up to a tick ahead (run_wave2_segment); below that both on the caller's stream with the second stream's
+// hand-over in front of the last one. (Weight-streaming launches BESIDE the wide ones stretch those: linear1 rides in G2.)
 enum { SEQ_STEPPED_TR = 0, SEQ_STEPPED = 1 };
 const int kRing = 16;
 
 struct TickStage { int kind; int net; int stage; int group; };   // kind: 0 linear1, 1 LSTM l0, 2 LSTM l1, 3 linear2
-// groups 0-3: caller's stream (wide tiles; linear1 rides in group 3); 5 (linear2): second stream (16-row tiles)
+// groups 0-3: wide tiles (linear1 rides in group 3; merged into G0 / G2 by w2_group); 5 (linear2): second stream (16-row tiles)
 const TickStage kTick[RC_TICK_PROB] = {
     {1, N4, 2, 0}, {2, N4, 3, 0}, {1, N6, 6, 1}, {2, N6, 7, 1},
     {1, N2, 2, 2}, {2, N2, 3, 2}, {1, N3, 6, 2}, {2, N3, 7, 2}, {1, N7, 6, 3}, {2, N7, 7, 3}, {1, N8, 6, 3}, {2, N8, 7, 3},
