@@ -788,10 +788,6 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     std::memcpy(ctx->frame_at_h, P.frame_at.data(), need * sizeof(int));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->frame_at_d, ctx->frame_at_h, need * sizeof(int), hipMemcpyHostToDevice, st));
 
-    int t4[2] = {4, 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
-    tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
-    tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
-    tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
     static const bool narrow_fill = tune_env("RC_SEQ_NARROW_FILL", 1) != 0;
     static const bool lin1_wide = tune_env("RC_SEQ_LIN1_WIDE", 1) != 0;
     static const bool merge_h512 = tune_env("RC_SEQ_MERGE_H512", 1) != 0;
@@ -811,6 +807,13 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     const bool split_main = (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 && merge_big &&
                             !merge_fill && ext_events;
     hipStream_t s2 = ctx->h512_stream;
+    // 64-row tile shapes of the wide launches. With both launches of a tick on one stream rnn4 ran best on 64 x 80 tiles (256 tiles
+    // per layer = whole rounds of the 256 CUs); on two streams the other launch fills what a round leaves idle and the 64 x 128 tile's
+    // 13 % fewer operand bytes per MFMA win: mixed 512 frames 1,030k -> 1,120k, all-visible 1,208k -> 1,258k, batch 1024 999k -> 1,088k
+    int t4[2] = {4, split_main ? 8 : 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
+    tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
+    tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
+    tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
     auto collect = [&](int k, int g) -> std::vector<GemmProblem> {            // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
