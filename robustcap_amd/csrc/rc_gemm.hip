@@ -448,6 +448,11 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     constexpr int EPI_ITEMS = (MT * UT + RC_NW * 64 - 1) / (RC_NW * 64);
     float c_prev[EPI_ITEMS];
     int st_row[EPI_ITEMS];
+    // The bias as well: a global load inside the item loop waits (vmcnt counts stores too) for the previous item's two state stores
+    // to be acknowledged -- 0.5 us per item, 8 items per thread in a 64 x 128 tile. A thread's items share their unit (and so their
+    // bias) whenever the workgroup size is a multiple of the units per tile: one float4 then, not one per item (registers).
+    constexpr bool BIAS_ONE = (RC_NW * 64) % UT == 0;             // (64 x 80 and 32 x 160 tiles: the load stays in the loop)
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (P.epi == RC_EPI_LSTM) {
 #pragma unroll
         for (int k = 0; k < EPI_ITEMS; ++k) {
@@ -467,6 +472,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 s_part[(wave * MT + 16 * r + 4 * kq + e) * LD + 16 * j + i] = acc[r][j][e];
+    if (P.epi == RC_EPI_LSTM) {       // (behind the accumulators' last use: their registers are free; the barrier covers the latency)
+        if constexpr (BIAS_ONE) bias4 = *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * (tid % UT)]);
+    }
     __syncthreads();
 
     if (P.epi == RC_EPI_LSTM) {
@@ -482,7 +490,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + 4 * u]);
 #pragma unroll
             for (int w = 1; w < RC_NW; ++w) g4 += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + 4 * u]);
-            g4 += *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * u]);
+            if constexpr (BIAS_ONE) g4 += bias4; else g4 += *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * u]);
             const int r2 = s_rows[rr];
             const int dst = (st_row[k] + P.step_off) % RC_HBUF;
             const long long ci = (long long)r2 * P.H + unit;
@@ -497,15 +505,22 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         // four columns per item, 16-byte LDS reads and one 16-byte store -- the same sums in the same order
         const bool vec4 = P.out_packed && P.out_bit == 0 && ((P.out_col0 | P.N) & 3) == 0;
         if (vec4) {
-            for (int item = tid; item < MT * (NT / 4); item += RC_NW * 64) {
+            // the items' bias first (every global load behind a store waits for that store: see the LSTM epilogue above); one float4
+            // where a thread's items share their four columns
+            constexpr int V4_ITEMS = (MT * (NT / 4) + RC_NW * 64 - 1) / (RC_NW * 64);
+            constexpr bool B4_ONE = (RC_NW * 64) % (NT / 4) == 0;
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (B4_ONE) b4 = *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + (tid % (NT / 4)) * 4]);
+#pragma unroll
+            for (int k = 0; k < V4_ITEMS; ++k) {
+                const int item = tid + k * RC_NW * 64;
                 const int rr = item / (NT / 4), c4 = (item - rr * (NT / 4)) * 4;
-                if (rr >= nrows) continue;
                 const int n = n_tile * NT + c4;
-                if (n >= P.N) continue;
+                if (item >= MT * (NT / 4) || rr >= nrows || n >= P.N) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + c4]);
 #pragma unroll
                 for (int w = 1; w < RC_NW; ++w) v += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + c4]);
-                v += *reinterpret_cast<const f32x4*>(&P.bias[n]);
+                if constexpr (B4_ONE) v += b4; else v += *reinterpret_cast<const f32x4*>(&P.bias[n]);
                 if (P.epi == RC_EPI_RELU) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
                 *reinterpret_cast<f32x4*>(&P.out[rc_pk(s_rows[rr], P.out_col0 + n, P.ldo)]) = v;
             }
