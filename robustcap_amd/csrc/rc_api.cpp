@@ -814,6 +814,10 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
+    // rows of a problem from which it runs 64-row tiles (split products). 128 until the ticks ran on two streams; measured then, 128 ->
+    // 64 -> 33 rows: batch 80 486k -> 519k -> 541k body-frames/s, batch 128 638k -> 773k -> 787k (the rnn4 / rnn6 problems of a mixed
+    // batch have 60-127 rows), batch 256 and 1024 unchanged: a half-filled 64-row tile still halves the weight bytes of two 32-row tiles
+    static const int tile64_rows = tune_env("RC_SEQ_TILE64_ROWS", 33);
     auto collect = [&](int k, int g) -> std::vector<GemmProblem> {            // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
@@ -834,7 +838,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (kind == 1 || kind == 2) {
                 const NetDev& n = ctx->net[net];
                 int mr, nc;
-                if (ctx->gemm_split && rows >= 128) {                          // (split products: the K loop is operand-bound, 64-row tiles)
+                if (ctx->gemm_split && rows >= tile64_rows) {                  // (split products: the K loop is operand-bound, 64-row tiles)
                     const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
                     mr = t[0]; nc = t[1];
                 } else {
@@ -843,7 +847,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
                 p.mr = mr; p.nc = nc; p.n_tiles = n.H / (4 * nc);
             } else if (kind == 0 || kind == 4) {
                 if (rows <= 16) { p.mr = 1; p.nc = 1; p.n_tiles = (p.N + 15) / 16; }
-                else if (kind == 0 && lin1_wide && ctx->gemm_split && rows >= 128) {
+                else if (kind == 0 && lin1_wide && ctx->gemm_split && rows >= tile64_rows) {
                     // linear1 rides in the last wide launch behind its 256 LSTM tiles: as 544 tiles of 32 x 64 (K = 128 / 256: two
                     // k-blocks, i.e. all prologue and epilogue) it added two rounds, ~18 us of a 245 us tick; 136 tiles of 64 x 128 add one
                     const int np = round_up(p.N, 64);
