@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--conf", default="mixed", choices=["mixed", "high", "occ"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gemm-mode", default="auto", choices=["auto", "split", "fp32"],
-                    help="product arithmetic of the GEMMs (auto: split-bf16 products from 80 bodies in total)")
+                    help="product arithmetic of the GEMMs (auto: split-bf16 products from 48 bodies in total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the variants (other schedules / configs)")
     args = ap.parse_args()

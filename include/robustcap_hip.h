@@ -114,7 +114,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
  *           of the partial products down to 2^-16 of it (what is dropped is below 2^-23 of a product, i.e. below the
  *           rounding of the running fp32 sum); operands, accumulators, gates and state stay fp32. Same accuracy class as
  *           mode 0 (parity with the reference: tests), 2.7x fewer MFMA cycles per product.
- * Default: mode 1 for contexts of batch >= 80, mode 0 below (weight-streaming bound: 6 B instead of 4 B per weight would
+ * Default: mode 1 for contexts of batch >= 48, mode 0 below (weight-streaming bound: 6 B instead of 4 B per weight would
  * slow them). Within one mode a row's result does not depend on the batch, the tile shape or the engine
  * (bitwise); between the two modes results differ by fp32 rounding noise. rc_get_gemm_mode returns the mode. */
 int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode);

@@ -25,12 +25,12 @@
 #include <vector>
 
 // From this batch on a context defaults to the split-bf16 products. Round 2 (frame-stepped launches only) put the break-even
-// at 192 rows; with the wavefront engine a tick is two merged launches that fill the chip at any batch, and the split wins
-// from ~80 rows (mixed, 256-frame calls, body-frames/s, split vs fp32 MFMA: batch 64 387k vs 428k, 96 633k vs 434k, 128 691k
-// vs 476k, 160 784k vs 595k). 64-row tiles for the FRAME-STEPPED full-batch stages stay tied to 192 rows (below that they
-// leave CUs without a tile).
+// at 192 rows; with the wavefront engine a tick is two merged launches that fill the chip at any batch and the split won from
+// ~80 rows; with 64-row tiles from 33 rows of a problem it wins from 48 (mixed, 128-frame calls, body-frames/s, split vs fp32
+// MFMA: batch 40 329k vs 344k, 48 434k vs 410k, 64 556k vs 417k, 72 486k vs 339k). 64-row tiles for the FRAME-STEPPED full-batch
+// stages stay tied to 192 rows (below that they leave CUs without a tile).
 #define RC_SPLIT_MAIN_MIN_BATCH 48  // wavefront engine: the tick's two wide launches on two streams from this many rows
-#define RC_SPLIT_MIN_BATCH 80
+#define RC_SPLIT_MIN_BATCH 48
 #define RC_TILE64_MIN_BATCH 192
 
 #ifndef RC_NC1280

@@ -254,13 +254,13 @@ class Net:
     @staticmethod
     def default_gemm_mode(total_rows):
         """The library's default product arithmetic for a workload of ``total_rows`` bodies (rc_default_gemm_mode: split-bf16
-        products from 80 rows). Sharded runs pass their TOTAL row count here and pin every shard's context with
+        products from 48 rows). Sharded runs pass their TOTAL row count here and pin every shard's context with
         ``set_gemm_mode``, so that a row's bits do not depend on the number of ranks it was split over."""
         return bool(_lib.load().rc_default_gemm_mode(int(total_rows)))
 
     def set_gemm_mode(self, split):
         """Product arithmetic of every GEMM of this context (rc_set_gemm_mode): False = fp32 MFMA (fma chains), True =
-        split-bf16 partial products with fp32 accumulation (default for batch >= 80). Results are bitwise reproducible
+        split-bf16 partial products with fp32 accumulation (default for batch >= 48). Results are bitwise reproducible
         across batch sizes and shards WITHIN one mode."""
         _lib.check(self._ctx, self._lib.rc_set_gemm_mode(self._ctx, int(bool(split))), "rc_set_gemm_mode")
         self.__dict__["_live_on"] = False

@@ -242,7 +242,7 @@ def joint_positions(body, pose, tran):
 @pytest.mark.parametrize("path", SEQS, ids=[os.path.basename(p)[4:-4] for p in SEQS])
 def test_sequence_vs_reference_capture(path, split, synth_assets):
     """forward_online (batch 1, frame by frame, like evaluate.py) against the REFERENCE's own outputs, in both product
-    arithmetics of the GEMMs (batch-1 contexts default to the fp32 MFMA, batch >= 80 to the split-bf16 products)."""
+    arithmetics of the GEMMs (batch-1 contexts default to the fp32 MFMA, batch >= 48 to the split-bf16 products)."""
     from oracle import sig_mp_oracle as O
     s = np.load(path)
     live = str(s["live"])

@@ -15,7 +15,7 @@ def _net(assets, B):
     from robustcap_amd.net.sig_mp import Net
     n = Net(body=assets["body"], batch=B)
     n.load_state_dict(assets["state_dict"])
-    assert n.gemm_mode == (1 if B >= 80 else 0) == int(Net.default_gemm_mode(B))   # split-bf16 products from batch 80 up
+    assert n.gemm_mode == (1 if B >= 48 else 0) == int(Net.default_gemm_mode(B))   # split-bf16 products from batch 48 up
     return n
 
 

@@ -25,7 +25,7 @@ def main():
         rows.append({"batch": B, "body_frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "gemm_frac": rf.get("frac"),
                      "path_frac": rf.get("path_frac"), "products": "split-bf16" if "split" in (rf.get("kernel") or "") else "fp32 MFMA"})
     print(json.dumps({"command": f"python bench.py --batch B --steps 256 (96 for B >= 1024) --warmup 16 --conf {conf} --no-cpu-baseline --no-variants",
-                      "note": "contexts of batch >= 80 use the split-bf16 products, smaller ones the fp32 MFMA (launch-chain and weight-streaming bound)",
+                      "note": "contexts of batch >= 48 use the split-bf16 products, smaller ones the fp32 MFMA (launch-chain and weight-streaming bound)",
                       "sweep": rows}, indent=1))
 
 
