@@ -168,6 +168,13 @@ int rc_live_begin(rc_ctx* ctx);
 int rc_live_step(rc_ctx* ctx, const float* j2dc_host, const float* accc_host, const float* oric_host,
                  const float* first_tran_host, uint32_t flags, float* pose_host, float* tran_host);
 int rc_live_end(rc_ctx* ctx);
+/* For batch <= 4 rc_live_begin also captures the LEAN plan of the steady-state frame (csrc/rc_live.hip): seven dependent launches --
+ * prep + linear1 | LSTM l0 | LSTM l1 + linear2 partial sums | (partials, fuse) + linear1 | LSTM l0 | LSTM l1 + partials | (partials) +
+ * tail -- replayed for every frame that needs neither a transition step nor rnn2.init_net (L178-183) and is not a sequence start;
+ * the other frames take the captures above. Same layer-step arithmetic as rc_step; linear2 sums per-tile partial products in a
+ * fixed order instead of one MFMA chain, so a lean frame equals an rc_step frame to rounding (<= 1e-6), not bit for bit.
+ * RC_LIVE_LEAN=0 in the environment of rc_create switches it off. Counters: frames replayed from the lean / the full captures. */
+int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames);
 
 /* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
 /* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264): r6d[n,6] -> R[n,3,3]. */
@@ -331,6 +338,10 @@ int rc_camera_inputs_rows(const float* kp_norm, const float* imu_acc_w, const fl
 /* ---- state access (tests / checkpointing of a running sequence) ------------------------------------------ */
 /* Copy the (h, c) state of sub-net `net` to HOST buffers h[2,batch,H], c[2,batch,H]. Synchronises `stream`. */
 int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, void* stream);
+/* Per-row fusion state (net/sig_mp.py:85-104 and the class attributes L43-45) for tests and debugging: out[batch,5] =
+ * {last_tran is set, len(floor_y), first_reach, update_vision_count, a deferred vision-updater step is pending}. Synchronises. */
+int rc_get_fusion_state(rc_ctx* ctx, int32_t* out_host, void* stream);
+
 /* Per-row branch trace of the last step, HOST int32[batch,8]:
  * {regime (0 low,1 mid,2 high), rnn4 steps, rnn6 steps, floor samples held, reach fired, used velocity branch,
  *  stance foot, jump reset}. Synchronises `stream`. */

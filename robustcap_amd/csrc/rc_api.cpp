@@ -52,6 +52,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct Dense {       // packed dense layer
     float* W = nullptr; float* b = nullptr;
     void* Ws = nullptr;                  // split-bf16 planes of W
+    float* Wrm = nullptr;                // narrow layers (linear2): the matrix as loaded, row-major [N][K] (rc_live.hip)
     int K = 0, N = 0, Kp = 0, Np = 0;
     int mr = 2, nc = 4;                  // tile shape: 16*mr rows x 16*nc columns
 };
@@ -64,6 +65,7 @@ struct NetDev {
     float* c = nullptr;                  // [layer][B][H]
     int* steps = nullptr;                // [B]
     float* x1 = nullptr;                 // relu(linear1) scratch [B][H]
+    float* part = nullptr;               // lean live frame: per-tile partial sums of linear2 [H / 4][RC_LIVE_MAXB][outp]
     int in = 0, H = 0, out = 0;
     int nc = 4;                          // 16-column blocks per LSTM tile (4*nc hidden units x 4 gates)
     int mr = 2;                          // 16-row blocks per LSTM tile
@@ -114,6 +116,15 @@ struct rc_ctx {
     hipGraphExec_t live_exec_notr = nullptr;
     std::vector<unsigned char> live_maybe_pend;             // host-side, conservative: row may carry a deferred updater step
     bool live_prev_known = false;
+    // the lean live frame (rc_live.hip): seven launches for the steady-state frame of a small batch
+    int live_lean = 1;                                      // RC_LIVE_LEAN: 0 = the frame-stepped plan for every live frame
+    int live_lean_nc = 1;                                   // RC_LIVE_LEAN_NC: 16-column blocks per LSTM tile (1 or 2)
+    hipGraph_t live_graph_lean = nullptr;
+    hipGraphExec_t live_exec_lean = nullptr;
+    LiveFrame live_frame{};
+    int* live_status_h = nullptr;                           // pinned + mapped: set by a lean frame that met an init_net trigger
+    std::vector<unsigned char> live_may_reach;              // host-side, conservative: the row may still trigger init_net (L178-183)
+    long long stat_live_lean = 0, stat_live_full = 0;
     // timing of the gate GEMM launches
     bool timing = false;
     int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernel (rc_gemm_kernel)
@@ -264,6 +275,7 @@ int make_dense(rc_ctx* ctx, Dense& d, const std::vector<float>& W, const std::ve
     for (int n = 0; n < N; ++n) bp[n] = b[n];
     if (int rc = upload(ctx, &d.W, pack_weights(d.Np, d.Kp, get))) return rc;
     if (int rc = upload16(ctx, &d.Ws, pack_weights_split(d.Np, d.Kp, get))) return rc;
+    if (N <= 160) if (int rc = upload(ctx, &d.Wrm, W)) return rc;
     return upload(ctx, &d.b, bp);
 }
 
@@ -1050,6 +1062,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->gemm_split = tune_env("RC_GEMM_SPLIT", batch >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0;
     ctx->live_eager = tune_env("RC_LIVE_EAGER", 0) != 0;
     ctx->live_nt_mask = (unsigned)tune_env("RC_LIVE_NT_MASK", 63);
+    ctx->live_lean = tune_env("RC_LIVE_LEAN", 1);
+    ctx->live_lean_nc = tune_env("RC_LIVE_LEAN_NC", 1) == 2 ? 2 : 1;
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
@@ -1080,6 +1094,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
         n.mr = 2;
         n.nc = n.H == 1280 ? 10 : (n.H == 1024 ? 8 : 4);
         A(n.h, 2 * RC_HBUF * Bp * n.H); A(n.c, 2 * B * n.H); A(n.steps, B); A(n.x1, Bp * n.H);
+        A(n.part, (size_t)(n.H / 4) * RC_LIVE_MAXB * round_up(n.out, 4));
     }
     A(ctx->hid1, Bp * 512); A(ctx->hid2, Bp * 1024); A(ctx->xtmp, Bp * 256);
     A(fb.x2, Bp * 128); A(fb.x3, Bp * 256); A(fb.x4, Bp * 256); A(fb.x6, Bp * 256); A(fb.x78, Bp * 256);
@@ -1278,6 +1293,7 @@ int rc_set_gravity(rc_ctx* ctx, const float* g) {
 int rc_reset(rc_ctx* ctx, const uint8_t* row_mask, void* stream) {
     if (!ctx) return RC_ERR_INVALID;
     ctx->live_prev_known = false;
+    ctx->live_may_reach.assign(ctx->B, 1);
     float* h[6]; float* c[6]; int H[6];
     for (int i = 0; i < 6; ++i) { h[i] = ctx->net[i].h; c[i] = ctx->net[i].c; H[i] = ctx->net[i].H; }
     rc_launch_reset(ctx->fb, h, c, H, row_mask, ctx->B, (hipStream_t)stream);
@@ -1454,6 +1470,9 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
     if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
+    if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
+    if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
+    if (ctx->live_status_h) { (void)hipHostFree(ctx->live_status_h); ctx->live_status_h = nullptr; }
     if (ctx->live_graph_notr) { (void)hipGraphDestroy(ctx->live_graph_notr); ctx->live_graph_notr = nullptr; }
     if (ctx->live_stream) { (void)hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
     if (ctx->live_in_h) { (void)hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
@@ -1505,8 +1524,38 @@ int rc_live_begin(rc_ctx* ctx) {
         if (!rc && hipGraphInstantiate(v == 0 ? &ctx->live_exec : &ctx->live_exec_notr, *g, nullptr, nullptr, 0) != hipSuccess)
             rc = fail(ctx, RC_ERR_HIP, "hipGraphInstantiate");
     }
+    // The lean plan of the steady-state frame (rc_live.hip): seven launches. rc_live_step replays it when the frame needs neither a
+    // transition step nor init_net and is not a sequence start; every other frame takes the captures above.
+    // (fp32-MFMA contexts only: the lean kernels stream the fp32 weights, a context switched to split products keeps one arithmetic)
+    if (!rc && ctx->live_lean && B <= RC_LIVE_MAXB && !ctx->gemm_split) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_status_h, sizeof(int), hipHostMallocMapped));
+        *ctx->live_status_h = 0;
+        LiveFrame& F = ctx->live_frame;
+        F = LiveFrame{};
+        for (int i = 0; i < 6; ++i) {
+            const NetDev& n = ctx->net[i];
+            LiveNet& l = F.net[i];
+            l.W1 = n.lin1.W; l.b1 = n.lin1.b;
+            for (int q = 0; q < 2; ++q) { l.Wl[q] = n.Wl[q]; l.bl[q] = n.bl[q]; }
+            l.W2 = n.lin2.Wrm; l.b2 = n.lin2.b;
+            l.x1 = n.x1; l.h = n.h; l.c = n.c; l.part = n.part; l.steps = n.steps;
+            l.H = n.H; l.out = n.out; l.outp = round_up(n.out, 4); l.Kp1 = n.lin1.Kp;
+            l.BpH = (long long)ctx->Bp * n.H;
+        }
+        F.fb = ctx->fb; F.io = io; F.prm = dev_params(ctx->prm); F.body = ctx->body; F.B = (int)B; F.nc = ctx->live_lean_nc;
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&F.status, ctx->live_status_h, 0));
+        HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+        rc_launch_live_frame(F, st);
+        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+        const hipError_t e = hipStreamEndCapture(st, &ctx->live_graph_lean);
+        if (e != hipSuccess) rc = fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture (lean frame): ") + hipGetErrorString(e));
+        if (!rc && hipGraphInstantiate(&ctx->live_exec_lean, ctx->live_graph_lean, nullptr, nullptr, 0) != hipSuccess)
+            rc = fail(ctx, RC_ERR_HIP, "hipGraphInstantiate (lean frame)");
+    }
     ctx->timing = timing;
     ctx->live_maybe_pend.assign(B, 1);
+    ctx->live_may_reach.assign(B, 1);
     ctx->live_prev_known = false;
     return rc;
 }
@@ -1529,8 +1578,10 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     // margin covers the summation-order difference between this double mean and the device's float butterfly; any
     // doubt, or an unknown previous frame, selects the full graph, where unneeded transition tiles simply exit.
     bool need_tr = !ctx->live_prev_known;
+    bool maybe_reach = false;        // some row may trigger init_net in this frame (c >= hi on a row that has not yet, L178-183)
     {
-        const double lo = ctx->prm.conf_lo, margin = 1e-4;
+        const double lo = ctx->prm.conf_lo, hi = ctx->prm.conf_hi, margin = 1e-4;
+        if (ctx->live_may_reach.size() != B) ctx->live_may_reach.assign(B, 1);
         for (size_t b = 0; b < B; ++b) {
             double acc = 0.0;
             for (int k = 0; k < 33; ++k) acc += (double)j2dc[(b * 33 + k) * 3 + 2];
@@ -1538,9 +1589,14 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
             const bool maybe_vis = !(c < lo - margin) || (flags & RC_FLAG_FIRST_FRAME);
             if (ctx->live_maybe_pend[b] && maybe_vis) need_tr = true;
             ctx->live_maybe_pend[b] = (ctx->prm.use_vision_updater && !(c > lo + margin)) ? 1 : 0;
+            if (ctx->prm.use_imu_updater && ctx->live_may_reach[b]) {
+                if (!(c < hi - margin)) maybe_reach = true;
+                if (c > hi + margin) ctx->live_may_reach[b] = 0;          // it fires in this frame at the latest (frames like this one never take the lean plan)
+            }
         }
         ctx->live_prev_known = true;
     }
+    const bool lean = ctx->live_exec_lean && !need_tr && !maybe_reach && !first_tran && !(flags & RC_FLAG_FIRST_FRAME);
     if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
         if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1548,6 +1604,10 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
                    ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
         if (int rc = step_impl(ctx, io, flags, st)) return rc;
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
+    } else if (lean) {
+        if (ctx->live_eager) rc_launch_live_frame(ctx->live_frame, st);
+        else HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec_lean, st));
+        ctx->stat_live_lean += 1;
     } else if (ctx->live_eager) {                                // tuning (RC_LIVE_EAGER=1): the 11-14 launches enqueued directly
         FrameIO io{ctx->live_in_io, ctx->live_in_io + B * 99, ctx->live_in_io + B * 117, nullptr,
                    ctx->live_out_io, ctx->live_out_io + B * 216, 99, 18, 54, 216, 3};
@@ -1569,8 +1629,20 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         (void)hipGetLastError();
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (!lean) ctx->stat_live_full += 1;
+    if (lean && *ctx->live_status_h != 0) {
+        *ctx->live_status_h = 0;
+        return fail(ctx, RC_ERR_STATE, "rc_live_step: a lean frame met an init_net trigger (host mirror of first_reach out of date)");
+    }
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));
     std::memcpy(tran, ctx->live_out_h + B * 216, B * 3 * sizeof(float));
+    return RC_OK;
+}
+
+int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (lean_frames) *lean_frames = ctx->stat_live_lean;
+    if (full_frames) *full_frames = ctx->stat_live_full;
     return RC_OK;
 }
 
@@ -1905,6 +1977,23 @@ int rc_get_state(rc_ctx* ctx, const char* net, float* h_host, float* c_host, voi
             const float* src = h.data() + (l * RC_HBUF + (steps[b] % RC_HBUF)) * Bp * H;
             for (size_t e = 0; e < H; ++e) h_host[(l * B + b) * H + e] = src[rc_pk((long long)b, (int)e, (int)H)];
         }
+    return RC_OK;
+}
+
+int rc_get_fusion_state(rc_ctx* ctx, int32_t* out_host, void* stream) {
+    if (!ctx || !out_host) return RC_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    const size_t B = ctx->B;
+    std::vector<int> a(B), b(B), c(B), d(B);
+    std::vector<unsigned char> e(B);
+    HIP_TRY(ctx, hipMemcpy(a.data(), ctx->fb.has_last, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(b.data(), ctx->fb.n_floor, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(c.data(), ctx->fb.first_reach, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(d.data(), ctx->fb.uv_count, B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(e.data(), ctx->fb.pend, B, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < B; ++r) {
+        out_host[5 * r] = a[r]; out_host[5 * r + 1] = b[r]; out_host[5 * r + 2] = c[r]; out_host[5 * r + 3] = d[r]; out_host[5 * r + 4] = e[r];
+    }
     return RC_OK;
 }
 

@@ -46,22 +46,9 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #define RC_ABLATE 0           // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
 #endif
 
-#ifndef RC_FAST_GATES
-#define RC_FAST_GATES 1       // gate non-linearities on v_exp_f32 / v_rcp_f32 (0: libm expf / tanhf, A/B builds): measured +3.6 %
-                              // frame rate with parity margins unchanged (profiles/r02_parity_margins.json)
-#endif
-#if RC_FAST_GATES
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
-// tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|) in (0, 1]: no cancellation near 0 (1 - 2 / (1 + e^2x) loses every
-// significant bit of a small x there)
-__device__ __forceinline__ float tanhf_(float x) {
-    const float t = __builtin_amdgcn_exp2f(-2.88539008177793f * __builtin_fabsf(x));
-    return __builtin_copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
-}
-#else
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
-#endif
+#include "rc_gates.h"
+__device__ __forceinline__ float sigmoidf_(float x) { return rc_gate_sigmoid(x); }
+__device__ __forceinline__ float tanhf_(float x) { return rc_gate_tanh(x); }
 
 template <int MR, int NC>
 struct Frag {                 // one chunk (16 k): a float4 per lane for each of the MR row blocks and NC column blocks

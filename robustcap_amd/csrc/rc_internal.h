@@ -164,6 +164,38 @@ struct rc_params_dev {
     float smooth;
 };
 
+// ---- the lean live frame (rc_live.hip; live_server.py:40-48 calls forward_online once per camera frame) -------------------------------
+// Batch <= RC_LIVE_MAXB, steady-state frames only (no first frame, no transition step, init_net already run): SEVEN dependent
+// launches instead of 11-14 --
+//   K1 prep + linear1{rnn4, rnn2} | K2 LSTM l0 | K3 LSTM l1 + per-tile partial sums of linear2 |
+//   K4 (sum of the partials, fuse) + linear1{rnn6, rnn3, rnn7, rnn8} | K5 LSTM l0 | K6 LSTM l1 + linear2 partials |
+//   K7 (sum of the partials) + tail
+// linear2 y = W2 h + b is computed where h is produced: the workgroup that owns 4 (or 8) hidden units multiplies them with its
+// columns of W2 and stores the partial y; the consuming kernel sums the partials of all tiles in a FIXED order behind the launch
+// boundary (no atomics, no fences, nothing placement-dependent). Every kernel requests its weights first and its per-row words
+// (flags, step parities, cell state) in the same batch: one memory latency in front of the first MFMA instead of a chain of four.
+#define RC_LIVE_MAXB 4
+struct LiveNet {
+    const float *W1, *b1;           // linear1: pack_weights order [N/16][Kp1/16][64][4], bias
+    const float *Wl[2], *bl[2];     // LSTM layers: pack_weights order, gate-interleaved columns; b_ih + b_hh
+    const float *W2, *b2;           // linear2 ROW-MAJOR [out][H] (a unit's column slice is one 16-byte piece per output), bias [out]
+    float *x1, *h, *c, *part;       // relu(linear1) [Bp][H] rc_pk | h [2][RC_HBUF][Bp][H] rc_pk | c [2][B][H] | partials [H/UT][RC_LIVE_MAXB][outp]
+    int* steps;
+    int H, out, outp, Kp1;
+    long long BpH;                  // elements between the copies of h
+};
+struct LiveFrame {
+    LiveNet net[6];                 // kNets order: rnn2, rnn3, rnn4, rnn6, rnn7, rnn8
+    FrameBuffers fb;
+    FrameIO io;
+    rc_params_dev prm;
+    const BodyConst* body;
+    int* status;                    // device word, set != 0 when a frame the lean plan does not cover reached it (init_net trigger)
+    int B;
+    int nc;                         // 16-column blocks per LSTM tile (1 or 2)
+};
+void rc_launch_live_frame(const LiveFrame& F, hipStream_t s);
+
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);
 void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t s);

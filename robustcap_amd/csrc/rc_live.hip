@@ -1,0 +1,385 @@
+// The lean live frame on gfx950 (BASELINE config 5: batch 1, one frame per host round trip; live_server.py:40-48 ->
+// Net.forward_online, net/sig_mp.py:113-274, step form of a sub-net L126-129).
+//
+// A live frame is a chain of dependent launches over a 243 MB weight stream; what it costs beyond the stream is the FIXED part of
+// every launch (dispatch, dependent per-row reads in front of the first MFMA, reduction, drain) -- profiles/r03_live_hoist_notes.txt.
+// The frame-stepped plan (rc_api.cpp: step_impl) spends 11-14 launches on it. This file is the same frame in SEVEN, for the
+// steady-state frame of a small batch (<= RC_LIVE_MAXB rows, no first frame, no transition step, init_net done):
+//   K1 rc_live_s1_kernel     prep (L138-152) recomputed by every workgroup + linear1{rnn4, rnn2}
+//   K2 rc_live_lstm_kernel   LSTM layer 0 {rnn4, rnn2}
+//   K3 rc_live_lstm_kernel   LSTM layer 1 + per-tile partial sums of linear2
+//   K4 rc_live_s2_kernel     sum of the partials + fuse (L154-167) recomputed by every workgroup + linear1{rnn6, rnn3, rnn7, rnn8}
+//   K5 / K6                  LSTM layers of the second stage (+ linear2 partials)
+//   K7 rc_live_tail_kernel   sum of the partials + the tail of the row (L173-273, rc_frame_dev.h: tail_impl)
+// linear2 is computed where h is produced (a tile's 4 or 8 hidden units times their columns of W2) and summed by the consumer
+// behind the launch boundary in a fixed order: no atomics, no fences, nothing that depends on placement. The LSTM tiles are those of
+// rc_gemm.hip's 16-row kernel (same K split over the 4 waves, same MFMA sequence per accumulator, same reduction order and gate
+// functions: layer steps are bitwise those of the frame-stepped plan), with a prologue that requests the weights FIRST and every
+// per-row word (flags, step parities, cell state, bias) in the same batch -- no row compaction, no dependent read in front of
+// the weight stream. Rows that do not step (rnn4 / rnn6 of an occluded row without a deferred step) are computed and discarded.
+#include "rc_internal.h"
+#include <hip/hip_ext.h>
+#include "rc_device.h"
+#include "rc_frame_dev.h"
+#include "rc_gates.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+enum { LN2 = 0, LN3 = 1, LN4 = 2, LN6 = 3, LN7 = 4, LN8 = 5 };     // rc_api.cpp: kNets order
+
+#define LIVE_XLD 260          // floats per A row in LDS (256 + 4: the 16 rows of a fragment read land on different banks)
+
+__device__ __forceinline__ f32x4 ldg_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+
+// ---- sum of a sub-net's linear2 partials for one row ---------------------------------------------------------------------------
+// part[(tile * RC_LIVE_MAXB + row) * OUTP + o]; OUTP / 4 column groups x S slices of tiles (slice sl owns tiles sl, sl + S, ...):
+// every thread sums its slice in ascending order, the slices meet in LDS and are added in ascending order, then the bias.
+// The order depends on (n_tiles, OUTP) only. All loads of a thread are in flight together.
+template <int OUTP, int MAXT>      // MAXT >= ceil(n_tiles / S)
+__device__ __forceinline__ void live_reduce(const float* __restrict__ part, const int n_tiles, const int row, const float* __restrict__ bias,
+                                            const int out, float* dst, float* s_red, const int tid) {
+    constexpr int G = OUTP / 4, S = (256 / G) < 32 ? (256 / G) : 32;
+    const int g = tid % G, sl = tid / G;
+    f32x4 v[MAXT];
+    if (sl < S) {
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q) {
+            const int tl = sl + q * S;
+            v[q] = tl < n_tiles ? *reinterpret_cast<const f32x4*>(part + ((long long)tl * RC_LIVE_MAXB + row) * OUTP + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 a = v[0];
+#pragma unroll
+        for (int q = 1; q < MAXT; ++q)
+            if (sl + q * S < n_tiles) a += v[q];
+        *reinterpret_cast<f32x4*>(s_red + sl * OUTP + 4 * g) = a;
+    }
+    __syncthreads();
+    if (tid < out) {
+        float y = s_red[tid];
+#pragma unroll 4
+        for (int q = 1; q < S; ++q) y += s_red[q * OUTP + tid];
+        dst[tid] = y + bias[tid];
+    }
+    __syncthreads();
+}
+
+// ---- one 16-column tile of a linear1 layer, A operand in LDS --------------------------------------------------------------------
+// The arithmetic of gemm_tile<1, 1, ...> of rc_gemm.hip for a dense layer: wave w owns the k chunks [w Qw, (w + 1) Qw), the wave
+// sums meet in LDS and are added in wave order, then bias and ReLU; four columns per item.
+struct Lin1W { f32x4 b[4]; f32x4 bias; };
+__device__ __forceinline__ void lin1_request(Lin1W& w, const LiveNet& n, const int n_tile, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Q = n.Kp1 / 16, Qw = Q / 4;                                  // Kp1 = 256 -> 4 chunks per wave, 128 -> 2
+    const float* pb = n.W1 + ((long long)n_tile * Q + (long long)wave * Qw) * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.b[q] = q < Qw ? ldg_nt(pb + q * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    w.bias = *reinterpret_cast<const f32x4*>(n.b1 + n_tile * 16 + 4 * (tid & 3));
+}
+__device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, const int n_tile, const int B, const float (*s_x)[LIVE_XLD],
+                                          float (*s_part)[16][20], const int tid) {
+    const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int Qw = n.Kp1 / 64;
+    const int ri = i < B ? i : B - 1;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < Qw) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&s_x[ri][16 * (wave * Qw + q) + 4 * kq]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[q][s], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_part[wave][4 * kq + e][i] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        const int rr = tid >> 2, c4 = (tid & 3) * 4;
+        if (rr < B) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&s_part[0][rr][c4]);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(&s_part[ww][rr][c4]);
+            v += w.bias;
+            v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
+            *reinterpret_cast<f32x4*>(&n.x1[rc_pk(rr, n_tile * 16 + c4, n.H)]) = v;
+        }
+    }
+}
+
+// =================================================================================================== K1: prep + linear1{rnn4, rnn2}
+// Grid: rnn4's H / 16 column tiles, then rnn2's. Wave w of EVERY workgroup runs the prep of row w (684 B of inputs, < 1 k FLOP) and
+// leaves the sub-net's input row in LDS; the first workgroup of each net also performs the prep's stores (row flags, the input
+// rows later stages read, trace) and opens the step (rc_gemm.hip: open_step).
+__global__ __launch_bounds__(256) void rc_live_s1_kernel(const LiveFrame F) {
+    __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
+    __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = F.B;
+    const int t4 = F.net[LN4].H / 16;
+    const bool is4 = (int)blockIdx.x < t4;
+    const LiveNet& n = is4 ? F.net[LN4] : F.net[LN2];
+    const int n_tile = is4 ? (int)blockIdx.x : (int)blockIdx.x - t4;
+    Lin1W w;
+    lin1_request(w, n, n_tile, tid);
+    if (wave < B) {
+        const int row = wave;
+        PrepIn in;
+        prep_load(in, F.io, row, lane);
+        const int pend = F.fb.pend[row], uvc = F.fb.uv_count[row];
+        // the deferred updater's input row (rows that are not on camera but carry a pending step read it, L264-271)
+        const f32x4 xl = is4 ? *reinterpret_cast<const f32x4*>(F.fb.x4l + rc_pk(row, 4 * lane, LD_X4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const PrepVals pv = prep_values(in, F.prm, lane, 0, pend, uvc);
+        float* x = s_x[row];
+        if (is4) {
+            if (pv.f & RC_ROW_VIS) {
+                if (lane < 18) x[lane] = in.al;
+                if (lane < 54) x[18 + lane] = in.ol;
+                if (lane < 33) { x[72 + 3 * lane] = pv.xn; x[73 + 3 * lane] = pv.yn; x[74 + 3 * lane] = in.cf; }
+                for (int k = 171 + lane; k < 256; k += 64) x[k] = 0.0f;
+            } else {
+                *reinterpret_cast<f32x4*>(x + 4 * lane) = xl;
+            }
+        } else {
+            if (lane < 18) x[lane] = pv.accr;
+            if (lane < 54) x[18 + lane] = pv.orir;
+            if (lane < 56) x[72 + lane] = 0.0f;
+        }
+        if (blockIdx.x == 0) {
+            prep_store(F.fb, in, pv, row, lane);
+            if (lane == 0 && (pv.f2 & RC_ROW2_M4)) n.steps[row] += 1;
+        }
+        if ((int)blockIdx.x == t4 && lane == 0) n.steps[row] += 1;
+    }
+    __syncthreads();
+    lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+}
+
+// ============================================================================= K4: linear2 sums + fuse + linear1 of the second stage
+// Grid: column tiles of rnn6, rnn3, rnn7, rnn8. Every workgroup sums the partials it needs (rnn6: rnn4's output, rnn3: rnn2's,
+// rnn7 / rnn8: both, then the fuse of L154-167 with the arithmetic of rc_fuse_kernel) and builds its input rows in LDS.
+__global__ __launch_bounds__(256) void rc_live_s2_kernel(const LiveFrame F) {
+    __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
+    __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
+    __shared__ __attribute__((aligned(16))) float s_red[1024];
+    __shared__ __attribute__((aligned(16))) float s_y4[RC_LIVE_MAXB][72], s_y2[RC_LIVE_MAXB][72];
+    const int tid = threadIdx.x;
+    const int B = F.B;
+    const int t6 = F.net[LN6].H / 16, t3 = F.net[LN3].H / 16, t7 = F.net[LN7].H / 16;
+    const int b = blockIdx.x;
+    const int ni = b < t6 ? LN6 : (b < t6 + t3 ? LN3 : (b < t6 + t3 + t7 ? LN7 : LN8));
+    const int n_tile = ni == LN6 ? b : (ni == LN3 ? b - t6 : (ni == LN7 ? b - t6 - t3 : b - t6 - t3 - t7));
+    const LiveNet& n = F.net[ni];
+    Lin1W w;
+    lin1_request(w, n, n_tile, tid);
+    // the prefix of the input rows (written by K1's first workgroup) and the alternative row of rnn6 -- requested before the sums
+    float xin[RC_LIVE_MAXB], xalt[RC_LIVE_MAXB];
+    const float* xsrc = ni == LN6 ? F.fb.x6 : (ni == LN3 ? F.fb.x3 : F.fb.x78);
+#pragma unroll
+    for (int r = 0; r < RC_LIVE_MAXB; ++r) {
+        xin[r] = r < B ? xsrc[rc_pk(r, tid, 256)] : 0.f;
+        xalt[r] = (r < B && ni == LN6) ? F.fb.x6l[rc_pk(r, tid, LD_X6)] : 0.f;
+    }
+    const LiveNet& n4 = F.net[LN4];
+    const LiveNet& n2 = F.net[LN2];
+    for (int r = 0; r < B; ++r) {
+        if (ni != LN3) live_reduce<72, 24>(n4.part, n4.H / (4 * F.nc), r, n4.b2, n4.out, s_y4[r], s_red, tid);
+        if (ni != LN6) live_reduce<72, 10>(n2.part, n2.H / (4 * F.nc), r, n2.b2, n2.out, s_y2[r], s_red, tid);
+    }
+    for (int r = 0; r < B; ++r) {
+        const unsigned fl = F.fb.flags[r];
+        const int regime = F.fb.regime[r];
+        float v = 0.0f;
+        if (ni == LN6) {                                                   // [acc, ori, j2d | j3dc] or the deferred updater's row (L155 / L266-267)
+            v = (fl & RC_ROW_PC) ? (tid < 171 ? xin[r] : (tid < 240 ? s_y4[r][tid - 171] : 0.0f)) : xalt[r];
+        } else if (ni == LN3) {                                            // [accr, orir | j3dr_i], L145
+            v = tid < 72 ? xin[r] : (tid < 141 ? s_y2[r][tid - 72] : 0.0f);
+        } else {                                                           // [accr, orir | j3dr], L169-170: rc_fuse_kernel's arithmetic
+            if (tid < 72) v = xin[r];
+            else if (tid < 141) {
+                const int e = tid - 72, j = e / 3, c = e - 3 * j;
+                const float vi = s_y2[r][e];
+                if (regime == 0) v = vi;
+                else {
+                    const float* R = F.io.ori + r * F.io.s_ori + 45;
+                    const float vc0 = s_y4[r][3 * j], vc1 = s_y4[r][3 * j + 1], vc2 = s_y4[r][3 * j + 2];
+                    const float vv = (vc0 * R[c] + vc1 * R[3 + c]) + vc2 * R[6 + c];      // j3dc.view(23,3).mm(Rcr), L154
+                    if (regime == 2) v = vv;
+                    else {                                                 // lerp with a python-double weight, L163-164
+                        const double k = F.fb.kconf[r];
+                        const float w1 = (float)(1.0 - k), w2 = (float)k;
+                        v = vi * w1 + vv * w2;
+                    }
+                }
+            }
+        }
+        s_x[r][tid] = v;
+        if (n_tile == 0 && tid == 0) {                                      // the step this frame takes (rc_gemm.hip: open_step)
+            if (ni != LN6 || (F.fb.flags2[r] & RC_ROW2_M6)) n.steps[r] += 1;
+            // L178-180: a frame that would trigger init_net is not this plan's (rc_api.cpp keeps it away; checked by rc_live_step)
+            if (ni == LN6 && regime == 2 && F.prm.use_imu_updater && F.fb.first_reach[r]) *F.status = 1;
+        }
+    }
+    __syncthreads();
+    lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+}
+
+// ========================================================================================= K2 / K3 / K5 / K6: one LSTM layer step
+struct LiveGrid { int n; int net[4]; int base[4]; int mask[4]; };          // problems of the launch: sub-net, first block, RC_ROW2_* row mask (0 = all)
+
+template <int LAYER, int NC>
+__global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F, const LiveGrid G) {
+    constexpr int D = NC == 1 ? 8 : 4, UT = 4 * NC, NT = 16 * NC, LD = NT + 16;
+    __shared__ __attribute__((aligned(16))) float s_part[4 * 16 * LD];
+    __shared__ __attribute__((aligned(16))) float s_h[RC_LIVE_MAXB][UT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int B = F.B;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < G.n && (int)blockIdx.x >= G.base[q]) pi = q;
+    const LiveNet& n = F.net[G.net[pi]];
+    const int mask = G.mask[pi], n_tile = (int)blockIdx.x - G.base[pi];
+    const int H = n.H;
+    // ---- the weight stream first: it depends on nothing but the block id
+    const int Q = 2 * H / 16, Qw = Q / 4;                                  // chunks per wave: 16 / 32 / 40 (multiples of D)
+    const long long bstride = (long long)Q * 256;
+    const float* pb = n.Wl[LAYER] + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
+    f32x4 fa[D], fw[D][NC];
+#define LB(d, qi) do { _Pragma("unroll") for (int j_ = 0; j_ < NC; ++j_) fw[d][j_] = ldg_nt(pb + (long long)(qi) * 256 + j_ * bstride); } while (0)
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) LB(d, d);
+    // ---- every per-row word of this workgroup, one batch behind the first weight requests
+    const int ri = i < B ? i : B - 1;
+    const int st_a = n.steps[ri];
+    const int er = tid / UT, eu = tid - er * UT;                           // epilogue item: row er, unit eu of the tile
+    const bool e_on = tid < 16 * UT && er < B;
+    const int st_e = e_on ? n.steps[er] : 0;
+    float* cst = n.c + (long long)LAYER * B * H;
+    const float c_prev = e_on ? cst[(long long)er * H + n_tile * UT + eu] : 0.f;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&n.bl[LAYER][n_tile * NT + 4 * (tid % UT)]);
+    unsigned amask = 0;                                                    // rows that take this step (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < RC_LIVE_MAXB; ++r)
+        if (r < B && (mask == 0 || (F.fb.flags2[r] & mask))) amask |= 1u << r;
+    f32x4 w2[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) w2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (LAYER == 1 && tid < n.out) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) w2[j] = ldg_nt(n.W2 + (long long)tid * H + n_tile * UT + 4 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (amask == 0) return;                                                // (nothing steps: e.g. rnn4 of occluded rows with the updater off)
+    // ---- A pointers: layer 0 reads relu(linear1) | own h of the previous step; layer 1 reads h of layer 0 (just written) | own h
+    // (st + 2) % 3 = (st - 1) % 3 for every row that has stepped; a row that never has reads a valid copy
+    const long long aoff = rc_pk(ri, 4 * kq, H);
+    const float* pa0 = (LAYER == 0 ? n.x1 : n.h + (long long)(st_a % RC_HBUF) * n.BpH) + aoff;
+    const float* pa1 = n.h + (long long)(LAYER * RC_HBUF + (st_a + 2) % RC_HBUF) * n.BpH + aoff;
+    const int kbase = wave * Qw * 16;
+#define LA(d, qi) do { const int k_ = kbase + (qi) * 16; fa[d] = k_ < H ? *reinterpret_cast<const f32x4*>(pa0 + (long long)k_ * 16) \
+                                                                        : *reinterpret_cast<const f32x4*>(pa1 + (long long)(k_ - H) * 16); } while (0)
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) LA(d, d);
+    f32x4 acc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q + D <= Qw; q += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int qi = min(q + d + D - 1, Qw - 1);                    // past the end: a redundant, valid load, no branch
+            LA((d + D - 1) % D, qi);
+            LB((d + D - 1) % D, qi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[d][s], fw[d][j][s], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef LA
+#undef LB
+    // ---- split-K reduction through LDS, gates, state update (rc_gemm.hip: gemm_tile, RC_EPI_LSTM)
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_part[(wave * 16 + 4 * kq + e) * LD + 16 * j + i] = acc[j][e];
+    __syncthreads();
+    if (e_on) {
+        f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[er * LD + 4 * eu]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) g4 += *reinterpret_cast<const f32x4*>(&s_part[(ww * 16 + er) * LD + 4 * eu]);
+        g4 += bias4;
+        const float ig = rc_gate_sigmoid(g4[0]), fg = rc_gate_sigmoid(g4[1]);
+        const float gg = rc_gate_tanh(g4[2]), og = rc_gate_sigmoid(g4[3]);
+        const float cn = fg * c_prev + ig * gg;
+        const float hn = og * rc_gate_tanh(cn);
+        const bool on = (amask >> er) & 1u;
+        if (on) {
+            const int unit = n_tile * UT + eu;
+            cst[(long long)er * H + unit] = cn;
+            n.h[(long long)(LAYER * RC_HBUF + st_e % RC_HBUF) * n.BpH + rc_pk(er, unit, H)] = hn;
+        }
+        if (LAYER == 1) s_h[er][eu] = hn;
+    }
+    if (LAYER == 1) {                                                      // linear2: this tile's units times their columns of W2
+        __syncthreads();
+        if (tid < n.outp) {
+#pragma unroll
+            for (int r = 0; r < RC_LIVE_MAXB; ++r) {
+                if (!((amask >> r) & 1u)) continue;
+                float p = w2[0][0] * s_h[r][0];
+#pragma unroll
+                for (int u = 1; u < UT; ++u) p = fmaf(w2[u >> 2][u & 3], s_h[r][u], p);
+                n.part[((long long)n_tile * RC_LIVE_MAXB + r) * n.outp + tid] = p;
+            }
+        }
+    }
+}
+
+// ================================================================================================ K7: linear2 sums + tail of the row
+__global__ __launch_bounds__(256) void rc_live_tail_kernel(const LiveFrame F) {
+    __shared__ WaveScratch s_all[1];
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
+    __shared__ __attribute__((aligned(16))) float s_red[1024];
+    __shared__ __attribute__((aligned(16))) LiveSub sub;
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const int ut = 4 * F.nc;
+    const LiveNet &n7 = F.net[LN7], &n6 = F.net[LN6], &n3 = F.net[LN3], &n8 = F.net[LN8];
+    live_reduce<144, 19>(n7.part, n7.H / ut, row, n7.b2, n7.out, sub.r6d, s_red, tid);
+    live_reduce<4, 8>(n6.part, n6.H / ut, row, n6.b2, n6.out, sub.pc, s_red, tid);
+    live_reduce<4, 4>(n3.part, n3.H / ut, row, n3.b2, n3.out, sub.vr, s_red, tid);
+    live_reduce<4, 4>(n8.part, n8.H / ut, row, n8.b2, n8.out, sub.ct, s_red, tid);
+    tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub);
+}
+
+// ================================================================================================================== launcher
+void rc_launch_live_frame(const LiveFrame& F, hipStream_t st) {
+    const dim3 blk(256);
+    const int ut = 4 * F.nc;
+    hipLaunchKernelGGL(rc_live_s1_kernel, dim3((F.net[LN4].H + F.net[LN2].H) / 16), blk, 0, st, F);
+    LiveGrid g1{};
+    g1.n = 2;
+    g1.net[0] = LN4; g1.base[0] = 0; g1.mask[0] = (int)RC_ROW2_M4;
+    g1.net[1] = LN2; g1.base[1] = F.net[LN4].H / ut; g1.mask[1] = 0;
+    const int wg1 = (F.net[LN4].H + F.net[LN2].H) / ut;
+    LiveGrid g2{};
+    g2.n = 4;
+    const int order[4] = {LN6, LN3, LN7, LN8};
+    int wg2 = 0;
+    for (int q = 0; q < 4; ++q) { g2.net[q] = order[q]; g2.base[q] = wg2; g2.mask[q] = order[q] == LN6 ? (int)RC_ROW2_M6 : 0; wg2 += F.net[order[q]].H / ut; }
+    if (F.nc == 2) {
+        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 2>), dim3(wg1), blk, 0, st, F, g1);
+        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 2>), dim3(wg1), blk, 0, st, F, g1);
+    } else {
+        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 1>), dim3(wg1), blk, 0, st, F, g1);
+        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 1>), dim3(wg1), blk, 0, st, F, g1);
+    }
+    hipLaunchKernelGGL(rc_live_s2_kernel, dim3((F.net[LN6].H + F.net[LN3].H + F.net[LN7].H + F.net[LN8].H) / 16), blk, 0, st, F);
+    if (F.nc == 2) {
+        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 2>), dim3(wg2), blk, 0, st, F, g2);
+        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 2>), dim3(wg2), blk, 0, st, F, g2);
+    } else {
+        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 1>), dim3(wg2), blk, 0, st, F, g2);
+        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 1>), dim3(wg2), blk, 0, st, F, g2);
+    }
+    hipLaunchKernelGGL(rc_live_tail_kernel, dim3(F.B), blk, 0, st, F);
+}

@@ -233,6 +233,18 @@ class Net:
         _lib.check(self._ctx, rc, "rc_live_step")
         return pose, tran
 
+    def fusion_state(self):
+        """int32 [batch, 5]: last_tran set, len(floor_y), first_reach, update_vision_count, deferred updater step pending."""
+        t = torch.empty(self.batch, 5, dtype=torch.int32)
+        _lib.check(self._ctx, self._lib.rc_get_fusion_state(self._ctx, _lib.ptr(t), _lib.stream_ptr()), "rc_get_fusion_state")
+        return t
+
+    def live_stats(self):
+        """(frames replayed from the lean seven-launch capture, frames on the full captures) of forward_live so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._ctx, self._lib.rc_get_live_stats(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_stats")
+        return a.value, b.value
+
     @torch.no_grad()
     def forward_sequence(self, j2dc, accc, oric, first_tran=None, first_frame=False):
         """The evaluate.py frame loop (evaluate.py:75-83) for B sequences of T frames in one call.

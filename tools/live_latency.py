@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """BASELINE config 5: batch 1, 60 fps streaming, per-frame latency p50/p99 of forward_online (host tensors in,
-host tensors out): hipGraph-captured frame vs the ordinary enqueue path. Prints one JSON line."""
+host tensors out). Prints one JSON line:
+  graph_c_abi   rc_live_step alone through ctypes on preallocated host tensors (what a C caller of the ABI sees; the default
+                configuration: steady-state frames on the lean seven-launch capture, the rest on the frame-stepped captures)
+  graph         the same through Net.forward_online (Python surface)
+  eager         Net.forward_online without use_graph (rc_step)
+  variants      C-ABI p50/p99 under environment switches (RC_LIVE_LEAN=0: round 3's plan, RC_LIVE_LEAN_NC=2, RC_LIVE_EAGER=1)
+    python tools/live_latency.py [frames=10000] [conf=mixed] [variants=1]"""
 import json
 import os
 import sys
@@ -48,20 +54,53 @@ def run_c(net, m, n):
     return lat[50:] * 1e6
 
 
+def stats(lat):
+    return {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+            "mean_us": round(float(lat.mean()), 1), "fps": round(1e6 / float(lat.mean()), 1)}
+
+
+def make(sd, body, m, graph=True, env=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        net = Net(body=body, batch=1)                                   # the switches are read when the context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    net.load_state_dict(sd)
+    net.gravityc = torch.from_numpy(m["gravityc"])
+    net.use_graph = graph
+    return net
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    conf = sys.argv[2] if len(sys.argv) > 2 else "mixed"
+    variants = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
     sd, body = synth.make_state_dict(0), synth.make_body(1)
-    m = synth.make_motion(7, 1, 600, body, conf="mixed")
+    m = synth.make_motion(7, 1, 600, body, conf=conf)
     out = {}
     for mode in ("graph", "graph_c_abi", "eager"):
-        net = Net(body=body, batch=1)
-        net.load_state_dict(sd)
-        net.gravityc = torch.from_numpy(m["gravityc"])
-        net.use_graph = mode != "eager"
-        lat = run_c(net, m, n) if mode == "graph_c_abi" else run(net, m, n)
-        out[mode] = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
-                     "mean_us": round(float(lat.mean()), 1), "fps": round(1e6 / float(lat.mean()), 1)}
-    print(json.dumps({"metric": "forward_online latency, batch 1, host->host", "frames": n, "weights_MB": 243.06,
+        net = make(sd, body, m, graph=(mode != "eager"))
+        lat = run_c(net, m, n) if mode == "graph_c_abi" else run(net, m, n if mode != "eager" else min(n, 3000))
+        out[mode] = stats(lat)
+        if mode == "graph_c_abi":
+            lean, full = net.live_stats()
+            out[mode]["lean_frames"], out[mode]["full_frames"] = lean, full
+        del net
+    if variants:
+        out["variants"] = {}
+        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}),
+                          ("lean_direct_launches", {"RC_LIVE_EAGER": "1"}), ("lean_again", {})):
+            net = make(sd, body, m, env=env)
+            out["variants"][name] = stats(run_c(net, m, min(n, 4000)))
+            del net
+    print(json.dumps({"metric": "forward_online latency, batch 1, host->host", "frames": n, "conf": conf, "weights_MB": 243.06,
                       "weight_stream_floor_us_at_6.3TBps": 38.6, **out}))
 
 
