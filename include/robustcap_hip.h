@@ -175,6 +175,13 @@ int rc_live_end(rc_ctx* ctx);
  * fixed order instead of one MFMA chain, so a lean frame equals an rc_step frame to rounding (<= 1e-6), not bit for bit.
  * RC_LIVE_LEAN=0 in the environment of rc_create switches it off. Counters: frames replayed from the lean / the full captures. */
 int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames);
+/* Host time of rc_live_step averaged over the lean frames so far, microseconds: {staging the inputs + choosing the capture, enqueue
+ * (hipGraphLaunch), waiting for the frame, copying the outputs}. The frame's GPU time is inside the third. */
+int rc_get_live_profile(rc_ctx* ctx, double* avg_us4);
+/* What rc_live_step uses for steady-state frames after rc_live_begin: *lean_captured = the seven-launch capture exists;
+ * *aql = its dispatches are pre-built AQL packets on an HSA queue of the context's own (csrc/rc_aql.cpp: ~0.5 us of host time per
+ * frame instead of hipGraphLaunch's ~7 us; RC_LIVE_AQL=0 switches it off); note: why not, when it is not (may be NULL). */
+int rc_get_live_backend(rc_ctx* ctx, int32_t* lean_captured, int32_t* aql, char* note, int32_t note_len);
 
 /* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
 /* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:249-264): r6d[n,6] -> R[n,3,3]. */

@@ -122,9 +122,14 @@ struct rc_ctx {
     hipGraph_t live_graph_lean = nullptr;
     hipGraphExec_t live_exec_lean = nullptr;
     LiveFrame live_frame{};
+    int live_aql_on = 1;                                    // RC_LIVE_AQL: 0 = lean frames by hipGraphLaunch only
+    AqlChain* live_aql = nullptr;                           // the lean frame as pre-built AQL packets on a queue of its own (rc_aql.cpp)
+    std::string live_aql_note;                              // why the AQL path is not in use (empty when it is)
     int* live_status_h = nullptr;                           // pinned + mapped: set by a lean frame that met an init_net trigger
     std::vector<unsigned char> live_may_reach;              // host-side, conservative: the row may still trigger init_net (L178-183)
     long long stat_live_lean = 0, stat_live_full = 0;
+    double live_prof_us[4] = {0.0, 0.0, 0.0, 0.0};          // host time of rc_live_step: staging + choice | enqueue | wait | copy out (sums, lean frames)
+    long long live_prof_n = 0;
     // timing of the gate GEMM launches
     bool timing = false;
     int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernel (rc_gemm_kernel)
@@ -1064,6 +1069,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_nt_mask = (unsigned)tune_env("RC_LIVE_NT_MASK", 63);
     ctx->live_lean = tune_env("RC_LIVE_LEAN", 1);
     ctx->live_lean_nc = tune_env("RC_LIVE_LEAN_NC", 1) == 2 ? 2 : 1;
+    ctx->live_aql_on = tune_env("RC_LIVE_AQL", 1);
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
@@ -1470,6 +1476,7 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
     if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
+    if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }
     if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
     if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
     if (ctx->live_status_h) { (void)hipHostFree(ctx->live_status_h); ctx->live_status_h = nullptr; }
@@ -1552,6 +1559,19 @@ int rc_live_begin(rc_ctx* ctx) {
         if (e != hipSuccess) rc = fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture (lean frame): ") + hipGetErrorString(e));
         if (!rc && hipGraphInstantiate(&ctx->live_exec_lean, ctx->live_graph_lean, nullptr, nullptr, 0) != hipSuccess)
             rc = fail(ctx, RC_ERR_HIP, "hipGraphInstantiate (lean frame)");
+        // ... and the same seven dispatches as pre-built AQL packets (rc_aql.cpp); without them the graph above is replayed
+        ctx->live_aql_note.clear();
+        // (not under a profiling tool: rocprofv3's HSA queue interception crashes on packets written straight into the ring --
+        // ROCm 7.2; traces then show the graph replay of the same kernels. RC_LIVE_AQL=2 insists.)
+        const char* preload = std::getenv("LD_PRELOAD");
+        const bool tool = std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("HSA_TOOLS_LIB") || (preload && std::strstr(preload, "rocprofiler"));
+        if (!rc && tool && ctx->live_aql_on == 1) ctx->live_aql_note = "a profiling tool intercepts the HSA queues";
+        else if (!rc && ctx->live_aql_on && ctx->live_zero_copy && !ctx->live_eager) {
+            std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
+            const int nk = rc_live_plan(F, plan.data());
+            char msg[256] = {0};
+            if (rc_aql_create(ctx->dev, plan.data(), nk, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
+        } else if (!rc) ctx->live_aql_note = "switched off";
     }
     ctx->timing = timing;
     ctx->live_maybe_pend.assign(B, 1);
@@ -1566,9 +1586,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (!j2dc || !accc || !oric || !pose || !tran) return fail(ctx, RC_ERR_INVALID, "rc_live_step: null buffer");
     const size_t B = ctx->B;
     hipStream_t st = ctx->live_stream;
+    const auto t_in = std::chrono::steady_clock::now();
+    bool waited_eager = false;
     if (ctx->eager_dirty) {          // e.g. reset_states() on the caller's stream just before this frame
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->eager_ev, 0));
         ctx->eager_dirty = false;
+        waited_eager = true;
     }
     std::memcpy(ctx->live_in_h, j2dc, B * 99 * sizeof(float));
     std::memcpy(ctx->live_in_h + B * 99, accc, B * 18 * sizeof(float));
@@ -1597,6 +1620,8 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         ctx->live_prev_known = true;
     }
     const bool lean = ctx->live_exec_lean && !need_tr && !maybe_reach && !first_tran && !(flags & RC_FLAG_FIRST_FRAME);
+    const auto t_staged = std::chrono::steady_clock::now();
+    bool aql_done = false;
     if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
         if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1605,7 +1630,11 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         if (int rc = step_impl(ctx, io, flags, st)) return rc;
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st));
     } else if (lean) {
-        if (ctx->live_eager) rc_launch_live_frame(ctx->live_frame, st);
+        if (ctx->live_aql) {
+            if (waited_eager) HIP_TRY(ctx, hipStreamSynchronize(st));        // the AQL queue is not ordered behind the stream: wait here
+            if (rc_aql_run(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete");
+            aql_done = true;
+        } else if (ctx->live_eager) rc_launch_live_frame(ctx->live_frame, st);
         else HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec_lean, st));
         ctx->stat_live_lean += 1;
     } else if (ctx->live_eager) {                                // tuning (RC_LIVE_EAGER=1): the 11-14 launches enqueued directly
@@ -1617,9 +1646,10 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     } else {
         HIP_TRY(ctx, hipGraphLaunch(need_tr ? ctx->live_exec : ctx->live_exec_notr, st));
     }
+    const auto t_enq = std::chrono::steady_clock::now();
     // A frame is ~100 us of GPU work: poll for its completion instead of sleeping on the stream (the blocking wait's wake-up
     // costs a sizeable fraction of that); after ~2 ms fall back to the blocking call.
-    {
+    if (!aql_done) {
         const auto t_spin = std::chrono::steady_clock::now();
         hipError_t q;
         while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
@@ -1627,15 +1657,38 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         }
         if (q != hipSuccess && q != hipErrorNotReady) return fail(ctx, RC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
         (void)hipGetLastError();
+        HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(st));
     if (!lean) ctx->stat_live_full += 1;
     if (lean && *ctx->live_status_h != 0) {
         *ctx->live_status_h = 0;
         return fail(ctx, RC_ERR_STATE, "rc_live_step: a lean frame met an init_net trigger (host mirror of first_reach out of date)");
     }
+    const auto t_done = std::chrono::steady_clock::now();
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));
     std::memcpy(tran, ctx->live_out_h + B * 216, B * 3 * sizeof(float));
+    if (lean) {
+        const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        ctx->live_prof_us[0] += us(t_in, t_staged); ctx->live_prof_us[1] += us(t_staged, t_enq); ctx->live_prof_us[2] += us(t_enq, t_done);
+        ctx->live_prof_us[3] += us(t_done, std::chrono::steady_clock::now());
+        ctx->live_prof_n += 1;
+    }
+    return RC_OK;
+}
+
+int rc_get_live_backend(rc_ctx* ctx, int32_t* lean_captured, int32_t* aql, char* note, int32_t note_len) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (lean_captured) *lean_captured = ctx->live_exec_lean ? 1 : 0;
+    if (aql) *aql = ctx->live_aql ? 1 : 0;
+    if (note && note_len > 0) std::snprintf(note, (size_t)note_len, "%s", ctx->live_aql_note.c_str());
+    return RC_OK;
+}
+
+int rc_get_live_profile(rc_ctx* ctx, double* avg_us4) {
+    if (!ctx || !avg_us4) return RC_ERR_INVALID;
+    for (int q = 0; q < 4; ++q) avg_us4[q] = ctx->live_prof_n ? ctx->live_prof_us[q] / (double)ctx->live_prof_n : 0.0;
     return RC_OK;
 }
 

@@ -1,0 +1,197 @@
+// The lean live frame as a chain of AQL packets on an HSA queue of the context's own (host code; the kernels are rc_live.hip's).
+//
+// hipGraphLaunch costs ~7 us of host time per replay on ROCm 7.2 and a further ~10 us between its return, the first kernel and the
+// host noticing the end (tools/launch_probe: a chain of seven 5-us kernels -- graph 58 us, direct launches 53.5 us, this 50.8 us;
+// one kernel: 23.9 / 20.7 / 16.2 us). A live frame is the same seven dispatches every time, with the same arguments (the inputs
+// arrive at fixed pinned addresses): the packets are built ONCE; a frame copies them into the ring, rings the doorbell and polls the
+// last packet's completion signal. Kernel objects are found by symbol among the code objects HIP has loaded (AMD loader
+// extension), kernel arguments live in device memory. Fences: agent scope between the links of the chain, system scope where
+// the host is on the other side (first acquire, last release).
+#include "rc_internal.h"
+
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/hsa_ven_amd_loader.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct AqlChain {
+    hsa_agent_t gpu{};
+    hsa_queue_t* q = nullptr;
+    hsa_signal_t done{};
+    char* kargs = nullptr;                       // device memory: n blocks of kKargStride bytes
+    hsa_kernel_dispatch_packet_t pkt[RC_LIVE_KERNELS]{};
+    uint16_t hdr[RC_LIVE_KERNELS]{};
+    int n = 0;
+    bool hsa_up = false;
+};
+
+namespace {
+constexpr size_t kKargStride = 2048;
+
+struct FindAgent { uint32_t bdf; int count = 0; hsa_agent_t first{}, match{}; bool have_match = false; };
+hsa_status_t agent_cb(hsa_agent_t a, void* d) {
+    FindAgent* f = (FindAgent*)d;
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    if (f->count++ == 0) f->first = a;
+    uint32_t bdf = 0;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS && bdf == f->bdf && !f->have_match) {
+        f->match = a; f->have_match = true;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+
+struct FindSyms { hsa_agent_t gpu; const LiveKernel* k; int n; uint64_t kobj[RC_LIVE_KERNELS]; uint32_t group[RC_LIVE_KERNELS], priv[RC_LIVE_KERNELS], karg[RC_LIVE_KERNELS]; };
+hsa_status_t sym_cb(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t s, void* d) {
+    FindSyms* f = (FindSyms*)d;
+    hsa_symbol_kind_t kind;
+    if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL) return HSA_STATUS_SUCCESS;
+    uint32_t len = 0;
+    hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len);
+    if (len == 0 || len > 200) return HSA_STATUS_SUCCESS;
+    char name[256];
+    hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_NAME, name);
+    name[len] = 0;
+    for (int i = 0; i < f->n; ++i) {
+        const std::string want = std::string(f->k[i].name) + ".kd";
+        if (want != name) continue;
+        hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &f->kobj[i]);
+        hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &f->group[i]);
+        hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &f->priv[i]);
+        hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &f->karg[i]);
+    }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t exec_cb(hsa_executable_t e, void* d) {
+    FindSyms* f = (FindSyms*)d;
+    (void)hsa_executable_iterate_agent_symbols(e, f->gpu, sym_cb, d);
+    return HSA_STATUS_SUCCESS;
+}
+
+int bail(AqlChain* c, char* err, int err_len, const char* what, hsa_status_t st = HSA_STATUS_SUCCESS) {
+    if (err && err_len > 0) {
+        const char* m = nullptr;
+        if (st != HSA_STATUS_SUCCESS) hsa_status_string(st, &m);
+        std::snprintf(err, (size_t)err_len, "%s%s%s", what, m ? ": " : "", m ? m : "");
+    }
+    rc_aql_destroy(c);
+    return -1;
+}
+}  // namespace
+
+int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, char* err, int err_len) {
+    if (!k || !out || n < 1 || n > RC_LIVE_KERNELS) return -1;
+    *out = nullptr;
+    AqlChain* c = new AqlChain();
+    hsa_status_t st = hsa_init();                                    // reference-counted: HIP runs on the same runtime
+    if (st != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_init", st);
+    c->hsa_up = true;
+    c->n = n;
+    // the HSA agent of the HIP device: by PCI bus / device / function
+    FindAgent fa{};
+    {
+        char bus[64] = {0};
+        unsigned dom = 0, b = 0, dv = 0, fn = 0;
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), hip_device) == hipSuccess && std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &dv, &fn) == 4)
+            fa.bdf = (b << 8) | (dv << 3) | fn;
+        else fa.bdf = 0xffffffffu;
+    }
+    if ((st = hsa_iterate_agents(agent_cb, &fa)) != HSA_STATUS_SUCCESS || fa.count == 0) return bail(c, err, err_len, "no GPU agent", st);
+    if (!fa.have_match && fa.count != 1) return bail(c, err, err_len, "cannot match the HIP device to an HSA agent");
+    c->gpu = fa.have_match ? fa.match : fa.first;
+    // kernel objects of the (already loaded) kernels
+    hsa_ven_amd_loader_1_03_pfn_t ld{};
+    if ((st = hsa_system_get_major_extension_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof(ld), &ld)) != HSA_STATUS_SUCCESS ||
+        !ld.hsa_ven_amd_loader_iterate_executables)
+        return bail(c, err, err_len, "AMD loader extension 1.03", st);
+    FindSyms fs{};
+    fs.gpu = c->gpu; fs.k = k; fs.n = n;
+    if ((st = ld.hsa_ven_amd_loader_iterate_executables(exec_cb, &fs)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "iterate executables", st);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t need = (uint32_t)(sizeof(LiveFrame) + (k[i].has_grid ? sizeof(LiveGrid) : 0));
+        if (!fs.kobj[i]) return bail(c, err, err_len, (std::string("kernel symbol not loaded: ") + k[i].name).c_str());
+        // explicit arguments only: a kernel that grew hidden arguments (printf, dynamic LDS, blockDim) does not fit this path
+        if (fs.karg[i] != need || fs.karg[i] > kKargStride) return bail(c, err, err_len, (std::string("unexpected kernarg segment of ") + k[i].name).c_str());
+    }
+    if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
+        return bail(c, err, err_len, "hsa_queue_create", st);
+    if ((st = hsa_signal_create(0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    // kernel arguments: device memory, written once (a frame's inputs arrive at fixed pinned addresses)
+    std::vector<char> host((size_t)n * kKargStride, 0);
+    if (hipMalloc((void**)&c->kargs, host.size()) != hipSuccess) return bail(c, err, err_len, "kernarg buffer");
+    // The LSTM launches find their per-row words in their own argument block (LiveGrid.hot): the linear1 kernel in front of them
+    // writes them there. Launch i's LiveGrid sits behind its LiveFrame; the plan is K1 | l0 l1 | K4 | l0 l1 | K7.
+    LiveGrid* hot[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (n == RC_LIVE_KERNELS) {
+        const int lstm[4] = {1, 2, 4, 5};
+        for (int q = 0; q < 4; ++q) hot[q] = reinterpret_cast<LiveGrid*>(c->kargs + (size_t)lstm[q] * kKargStride + sizeof(LiveFrame));
+    }
+    for (int i = 0; i < n; ++i) {
+        LiveFrame F = k[i].F;
+        for (int q = 0; q < 4; ++q) F.hot[q] = hot[q];
+        std::memcpy(&host[(size_t)i * kKargStride], &F, sizeof(LiveFrame));
+        if (k[i].has_grid) {
+            LiveGrid G = k[i].G;
+            G.hot = hot[0] ? 1 : 0;
+            std::memcpy(&host[(size_t)i * kKargStride + sizeof(LiveFrame)], &G, sizeof(LiveGrid));
+        }
+    }
+    if (hipMemcpy(c->kargs, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(c, err, err_len, "kernarg upload");
+    for (int i = 0; i < n; ++i) {
+        hsa_kernel_dispatch_packet_t& p = c->pkt[i];
+        std::memset(&p, 0, sizeof(p));
+        p.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        p.workgroup_size_x = 256; p.workgroup_size_y = 1; p.workgroup_size_z = 1;
+        p.grid_size_x = k[i].grid * 256u; p.grid_size_y = 1; p.grid_size_z = 1;
+        p.private_segment_size = fs.priv[i]; p.group_segment_size = fs.group[i];
+        p.kernel_object = fs.kobj[i];
+        p.kernarg_address = c->kargs + (size_t)i * kKargStride;
+        p.completion_signal = i == n - 1 ? c->done : hsa_signal_t{0};
+        const int acq = i == 0 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        const int rel = i == n - 1 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        c->hdr[i] = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                               (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+    }
+    *out = c;
+    return 0;
+}
+
+int rc_aql_run(AqlChain* c) {
+    if (!c || !c->q) return -1;
+    hsa_queue_t* q = c->q;
+    const uint32_t mask = q->size - 1;
+    hsa_signal_store_relaxed(c->done, 1);
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; the queue is empty (every run waits)
+    for (int i = 0; i < c->n; ++i) {
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & mask);
+        // body first, header (which hands the packet to the packet processor) last
+        std::memcpy((char*)p + 4, (const char*)&c->pkt[i] + 4, sizeof(*p) - 4);
+        __atomic_store_n((uint32_t*)p, (uint32_t)c->hdr[i] | ((uint32_t)c->pkt[i].setup << 16), __ATOMIC_RELEASE);
+    }
+    hsa_queue_store_write_index_release(q, base + c->n);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + c->n - 1));
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (hsa_signal_load_scacquire(c->done) != 0) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            // a frame is ~100 us: something is slow (profiler, contention) -- sleep on the signal, give up after 10 s
+            if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, 0, 10000000000ull, HSA_WAIT_STATE_BLOCKED) != 0) return -2;
+            break;
+        }
+    }
+    return 0;
+}
+
+void rc_aql_destroy(AqlChain* c) {
+    if (!c) return;
+    if (c->q) (void)hsa_queue_destroy(c->q);
+    if (c->done.handle) (void)hsa_signal_destroy(c->done);
+    if (c->kargs) (void)hipFree(c->kargs);
+    if (c->hsa_up) (void)hsa_shut_down();
+    delete c;
+}

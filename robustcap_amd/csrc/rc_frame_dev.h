@@ -4,6 +4,15 @@
 #include "rc_internal.h"
 #include "rc_device.h"
 
+// -DRC_LIVE_TRACE (tools/live_trace.py; never in the product library): thread 0 of block 0 stamps points inside the lean live
+// frame's kernels with the 100 MHz wall clock -- where a latency-bound kernel spends its microseconds.
+#ifdef RC_LIVE_TRACE
+__device__ unsigned long long g_live_tt[4][16];
+#define RC_LT(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_live_tt[k][i] = wall_clock64(); } while (0)
+#else
+#define RC_LT(k, i) do { } while (0)
+#endif
+
 #define LD_X2 128
 #define LD_X3 256
 #define LD_X4 256
@@ -152,21 +161,49 @@ __device__ __forceinline__ unsigned prep_body(const FrameBuffers& fb, const Fram
 // LIVE (rc_live.hip: the last kernel of the lean live frame): a 256-thread workgroup per row whose four waves have just summed the
 // second stage's linear2 partial sums into `sub` (LDS); all of them stage the body constants, then wave 0 runs the row.
 struct LiveSub { float r6d[144]; float pc[4]; float vr[4]; float ct[4]; };
+// The per-row words of the tail, GATHERED: lane l loads word l of this list with ONE vector load and the values are handed out with
+// readlane -- as wave-uniform reads they would be scalar loads, each waiting for the previous one (s_waitcnt lgkmcnt(0)).
+struct TailRegs { float gv; unsigned bv; float acc_l, ori_l; };
+template <bool LIVE>
+__device__ __forceinline__ void tail_request(TailRegs& t, const FrameBuffers& fb, const FrameIO& io, const int row, const int lane) {
+    const float* ori = io.ori + row * io.s_ori;
+    const float* acc = io.acc + row * io.s_acc;
+    const bool ft_given = io.first_tran != nullptr;
+    const float* gp = nullptr;
+    if (lane < 6) gp = fb.last_pfoot + row * 6 + lane;
+    else if (lane < 9) gp = fb.last_tran + row * 3 + (lane - 6);
+    else if (lane < 12) gp = fb.gravity + row * 3 + (lane - 9);
+    else if (lane < 15) gp = LIVE ? nullptr : fb.pc + row * 4 + (lane - 12);       // (LIVE: the sub-net outputs come from LDS)
+    else if (lane < 18) gp = LIVE ? nullptr : fb.vr + row * 4 + (lane - 15);
+    else if (lane < 20) gp = LIVE ? nullptr : fb.contact + row * 2 + (lane - 18);
+    else if (lane < 38) gp = fb.floor + row * 33 + 15 + (lane - 20);              // floor samples 5..10 (L213: mean of the last six)
+    else if (lane < 47) gp = ori + 45 + (lane - 38);                               // Rcr, L139
+    else if (lane < 50) gp = ft_given ? io.first_tran + row * 3 + (lane - 47) : nullptr;
+    else if (lane < 52) gp = reinterpret_cast<const float*>(fb.kconf + row) + (lane - 50);
+    else if (lane == 52) gp = reinterpret_cast<const float*>(fb.has_last + row);
+    else if (lane == 53) gp = reinterpret_cast<const float*>(fb.n_floor + row);
+    else if (lane == 54) gp = reinterpret_cast<const float*>(fb.uv_count + row);
+    t.gv = gp ? *gp : 0.f;
+    const unsigned char* bp = lane == 0 ? fb.flags + row : (lane == 1 ? fb.regime + row : nullptr);
+    t.bv = bp ? (unsigned)*bp : 0u;
+    t.acc_l = lane < 18 ? acc[lane] : 0.f;                                         // this frame's IMU data (updater inputs)
+    t.ori_l = lane < 54 ? ori[lane] : 0.f;
+}
+// LIVE: the caller (rc_live_tail_kernel) has staged the body constants, requested the row's words (`pre`) and summed the sub-net
+// outputs into `sub` (LDS) behind ONE batch of loads; wave 0 runs the row with wave-local synchronisation.
 template <int RPB, bool LIVE>
 __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_params_dev& prm, const BodyConst* __restrict__ body_g,
                                           const int B, const int first_frame, const FrameIO& io_next, const int has_next, WaveTail wt,
-                                          WaveScratch* s_all, BodyConst& s_body, const LiveSub* sub) {
+                                          WaveScratch* s_all, BodyConst& s_body, const LiveSub* sub, const TailRegs* pre = nullptr) {
     constexpr bool WL = RPB > 1 || LIVE;
     const int row = LIVE ? (int)blockIdx.x : (int)(blockIdx.x * RPB + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     WaveScratch& s = s_all[LIVE ? 0 : (threadIdx.x >> 6)];
-    if constexpr (WL) {
-        constexpr int NTH = LIVE ? 256 : 64 * RPB;
-        BodyStage<NTH> bsa;
+    if constexpr (WL && !LIVE) {
+        BodyStage<64 * RPB> bsa;
         bsa.load(body_g, threadIdx.x);
         bsa.store(&s_body, threadIdx.x);
-        __syncthreads();                                                   // (LIVE: also publishes `sub`)
+        __syncthreads();
         if (row >= B) return;
-        if (LIVE && threadIdx.x >= 64) return;
     }
     int frame = 0;
     if (wt.on) {
@@ -177,38 +214,20 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
     }
     const bool wave_ride = wt.on && frame != wt.t_last;                    // updater inputs ride the target slot
     // ---- every global read of this wave, requested up front (one memory latency instead of a chain of ~10: this kernel is a
-    // dependent-latency chain, 1,560 B of I/O per body). The ~55 per-row scalars (fusion state, sub-net outputs, root orientation)
-    // are GATHERED: lane l loads word l of the list below with one vector load and the values are handed out with readlane --
-    // as wave-uniform reads they would be scalar loads, each waiting for the previous one (s_waitcnt lgkmcnt(0)).
-    // The state reads are safe to hoist: only this wave writes its row.
+    // dependent-latency chain, 1,560 B of I/O per body). The state reads are safe to hoist: only this wave writes its row.
     BodyStage<64> bst;
     if constexpr (!WL) bst.load(body_g, lane);
-    const float* ori = io.ori + row * io.s_ori;
-    const float* acc = io.acc + row * io.s_acc;
     const bool ft_given = io.first_tran != nullptr;
-    const float* gp = nullptr;
-    if (lane < 6) gp = fb.last_pfoot + row * 6 + lane;
-    else if (lane < 9) gp = fb.last_tran + row * 3 + (lane - 6);
-    else if (lane < 12) gp = fb.gravity + row * 3 + (lane - 9);
-    else if (lane < 15) gp = LIVE ? nullptr : fb.pc + row * 4 + (lane - 12);
-    else if (lane < 18) gp = LIVE ? nullptr : fb.vr + row * 4 + (lane - 15);
-    else if (lane < 20) gp = LIVE ? nullptr : fb.contact + row * 2 + (lane - 18);
-    else if (lane < 38) gp = fb.floor + row * 33 + 15 + (lane - 20);              // floor samples 5..10 (L213: mean of the last six)
-    else if (lane < 47) gp = ori + 45 + (lane - 38);                               // Rcr, L139
-    else if (lane < 50) gp = ft_given ? io.first_tran + row * 3 + (lane - 47) : nullptr;
-    else if (lane < 52) gp = reinterpret_cast<const float*>(fb.kconf + row) + (lane - 50);
-    else if (lane == 52) gp = reinterpret_cast<const float*>(fb.has_last + row);
-    else if (lane == 53) gp = reinterpret_cast<const float*>(fb.n_floor + row);
-    else if (lane == 54) gp = reinterpret_cast<const float*>(fb.uv_count + row);
-    const float gv = gp ? *gp : 0.f;
-    const unsigned char* bp = lane == 0 ? fb.flags + row : (lane == 1 ? fb.regime + row : nullptr);
-    const unsigned bv = bp ? (unsigned)*bp : 0u;
+    TailRegs tr_;
+    if constexpr (LIVE) tr_ = *pre; else tail_request<false>(tr_, fb, io, row, lane);
+    const float gv = tr_.gv;
+    const unsigned bv = tr_.bv;
     float r6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (lane < 24) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) r6[k] = LIVE ? sub->r6d[6 * lane + k] : fb.r6d[row * 144 + 6 * lane + k];
     }
-    const float acc_l = lane < 18 ? acc[lane] : 0.f, ori_l = lane < 54 ? ori[lane] : 0.f;   // this frame's IMU data (updater inputs)
+    const float acc_l = tr_.acc_l, ori_l = tr_.ori_l;
     PrepIn nin;
     if (has_next) prep_load(nin, io_next, row, lane);
     if constexpr (!WL) bst.store(&s_body, lane);                          // (LDS: visible to the wave after the first barrier)
@@ -239,6 +258,7 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
     const int uvc = __float_as_int(lane_bcast(gv, 54));
     const unsigned flags = (unsigned)__builtin_amdgcn_readlane((int)bv, 0);
     const int regime = __builtin_amdgcn_readlane((int)bv, 1);
+    if constexpr (LIVE) RC_LT(2, 3);
 
     // L173: 6D -> global rotations (root-relative frame)
     if (lane < 24) {
@@ -248,6 +268,7 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
         for (int k = 0; k < 9; ++k) s.Rg[lane][k] = R[k];
     }
     rc_sync<WL>();
+    if constexpr (LIVE) RC_LT(2, 4);
     // L174-175: local rotations, root replaced by the pelvis IMU orientation
     if (lane < 24) {
         float R[9];
@@ -257,19 +278,21 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
         } else {
             mat3T_mul(s.Rg[body->parent[lane]], s.Rg[lane], R);
         }
-        float* po = io.pose_out + row * io.s_pose + 9 * lane;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { s.Rl[lane][k] = R[k]; po[k] = R[k]; }
+        for (int k = 0; k < 9; ++k) s.Rl[lane][k] = R[k];                   // (written out below, 256 contiguous bytes per store)
     }
-    // L186: feet from the predicted GLOBAL rotations, rotated to the camera frame
+    // L186: feet from the predicted GLOBAL rotations, rotated to the camera frame. Even lanes walk the chain of joint 10, odd lanes
+    // that of joint 11 (two dependent chains of LDS reads side by side instead of one after the other), then both are broadcast.
     float pf[2][3];
+    {
+        float jf[3], pl[3];
+        bone_chain(body, s.Rg, 10 + (lane & 1), jf);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        float jf[3];
-        bone_chain(body, s.Rg, 10 + f, jf);
+        for (int c = 0; c < 3; ++c) pl[c] = (jf[0] * Rcr[3 * c] + jf[1] * Rcr[3 * c + 1]) + jf[2] * Rcr[3 * c + 2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pf[f][c] = (jf[0] * Rcr[3 * c] + jf[1] * Rcr[3 * c + 1]) + jf[2] * Rcr[3 * c + 2];
+        for (int c = 0; c < 3; ++c) { pf[0][c] = lane_bcast(pl[c], 0); pf[1][c] = lane_bcast(pl[c], 1); }
     }
+    if constexpr (LIVE) RC_LT(2, 5);
 
     // L187-203: root translation
     const float c0 = sigmoidf_(ct0), c1 = sigmoidf_(ct1);                  // L170
@@ -352,7 +375,15 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
     const bool refresh = !live || uvc == 0;
     const int uvc_next = (live && (prm.use_reproj_opt || prm.use_vision_updater)) ? (refresh ? prm.update_vision_freq : uvc - 1) : uvc;
     const int pend_next = ((flags & RC_ROW_UPD) && !wave_ride) ? 1 : 0;
+    if constexpr (LIVE) RC_LT(2, 6);
     rc_sync<WL>();   // all lanes have read the per-row state; lane 0 may now overwrite it
+    {
+        float* po = io.pose_out + row * io.s_pose;                         // L174-175 -> output (s.Rl is complete behind the barrier above)
+        const float* rl = &s.Rl[0][0];
+#pragma unroll
+        for (int e = lane; e < 216; e += 64) po[e] = rl[e];
+    }
+    if constexpr (LIVE) RC_LT(2, 7);
     if (lane == 0) {                                                       // L227, L273
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -384,9 +415,15 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
         tr[7] = (far && regime == 2) ? 1 : 0;
     }
 
-    // L228-242: mesh landmarks from the LOCAL pose chained from the camera-frame root
-    wave_body_fk<WL>(body, s, tran, lane);
-    if (live && (prm.use_reproj_opt || prm.use_vision_updater)) {
+    // L228-242: mesh landmarks from the LOCAL pose chained from the camera-frame root. The reference skins the mesh on every frame;
+    // its landmarks are READ only by the vision updater (L264-271), the optional re-projection refinement (L245-261) and the live
+    // mode's landmark cache (L234-242) -- on every other frame (a visible row, the common case) the chain and the skinning are
+    // skipped: the frame's outputs do not depend on them. (Wave-uniform: flags, regime and the counters are per row.)
+    const bool need_mesh = (flags & RC_ROW_UPD) || (prm.use_reproj_opt && regime >= 1) ||
+                           (live && refresh && (prm.use_reproj_opt || prm.use_vision_updater));
+    if (need_mesh) wave_body_fk<WL>(body, s, tran, lane);
+    if constexpr (LIVE) RC_LT(2, 8);
+    if (need_mesh && live && (prm.use_reproj_opt || prm.use_vision_updater)) {
         if (lane < 33) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -462,6 +499,7 @@ __device__ __forceinline__ void tail_impl(FrameBuffers fb, FrameIO io, const rc_
         }
     }
     if (has_next) prep_compute(fb, nin, prm, row, lane, 0, pend_next, uvc_next);
+    if constexpr (LIVE) RC_LT(2, 9);
 }
 
 template <int RPB>

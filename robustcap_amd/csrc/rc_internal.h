@@ -175,6 +175,12 @@ struct rc_params_dev {
 // boundary (no atomics, no fences, nothing placement-dependent). Every kernel requests its weights first and its per-row words
 // (flags, step parities, cell state) in the same batch: one memory latency in front of the first MFMA instead of a chain of four.
 #define RC_LIVE_MAXB 4
+// Problems of an LSTM launch: sub-net, first block, RC_ROW2_* row mask (0 = all rows). `hot`: the per-row words the launch needs
+// before its first activation load -- step number (-> which copy of h) and whether the row steps -- are IN the kernel arguments:
+// on the AQL path (rc_aql.cpp) the arguments live in device memory of the context's own, and the linear1 kernel that opens the
+// steps (K1 / K4) writes them there, so the LSTM kernels have no dependent global read (3.6 -> ~1.3 us from entry to the first
+// activation load: tools/live_trace.py) in front of the weight stream. hot = 0 (graph replay, direct launches): read from the state.
+struct LiveGrid { int n; int net[4]; int base[4]; int mask[4]; int hot; int st[4][RC_LIVE_MAXB]; int act[4][RC_LIVE_MAXB]; };
 struct LiveNet {
     const float *W1, *b1;           // linear1: pack_weights order [N/16][Kp1/16][64][4], bias
     const float *Wl[2], *bl[2];     // LSTM layers: pack_weights order, gate-interleaved columns; b_ih + b_hh
@@ -191,10 +197,28 @@ struct LiveFrame {
     rc_params_dev prm;
     const BodyConst* body;
     int* status;                    // device word, set != 0 when a frame the lean plan does not cover reached it (init_net trigger)
+    LiveGrid* hot[4];               // AQL path: the LiveGrid argument blocks of K2, K3 (written by K1) and K5, K6 (by K4); else null
     int B;
     int nc;                         // 16-column blocks per LSTM tile (1 or 2)
 };
+#define RC_LIVE_KERNELS 7
+struct LiveKernel {             // one launch of the lean frame: host function + symbol name, grid (workgroups of 256), arguments
+    const void* fn;
+    const char* name;
+    unsigned grid;
+    int has_grid;               // arguments: (LiveFrame) or (LiveFrame, LiveGrid)
+    LiveFrame F;
+    LiveGrid G;
+};
+int rc_live_plan(const LiveFrame& F, LiveKernel* out);                // fills RC_LIVE_KERNELS entries, returns their number
 void rc_launch_live_frame(const LiveFrame& F, hipStream_t s);
+
+// The same chain as AQL packets on an HSA queue of the context's own (rc_aql.cpp): rc_live_step then pays ~0.5 us of host time to
+// enqueue the frame instead of hipGraphLaunch's ~7 us, and polls the completion signal itself.
+struct AqlChain;
+int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, char* err, int err_len);
+int rc_aql_run(AqlChain* c);                                          // submit, then spin until the last packet's signal; 0 = done
+void rc_aql_destroy(AqlChain* c);
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);

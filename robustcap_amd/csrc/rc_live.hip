@@ -32,35 +32,41 @@ __device__ __forceinline__ f32x4 ldg_nt(const float* p) { return __builtin_nonte
 
 // ---- sum of a sub-net's linear2 partials for one row ---------------------------------------------------------------------------
 // part[(tile * RC_LIVE_MAXB + row) * OUTP + o]; OUTP / 4 column groups x S slices of tiles (slice sl owns tiles sl, sl + S, ...):
-// every thread sums its slice in ascending order, the slices meet in LDS and are added in ascending order, then the bias.
-// The order depends on (n_tiles, OUTP) only. All loads of a thread are in flight together.
+// a thread sums its slice in ascending order, the slices meet in LDS and are added in ascending order, then the bias. The order
+// depends on (n_tiles, OUTP) only. Three phases so that a kernel can put the loads of ALL its sums (and its other reads) in flight
+// together and pay one memory latency: request (loads -> registers), slices (-> LDS; a block barrier follows), finish (-> dst).
+// `t` is the thread's index within the group of G * S threads that works on this sum.
 template <int OUTP, int MAXT>      // MAXT >= ceil(n_tiles / S)
-__device__ __forceinline__ void live_reduce(const float* __restrict__ part, const int n_tiles, const int row, const float* __restrict__ bias,
-                                            const int out, float* dst, float* s_red, const int tid) {
-    constexpr int G = OUTP / 4, S = (256 / G) < 32 ? (256 / G) : 32;
-    const int g = tid % G, sl = tid / G;
+struct LiveSum {
+    static constexpr int G = OUTP / 4, S = (256 / G) < 32 ? (256 / G) : 32, THREADS = G * S;
     f32x4 v[MAXT];
-    if (sl < S) {
+    __device__ __forceinline__ void request(const float* __restrict__ part, const int n_tiles, const int row, const int t) {
+        const int g = t % G, sl = t / G;
 #pragma unroll
         for (int q = 0; q < MAXT; ++q) {
             const int tl = sl + q * S;
-            v[q] = tl < n_tiles ? *reinterpret_cast<const f32x4*>(part + ((long long)tl * RC_LIVE_MAXB + row) * OUTP + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[q] = (t >= 0 && t < THREADS && tl < n_tiles)
+                       ? *reinterpret_cast<const f32x4*>(part + ((long long)tl * RC_LIVE_MAXB + row) * OUTP + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    }
+    __device__ __forceinline__ void slices(const int n_tiles, float* s_red, const int t) const {
+        if (t < 0 || t >= THREADS) return;
+        const int g = t % G, sl = t / G;
         f32x4 a = v[0];
 #pragma unroll
         for (int q = 1; q < MAXT; ++q)
             if (sl + q * S < n_tiles) a += v[q];
         *reinterpret_cast<f32x4*>(s_red + sl * OUTP + 4 * g) = a;
     }
-    __syncthreads();
-    if (tid < out) {
-        float y = s_red[tid];
+    // bias_t: bias[t] of the finishing thread, loaded by the caller WITH the partials (a global read here would be a second latency)
+    static __device__ __forceinline__ void finish(const float* s_red, const float bias_t, const int out, float* dst, const int t) {
+        if (t < 0 || t >= out) return;
+        float y = s_red[t];
 #pragma unroll 4
-        for (int q = 1; q < S; ++q) y += s_red[q * OUTP + tid];
-        dst[tid] = y + bias[tid];
+        for (int q = 1; q < S; ++q) y += s_red[q * OUTP + t];
+        dst[t] = y + bias_t;
     }
-    __syncthreads();
-}
+};
 
 // ---- one 16-column tile of a linear1 layer, A operand in LDS --------------------------------------------------------------------
 // The arithmetic of gemm_tile<1, 1, ...> of rc_gemm.hip for a dense layer: wave w owns the k chunks [w Qw, (w + 1) Qw), the wave
@@ -108,7 +114,7 @@ __device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, cons
 // Grid: rnn4's H / 16 column tiles, then rnn2's. Wave w of EVERY workgroup runs the prep of row w (684 B of inputs, < 1 k FLOP) and
 // leaves the sub-net's input row in LDS; the first workgroup of each net also performs the prep's stores (row flags, the input
 // rows later stages read, trace) and opens the step (rc_gemm.hip: open_step).
-__global__ __launch_bounds__(256) void rc_live_s1_kernel(const LiveFrame F) {
+extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) {
     __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
     __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(256) void rc_live_s1_kernel(const LiveFrame F) {
     const bool is4 = (int)blockIdx.x < t4;
     const LiveNet& n = is4 ? F.net[LN4] : F.net[LN2];
     const int n_tile = is4 ? (int)blockIdx.x : (int)blockIdx.x - t4;
+    RC_LT(0, 0);
     Lin1W w;
     lin1_request(w, n, n_tile, tid);
     if (wave < B) {
@@ -124,9 +131,11 @@ __global__ __launch_bounds__(256) void rc_live_s1_kernel(const LiveFrame F) {
         PrepIn in;
         prep_load(in, F.io, row, lane);
         const int pend = F.fb.pend[row], uvc = F.fb.uv_count[row];
+        const int st_old = (n_tile == 0 && lane == 0) ? n.steps[row] : 0;
         // the deferred updater's input row (rows that are not on camera but carry a pending step read it, L264-271)
         const f32x4 xl = is4 ? *reinterpret_cast<const f32x4*>(F.fb.x4l + rc_pk(row, 4 * lane, LD_X4)) : f32x4{0.f, 0.f, 0.f, 0.f};
         const PrepVals pv = prep_values(in, F.prm, lane, 0, pend, uvc);
+        RC_LT(0, 1);
         float* x = s_x[row];
         if (is4) {
             if (pv.f & RC_ROW_VIS) {
@@ -142,23 +151,30 @@ __global__ __launch_bounds__(256) void rc_live_s1_kernel(const LiveFrame F) {
             if (lane < 54) x[18 + lane] = pv.orir;
             if (lane < 56) x[72 + lane] = 0.0f;
         }
-        if (blockIdx.x == 0) {
-            prep_store(F.fb, in, pv, row, lane);
-            if (lane == 0 && (pv.f2 & RC_ROW2_M4)) n.steps[row] += 1;
+        if (blockIdx.x == 0) prep_store(F.fb, in, pv, row, lane);
+        if (n_tile == 0 && lane == 0) {                                     // the step this frame takes (rc_gemm.hip: open_step)
+            const bool on = !is4 || (pv.f2 & RC_ROW2_M4);
+            const int stn = st_old + (on ? 1 : 0);
+            if (on) n.steps[row] = stn;
+            const int p = is4 ? 0 : 1;                                      // problem order of the first stage's LSTM launches: rnn4, rnn2
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (F.hot[q]) { F.hot[q]->st[p][row] = stn; F.hot[q]->act[p][row] = on ? 1 : 0; }
         }
-        if ((int)blockIdx.x == t4 && lane == 0) n.steps[row] += 1;
     }
     __syncthreads();
+    RC_LT(0, 2);
     lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+    RC_LT(0, 3);
 }
 
 // ============================================================================= K4: linear2 sums + fuse + linear1 of the second stage
 // Grid: column tiles of rnn6, rnn3, rnn7, rnn8. Every workgroup sums the partials it needs (rnn6: rnn4's output, rnn3: rnn2's,
 // rnn7 / rnn8: both, then the fuse of L154-167 with the arithmetic of rc_fuse_kernel) and builds its input rows in LDS.
-__global__ __launch_bounds__(256) void rc_live_s2_kernel(const LiveFrame F) {
+extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) {
     __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
     __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
-    __shared__ __attribute__((aligned(16))) float s_red[1024];
+    __shared__ __attribute__((aligned(16))) float s_red[2048];
     __shared__ __attribute__((aligned(16))) float s_y4[RC_LIVE_MAXB][72], s_y2[RC_LIVE_MAXB][72];
     const int tid = threadIdx.x;
     const int B = F.B;
@@ -167,10 +183,14 @@ __global__ __launch_bounds__(256) void rc_live_s2_kernel(const LiveFrame F) {
     const int ni = b < t6 ? LN6 : (b < t6 + t3 ? LN3 : (b < t6 + t3 + t7 ? LN7 : LN8));
     const int n_tile = ni == LN6 ? b : (ni == LN3 ? b - t6 : (ni == LN7 ? b - t6 - t3 : b - t6 - t3 - t7));
     const LiveNet& n = F.net[ni];
+    RC_LT(1, 0);
     Lin1W w;
     lin1_request(w, n, n_tile, tid);
     // the prefix of the input rows (written by K1's first workgroup) and the alternative row of rnn6 -- requested before the sums
     float xin[RC_LIVE_MAXB], xalt[RC_LIVE_MAXB];
+    int st_old[RC_LIVE_MAXB];
+#pragma unroll
+    for (int r = 0; r < RC_LIVE_MAXB; ++r) st_old[r] = (r < B && n_tile == 0 && tid == 0) ? n.steps[r] : 0;
     const float* xsrc = ni == LN6 ? F.fb.x6 : (ni == LN3 ? F.fb.x3 : F.fb.x78);
 #pragma unroll
     for (int r = 0; r < RC_LIVE_MAXB; ++r) {
@@ -179,10 +199,23 @@ __global__ __launch_bounds__(256) void rc_live_s2_kernel(const LiveFrame F) {
     }
     const LiveNet& n4 = F.net[LN4];
     const LiveNet& n2 = F.net[LN2];
-    for (int r = 0; r < B; ++r) {
-        if (ni != LN3) live_reduce<72, 24>(n4.part, n4.H / (4 * F.nc), r, n4.b2, n4.out, s_y4[r], s_red, tid);
-        if (ni != LN6) live_reduce<72, 10>(n2.part, n2.H / (4 * F.nc), r, n2.b2, n2.out, s_y2[r], s_red, tid);
+    for (int r = 0; r < B; ++r) {                                         // both sums of a row behind one batch of loads
+        LiveSum<72, 23> s4;
+        LiveSum<72, 10> s2;
+        const int nt4 = n4.H / (4 * F.nc), nt2 = n2.H / (4 * F.nc);
+        if (ni != LN3) s4.request(n4.part, nt4, r, tid);
+        if (ni != LN6) s2.request(n2.part, nt2, r, tid);
+        const float b4 = tid < n4.out ? n4.b2[tid] : 0.f, b2 = tid < n2.out ? n2.b2[tid] : 0.f;
+        if (r > 0) __syncthreads();                                         // the previous row's finish has read s_red
+        if (ni != LN3) s4.slices(nt4, s_red, tid);
+        if (ni != LN6) s2.slices(nt2, s_red + 1024, tid);
+        __syncthreads();
+        RC_LT(1, 1);
+        if (ni != LN3) LiveSum<72, 23>::finish(s_red, b4, n4.out, s_y4[r], tid);
+        if (ni != LN6) LiveSum<72, 10>::finish(s_red + 1024, b2, n2.out, s_y2[r], tid);
     }
+    __syncthreads();
+    RC_LT(1, 2);
     for (int r = 0; r < B; ++r) {
         const unsigned fl = F.fb.flags[r];
         const int regime = F.fb.regime[r];
@@ -212,20 +245,26 @@ __global__ __launch_bounds__(256) void rc_live_s2_kernel(const LiveFrame F) {
         }
         s_x[r][tid] = v;
         if (n_tile == 0 && tid == 0) {                                      // the step this frame takes (rc_gemm.hip: open_step)
-            if (ni != LN6 || (F.fb.flags2[r] & RC_ROW2_M6)) n.steps[r] += 1;
+            const bool on = ni != LN6 || (F.fb.flags2[r] & RC_ROW2_M6);
+            const int stn = st_old[r] + (on ? 1 : 0);
+            if (on) n.steps[r] = stn;
+            const int p = ni == LN6 ? 0 : (ni == LN3 ? 1 : (ni == LN7 ? 2 : 3));   // problem order of the second stage's LSTM launches
+#pragma unroll
+            for (int q = 2; q < 4; ++q)
+                if (F.hot[q]) { F.hot[q]->st[p][r] = stn; F.hot[q]->act[p][r] = on ? 1 : 0; }
             // L178-180: a frame that would trigger init_net is not this plan's (rc_api.cpp keeps it away; checked by rc_live_step)
             if (ni == LN6 && regime == 2 && F.prm.use_imu_updater && F.fb.first_reach[r]) *F.status = 1;
         }
     }
     __syncthreads();
+    RC_LT(1, 3);
     lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+    RC_LT(1, 4);
 }
 
 // ========================================================================================= K2 / K3 / K5 / K6: one LSTM layer step
-struct LiveGrid { int n; int net[4]; int base[4]; int mask[4]; };          // problems of the launch: sub-net, first block, RC_ROW2_* row mask (0 = all)
-
 template <int LAYER, int NC>
-__global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F, const LiveGrid G) {
+__device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGrid& G) {
     constexpr int D = NC == 1 ? 8 : 4, UT = 4 * NC, NT = 16 * NC, LD = NT + 16;
     __shared__ __attribute__((aligned(16))) float s_part[4 * 16 * LD];
     __shared__ __attribute__((aligned(16))) float s_h[RC_LIVE_MAXB][UT];
@@ -238,6 +277,7 @@ __global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F,
     const LiveNet& n = F.net[G.net[pi]];
     const int mask = G.mask[pi], n_tile = (int)blockIdx.x - G.base[pi];
     const int H = n.H;
+    RC_LT(3, 0 + 5 * LAYER);
     // ---- the weight stream first: it depends on nothing but the block id
     const int Q = 2 * H / 16, Qw = Q / 4;                                  // chunks per wave: 16 / 32 / 40 (multiples of D)
     const long long bstride = (long long)Q * 256;
@@ -248,17 +288,29 @@ __global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F,
     for (int d = 0; d < D - 1; ++d) LB(d, d);
     // ---- every per-row word of this workgroup, one batch behind the first weight requests
     const int ri = i < B ? i : B - 1;
-    const int st_a = n.steps[ri];
     const int er = tid / UT, eu = tid - er * UT;                           // epilogue item: row er, unit eu of the tile
     const bool e_on = tid < 16 * UT && er < B;
-    const int st_e = e_on ? n.steps[er] : 0;
+    int st_a, st_e;
+    unsigned amask = 0;                                                    // rows that take this step (wave-uniform)
+    if (G.hot) {                                                           // in the kernel arguments (written by K1 / K4): no global read
+        const int* hs = G.st[pi];
+        const int* ha = G.act[pi];
+        const int s0 = hs[0], s1 = hs[1], s2 = hs[2], s3 = hs[3];
+        st_a = ri == 0 ? s0 : (ri == 1 ? s1 : (ri == 2 ? s2 : s3));
+        st_e = er == 0 ? s0 : (er == 1 ? s1 : (er == 2 ? s2 : s3));
+#pragma unroll
+        for (int r = 0; r < RC_LIVE_MAXB; ++r)
+            if (r < B && ha[r]) amask |= 1u << r;
+    } else {
+        st_a = n.steps[ri];
+        st_e = e_on ? n.steps[er] : 0;
+#pragma unroll
+        for (int r = 0; r < RC_LIVE_MAXB; ++r)
+            if (r < B && (mask == 0 || (F.fb.flags2[r] & mask))) amask |= 1u << r;
+    }
     float* cst = n.c + (long long)LAYER * B * H;
     const float c_prev = e_on ? cst[(long long)er * H + n_tile * UT + eu] : 0.f;
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&n.bl[LAYER][n_tile * NT + 4 * (tid % UT)]);
-    unsigned amask = 0;                                                    // rows that take this step (wave-uniform)
-#pragma unroll
-    for (int r = 0; r < RC_LIVE_MAXB; ++r)
-        if (r < B && (mask == 0 || (F.fb.flags2[r] & mask))) amask |= 1u << r;
     f32x4 w2[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) w2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -281,6 +333,7 @@ __global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F,
     f32x4 acc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    RC_LT(3, 1 + 5 * LAYER);
     for (int q = 0; q + D <= Qw; q += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -297,12 +350,14 @@ __global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F,
     }
 #undef LA
 #undef LB
+    RC_LT(3, 2 + 5 * LAYER);
     // ---- split-K reduction through LDS, gates, state update (rc_gemm.hip: gemm_tile, RC_EPI_LSTM)
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s_part[(wave * 16 + 4 * kq + e) * LD + 16 * j + i] = acc[j][e];
     __syncthreads();
+    RC_LT(3, 3 + 5 * LAYER);
     if (e_on) {
         f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[er * LD + 4 * eu]);
 #pragma unroll
@@ -333,53 +388,101 @@ __global__ __launch_bounds__(256, 4) void rc_live_lstm_kernel(const LiveFrame F,
             }
         }
     }
+    RC_LT(3, 4 + 5 * LAYER);
 }
 
 // ================================================================================================ K7: linear2 sums + tail of the row
-__global__ __launch_bounds__(256) void rc_live_tail_kernel(const LiveFrame F) {
+// One 256-thread workgroup per row. Everything the row reads -- the partial sums of the four second-stage sub-nets, the body
+// constants, the row's own words (tail_request) -- is requested in ONE batch; the four waves sum the partials, then wave 0 runs the
+// tail of the row (rc_frame_dev.h: tail_impl) on the sub-net outputs in LDS.
+extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) {
     __shared__ WaveScratch s_all[1];
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
-    __shared__ __attribute__((aligned(16))) float s_red[1024];
+    __shared__ __attribute__((aligned(16))) float s_red[1008 + 3 * 128];
     __shared__ __attribute__((aligned(16))) LiveSub sub;
-    const int tid = threadIdx.x, row = blockIdx.x;
+    const int tid = threadIdx.x, row = blockIdx.x, lane = tid & 63;
     const int ut = 4 * F.nc;
     const LiveNet &n7 = F.net[LN7], &n6 = F.net[LN6], &n3 = F.net[LN3], &n8 = F.net[LN8];
-    live_reduce<144, 19>(n7.part, n7.H / ut, row, n7.b2, n7.out, sub.r6d, s_red, tid);
-    live_reduce<4, 8>(n6.part, n6.H / ut, row, n6.b2, n6.out, sub.pc, s_red, tid);
-    live_reduce<4, 4>(n3.part, n3.H / ut, row, n3.b2, n3.out, sub.vr, s_red, tid);
-    live_reduce<4, 4>(n8.part, n8.H / ut, row, n8.b2, n8.out, sub.ct, s_red, tid);
-    tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub);
+    const int nt7 = n7.H / ut, nt6 = n6.H / ut, nt3 = n3.H / ut, nt8 = n8.H / ut;
+    RC_LT(2, 0);
+    TailRegs tr;
+    tr.gv = 0.f; tr.bv = 0u; tr.acc_l = 0.f; tr.ori_l = 0.f;
+    if (tid < 64) tail_request<true>(tr, F.fb, F.io, row, lane);
+    LiveSum<144, 19> s7;                                                  // threads 0..251
+    LiveSum<4, 8> s6;                                                     // threads 0..31
+    LiveSum<4, 4> s3, s8;                                                 // threads 64..95 / 128..159 (one group per wave)
+    s7.request(n7.part, nt7, row, tid);
+    s6.request(n6.part, nt6, row, tid);
+    s3.request(n3.part, nt3, row, tid - 64);
+    s8.request(n8.part, nt8, row, tid - 128);
+    float bias_t = 0.f;                                                   // bias of the output this thread finishes (see below)
+    if (tid < n7.out) bias_t = n7.b2[tid];
+    else if (tid >= 192 && tid < 192 + n6.out) bias_t = n6.b2[tid - 192];
+    else if (tid >= 200 && tid < 200 + n3.out) bias_t = n3.b2[tid - 200];
+    else if (tid >= 208 && tid < 208 + n8.out) bias_t = n8.b2[tid - 208];
+    BodyStage<256> bsa;
+    bsa.load(F.body, tid);
+    bsa.store(&s_body, tid);
+    s7.slices(nt7, s_red, tid);
+    s6.slices(nt6, s_red + 1008, tid);
+    s3.slices(nt3, s_red + 1008 + 128, tid - 64);
+    s8.slices(nt8, s_red + 1008 + 256, tid - 128);
+    __syncthreads();
+    RC_LT(2, 1);
+    LiveSum<144, 19>::finish(s_red, bias_t, n7.out, sub.r6d, tid);
+    LiveSum<4, 8>::finish(s_red + 1008, bias_t, n6.out, sub.pc, tid - 192);             // (wave 3: idle in the line above from thread 144)
+    LiveSum<4, 4>::finish(s_red + 1008 + 128, bias_t, n3.out, sub.vr, tid - 200);
+    LiveSum<4, 4>::finish(s_red + 1008 + 256, bias_t, n8.out, sub.ct, tid - 208);
+    __syncthreads();
+    RC_LT(2, 2);
+    if (tid >= 64) return;
+    tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub, &tr);
 }
 
-// ================================================================================================================== launcher
-void rc_launch_live_frame(const LiveFrame& F, hipStream_t st) {
-    const dim3 blk(256);
+// (plain names: the AQL path of rc_aql.cpp finds the kernels by symbol)
+extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l0(const LiveFrame F, const LiveGrid G) { live_lstm_body<0, 1>(F, G); }
+extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l1(const LiveFrame F, const LiveGrid G) { live_lstm_body<1, 1>(F, G); }
+extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l0w(const LiveFrame F, const LiveGrid G) { live_lstm_body<0, 2>(F, G); }
+extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l1w(const LiveFrame F, const LiveGrid G) { live_lstm_body<1, 2>(F, G); }
+
+#ifdef RC_LIVE_TRACE
+extern "C" int rc_live_trace_read(unsigned long long* out) {      // [4][16] stamps of the last frame (probe builds only)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_tt), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ============================================================================================================= the frame's launches
+int rc_live_plan(const LiveFrame& F, LiveKernel* k) {
     const int ut = 4 * F.nc;
-    hipLaunchKernelGGL(rc_live_s1_kernel, dim3((F.net[LN4].H + F.net[LN2].H) / 16), blk, 0, st, F);
     LiveGrid g1{};
     g1.n = 2;
     g1.net[0] = LN4; g1.base[0] = 0; g1.mask[0] = (int)RC_ROW2_M4;
     g1.net[1] = LN2; g1.base[1] = F.net[LN4].H / ut; g1.mask[1] = 0;
-    const int wg1 = (F.net[LN4].H + F.net[LN2].H) / ut;
+    const unsigned wg1 = (unsigned)((F.net[LN4].H + F.net[LN2].H) / ut);
     LiveGrid g2{};
     g2.n = 4;
     const int order[4] = {LN6, LN3, LN7, LN8};
-    int wg2 = 0;
-    for (int q = 0; q < 4; ++q) { g2.net[q] = order[q]; g2.base[q] = wg2; g2.mask[q] = order[q] == LN6 ? (int)RC_ROW2_M6 : 0; wg2 += F.net[order[q]].H / ut; }
-    if (F.nc == 2) {
-        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 2>), dim3(wg1), blk, 0, st, F, g1);
-        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 2>), dim3(wg1), blk, 0, st, F, g1);
-    } else {
-        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 1>), dim3(wg1), blk, 0, st, F, g1);
-        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 1>), dim3(wg1), blk, 0, st, F, g1);
+    unsigned wg2 = 0;
+    for (int q = 0; q < 4; ++q) { g2.net[q] = order[q]; g2.base[q] = (int)wg2; g2.mask[q] = order[q] == LN6 ? (int)RC_ROW2_M6 : 0; wg2 += (unsigned)(F.net[order[q]].H / ut); }
+    const bool w = F.nc == 2;
+    auto set = [&](int i, const void* fn, const char* name, unsigned grid, const LiveGrid* g) {
+        k[i].fn = fn; k[i].name = name; k[i].grid = grid; k[i].F = F; k[i].G = g ? *g : LiveGrid{}; k[i].has_grid = g ? 1 : 0;
+    };
+    set(0, (const void*)rc_live_k1, "rc_live_k1", (unsigned)((F.net[LN4].H + F.net[LN2].H) / 16), nullptr);
+    set(1, w ? (const void*)rc_live_lstm_l0w : (const void*)rc_live_lstm_l0, w ? "rc_live_lstm_l0w" : "rc_live_lstm_l0", wg1, &g1);
+    set(2, w ? (const void*)rc_live_lstm_l1w : (const void*)rc_live_lstm_l1, w ? "rc_live_lstm_l1w" : "rc_live_lstm_l1", wg1, &g1);
+    set(3, (const void*)rc_live_k4, "rc_live_k4", (unsigned)((F.net[LN6].H + F.net[LN3].H + F.net[LN7].H + F.net[LN8].H) / 16), nullptr);
+    set(4, k[1].fn, k[1].name, wg2, &g2);
+    set(5, k[2].fn, k[2].name, wg2, &g2);
+    set(6, (const void*)rc_live_k7, "rc_live_k7", (unsigned)F.B, nullptr);
+    return 7;
+}
+
+void rc_launch_live_frame(const LiveFrame& F, hipStream_t st) {
+    static thread_local LiveKernel k[RC_LIVE_KERNELS];
+    const int n = rc_live_plan(F, k);
+    for (int i = 0; i < n; ++i) {
+        void* args[2] = {(void*)&k[i].F, (void*)&k[i].G};
+        (void)hipLaunchKernel(k[i].fn, dim3(k[i].grid), dim3(256), args, 0, st);
     }
-    hipLaunchKernelGGL(rc_live_s2_kernel, dim3((F.net[LN6].H + F.net[LN3].H + F.net[LN7].H + F.net[LN8].H) / 16), blk, 0, st, F);
-    if (F.nc == 2) {
-        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 2>), dim3(wg2), blk, 0, st, F, g2);
-        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 2>), dim3(wg2), blk, 0, st, F, g2);
-    } else {
-        hipLaunchKernelGGL((rc_live_lstm_kernel<0, 1>), dim3(wg2), blk, 0, st, F, g2);
-        hipLaunchKernelGGL((rc_live_lstm_kernel<1, 1>), dim3(wg2), blk, 0, st, F, g2);
-    }
-    hipLaunchKernelGGL(rc_live_tail_kernel, dim3(F.B), blk, 0, st, F);
 }

@@ -92,10 +92,17 @@ def main():
         if mode == "graph_c_abi":
             lean, full = net.live_stats()
             out[mode]["lean_frames"], out[mode]["full_frames"] = lean, full
+            import ctypes as C
+            prof = (C.c_double * 4)()
+            net._lib.rc_get_live_profile(net._ctx, prof)
+            out[mode]["host_us"] = {"stage": round(prof[0], 2), "enqueue": round(prof[1], 2), "wait": round(prof[2], 2), "copy_out": round(prof[3], 2)}
+            a, b, note = C.c_int32(0), C.c_int32(0), C.create_string_buffer(256)
+            net._lib.rc_get_live_backend(net._ctx, C.byref(a), C.byref(b), note, 256)
+            out[mode]["backend"] = {"lean_captured": a.value, "aql": b.value, "note": note.value.decode()}
         del net
     if variants:
         out["variants"] = {}
-        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}),
+        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}),
                           ("lean_direct_launches", {"RC_LIVE_EAGER": "1"}), ("lean_again", {})):
             net = make(sd, body, m, env=env)
             out["variants"][name] = stats(run_c(net, m, min(n, 4000)))
