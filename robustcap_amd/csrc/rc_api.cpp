@@ -1551,6 +1551,9 @@ int rc_live_begin(rc_ctx* ctx) {
         }
         F.fb = ctx->fb; F.io = io; F.prm = dev_params(ctx->prm); F.body = ctx->body; F.B = (int)B; F.nc = ctx->live_lean_nc;
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&F.status, ctx->live_status_h, 0));
+        std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
+        const int nk = rc_live_plan(F, plan.data());
+      if (nk == RC_LIVE_KERNELS) {                                          // (0: sub-net sizes these kernels are not compiled for)
         HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
         rc_launch_live_frame(F, st);
@@ -1567,11 +1570,10 @@ int rc_live_begin(rc_ctx* ctx) {
         const bool tool = std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("HSA_TOOLS_LIB") || (preload && std::strstr(preload, "rocprofiler"));
         if (!rc && tool && ctx->live_aql_on == 1) ctx->live_aql_note = "a profiling tool intercepts the HSA queues";
         else if (!rc && ctx->live_aql_on && ctx->live_zero_copy && !ctx->live_eager) {
-            std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
-            const int nk = rc_live_plan(F, plan.data());
             char msg[256] = {0};
             if (rc_aql_create(ctx->dev, plan.data(), nk, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
         } else if (!rc) ctx->live_aql_note = "switched off";
+      }
     }
     ctx->timing = timing;
     ctx->live_maybe_pend.assign(B, 1);

@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -152,8 +153,10 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
         p.kernel_object = fs.kobj[i];
         p.kernarg_address = c->kargs + (size_t)i * kKargStride;
         p.completion_signal = i == n - 1 ? c->done : hsa_signal_t{0};
-        const int acq = i == 0 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-        const int rel = i == n - 1 ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        // (RC_AQL_EDGE_SCOPE=agent: probe of what the two system-scope fences cost; the frame's host-side I/O is fine-grained memory)
+        static const bool edge_agent = [] { const char* e = std::getenv("RC_AQL_EDGE_SCOPE"); return e && !std::strcmp(e, "agent"); }();
+        const int acq = (i == 0 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        const int rel = (i == n - 1 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
         c->hdr[i] = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     }

@@ -169,6 +169,9 @@ __device__ __forceinline__ void tail_request(TailRegs& t, const FrameBuffers& fb
     const float* ori = io.ori + row * io.s_ori;
     const float* acc = io.acc + row * io.s_acc;
     const bool ft_given = io.first_tran != nullptr;
+    // LIVE: the frame's inputs sit in pinned HOST memory (a PCIe round trip per read); the first kernel of the frame has left the IMU
+    // data in the prefix of the rnn6 input row (prep_store: x6[0..17] = acc, x6[18..71] = ori) -- read that copy instead
+    const float* x6 = fb.x6;
     const float* gp = nullptr;
     if (lane < 6) gp = fb.last_pfoot + row * 6 + lane;
     else if (lane < 9) gp = fb.last_tran + row * 3 + (lane - 6);
@@ -177,7 +180,7 @@ __device__ __forceinline__ void tail_request(TailRegs& t, const FrameBuffers& fb
     else if (lane < 18) gp = LIVE ? nullptr : fb.vr + row * 4 + (lane - 15);
     else if (lane < 20) gp = LIVE ? nullptr : fb.contact + row * 2 + (lane - 18);
     else if (lane < 38) gp = fb.floor + row * 33 + 15 + (lane - 20);              // floor samples 5..10 (L213: mean of the last six)
-    else if (lane < 47) gp = ori + 45 + (lane - 38);                               // Rcr, L139
+    else if (lane < 47) gp = LIVE ? x6 + rc_pk(row, 18 + 45 + (lane - 38), LD_X6) : ori + 45 + (lane - 38);   // Rcr, L139
     else if (lane < 50) gp = ft_given ? io.first_tran + row * 3 + (lane - 47) : nullptr;
     else if (lane < 52) gp = reinterpret_cast<const float*>(fb.kconf + row) + (lane - 50);
     else if (lane == 52) gp = reinterpret_cast<const float*>(fb.has_last + row);
@@ -186,8 +189,8 @@ __device__ __forceinline__ void tail_request(TailRegs& t, const FrameBuffers& fb
     t.gv = gp ? *gp : 0.f;
     const unsigned char* bp = lane == 0 ? fb.flags + row : (lane == 1 ? fb.regime + row : nullptr);
     t.bv = bp ? (unsigned)*bp : 0u;
-    t.acc_l = lane < 18 ? acc[lane] : 0.f;                                         // this frame's IMU data (updater inputs)
-    t.ori_l = lane < 54 ? ori[lane] : 0.f;
+    t.acc_l = lane < 18 ? (LIVE ? x6[rc_pk(row, lane, LD_X6)] : acc[lane]) : 0.f;  // this frame's IMU data (updater inputs)
+    t.ori_l = lane < 54 ? (LIVE ? x6[rc_pk(row, 18 + lane, LD_X6)] : ori[lane]) : 0.f;
 }
 // LIVE: the caller (rc_live_tail_kernel) has staged the body constants, requested the row's words (`pre`) and summed the sub-net
 // outputs into `sub` (LDS) behind ONE batch of loads; wave 0 runs the row with wave-local synchronisation.

@@ -175,12 +175,12 @@ struct rc_params_dev {
 // boundary (no atomics, no fences, nothing placement-dependent). Every kernel requests its weights first and its per-row words
 // (flags, step parities, cell state) in the same batch: one memory latency in front of the first MFMA instead of a chain of four.
 #define RC_LIVE_MAXB 4
-// Problems of an LSTM launch: sub-net, first block, RC_ROW2_* row mask (0 = all rows). `hot`: the per-row words the launch needs
-// before its first activation load -- step number (-> which copy of h) and whether the row steps -- are IN the kernel arguments:
-// on the AQL path (rc_aql.cpp) the arguments live in device memory of the context's own, and the linear1 kernel that opens the
-// steps (K1 / K4) writes them there, so the LSTM kernels have no dependent global read (3.6 -> ~1.3 us from entry to the first
-// activation load: tools/live_trace.py) in front of the weight stream. hot = 0 (graph replay, direct launches): read from the state.
-struct LiveGrid { int n; int net[4]; int base[4]; int mask[4]; int hot; int st[4][RC_LIVE_MAXB]; int act[4][RC_LIVE_MAXB]; };
+// Second argument of the LSTM launches of the lean frame. `hot`: the per-row words a launch needs before its first activation load --
+// step number (-> which copy of h) and whether the row steps, per problem of the launch (stage 1: rnn4, rnn2; stage 2: rnn6, rnn3,
+// rnn7, rnn8) -- are IN the kernel arguments: on the AQL path (rc_aql.cpp) the arguments live in device memory of the context's own,
+// and the linear1 kernel that opens the steps (K1 / K4) writes them there, so the LSTM kernels have no dependent global read in
+// front of the weight stream. hot = 0 (graph replay, direct launches): read from the state.
+struct LiveGrid { int hot; int st[4][RC_LIVE_MAXB]; int act[4][RC_LIVE_MAXB]; };
 struct LiveNet {
     const float *W1, *b1;           // linear1: pack_weights order [N/16][Kp1/16][64][4], bias
     const float *Wl[2], *bl[2];     // LSTM layers: pack_weights order, gate-interleaved columns; b_ih + b_hh

@@ -25,10 +25,34 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { LN2 = 0, LN3 = 1, LN4 = 2, LN6 = 3, LN7 = 4, LN8 = 5 };     // rc_api.cpp: kNets order
+// Hidden sizes of the six sub-nets (net/sig_mp.py:52-81), compile-time here: which problem and tile a workgroup owns is then
+// arithmetic on its block id, and every pointer it needs is ONE scalar load from the kernel arguments away (a chain of dependent
+// kernel-argument loads -- problem table -> sub-net index -> sub-net record -- cost ~1 us per level at the top of every kernel).
+// rc_live_plan refuses a LiveFrame whose sizes differ.
+#define LIVE_H4 1280
+#define LIVE_H6 1024
+#define LIVE_H5 512
+__host__ __device__ constexpr int live_H(int ni) { return ni == LN4 ? LIVE_H4 : (ni == LN6 ? LIVE_H6 : LIVE_H5); }
 
 #define LIVE_XLD 260          // floats per A row in LDS (256 + 4: the 16 rows of a fragment read land on different banks)
 
 __device__ __forceinline__ f32x4 ldg_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+
+// The kernel arguments of these kernels are a 1.2 KB record (LiveFrame) that hipcc reads with scalar loads WHERE each field is first
+// used -- in kernels that are chains of small dependent steps that is ~10 scalar-cache misses one after the other (~0.25 us each:
+// ISA + tools/live_trace.py). One scalar load per 64-byte line up front brings the whole record into the scalar cache behind a
+// single wait; every later field read is a hit.
+template <int BYTES>
+__device__ __forceinline__ void live_warm_kernargs() {
+    constexpr int LINES = (BYTES + 63) / 64;
+    const auto karg = __builtin_amdgcn_kernarg_segment_ptr();             // (never &F: hipcc then copies F to scratch)
+    int sink[LINES];
+#pragma unroll
+    for (int q = 0; q < LINES; ++q) asm volatile("s_load_dword %0, %1, %2" : "=s"(sink[q]) : "s"(karg), "n"(q * 64));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < LINES; ++q) asm volatile("" ::"s"(sink[q]));
+}
 
 // ---- sum of a sub-net's linear2 partials for one row ---------------------------------------------------------------------------
 // part[(tile * RC_LIVE_MAXB + row) * OUTP + o]; OUTP / 4 column groups x S slices of tiles (slice sl owns tiles sl, sl + S, ...):
@@ -58,6 +82,24 @@ struct LiveSum {
             if (sl + q * S < n_tiles) a += v[q];
         *reinterpret_cast<f32x4*>(s_red + sl * OUTP + 4 * g) = a;
     }
+    // Narrow outputs (OUTP = 4: rnn6 / rnn3 / rnn8): the S <= 32 slices sit in the low lanes of ONE wave -- their sums meet by a
+    // fixed butterfly of lane exchanges instead of a chain of S dependent LDS reads (1.7 us of a one-workgroup kernel); every lane
+    // returns the total (the order of the additions is that of the butterfly: fixed).
+    __device__ __forceinline__ f32x4 wave_total(const int n_tiles, const int t) const {
+        const int sl = t;                                                    // G = 1
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < THREADS) {
+            a = v[0];
+#pragma unroll
+            for (int q = 1; q < MAXT; ++q)
+                if (sl + q * S < n_tiles) a += v[q];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += __shfl_xor(a[e], off);
+        return a;
+    }
     // bias_t: bias[t] of the finishing thread, loaded by the caller WITH the partials (a global read here would be a second latency)
     static __device__ __forceinline__ void finish(const float* s_red, const float bias_t, const int out, float* dst, const int t) {
         if (t < 0 || t >= out) return;
@@ -72,18 +114,18 @@ struct LiveSum {
 // The arithmetic of gemm_tile<1, 1, ...> of rc_gemm.hip for a dense layer: wave w owns the k chunks [w Qw, (w + 1) Qw), the wave
 // sums meet in LDS and are added in wave order, then bias and ReLU; four columns per item.
 struct Lin1W { f32x4 b[4]; f32x4 bias; };
-__device__ __forceinline__ void lin1_request(Lin1W& w, const LiveNet& n, const int n_tile, const int tid) {
+__device__ __forceinline__ void lin1_request(Lin1W& w, const LiveNet& n, const int Kp1, const int n_tile, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int Q = n.Kp1 / 16, Qw = Q / 4;                                  // Kp1 = 256 -> 4 chunks per wave, 128 -> 2
+    const int Q = Kp1 / 16, Qw = Q / 4;                                    // Kp1 = 256 -> 4 chunks per wave, 128 (rnn2) -> 2
     const float* pb = n.W1 + ((long long)n_tile * Q + (long long)wave * Qw) * 256 + lane * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) w.b[q] = q < Qw ? ldg_nt(pb + q * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
     w.bias = *reinterpret_cast<const f32x4*>(n.b1 + n_tile * 16 + 4 * (tid & 3));
 }
-__device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, const int n_tile, const int B, const float (*s_x)[LIVE_XLD],
-                                          float (*s_part)[16][20], const int tid) {
+__device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, const int H, const int Kp1, const int n_tile, const int B,
+                                          const float (*s_x)[LIVE_XLD], float (*s_part)[16][20], const int tid) {
     const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int Qw = n.Kp1 / 64;
+    const int Qw = Kp1 / 64;
     const int ri = i < B ? i : B - 1;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -105,7 +147,7 @@ __device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, cons
             for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4*>(&s_part[ww][rr][c4]);
             v += w.bias;
             v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f);
-            *reinterpret_cast<f32x4*>(&n.x1[rc_pk(rr, n_tile * 16 + c4, n.H)]) = v;
+            *reinterpret_cast<f32x4*>(&n.x1[rc_pk(rr, n_tile * 16 + c4, H)]) = v;
         }
     }
 }
@@ -115,17 +157,19 @@ __device__ __forceinline__ void lin1_tile(const Lin1W& w, const LiveNet& n, cons
 // leaves the sub-net's input row in LDS; the first workgroup of each net also performs the prep's stores (row flags, the input
 // rows later stages read, trace) and opens the step (rc_gemm.hip: open_step).
 extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) {
+    live_warm_kernargs<(int)sizeof(LiveFrame)>();
     __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
     __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = F.B;
-    const int t4 = F.net[LN4].H / 16;
+    constexpr int t4 = LIVE_H4 / 16;
     const bool is4 = (int)blockIdx.x < t4;
-    const LiveNet& n = is4 ? F.net[LN4] : F.net[LN2];
+    const LiveNet& n = F.net[is4 ? LN4 : LN2];
+    const int H = is4 ? LIVE_H4 : LIVE_H5, Kp1 = is4 ? 256 : 128;
     const int n_tile = is4 ? (int)blockIdx.x : (int)blockIdx.x - t4;
     RC_LT(0, 0);
     Lin1W w;
-    lin1_request(w, n, n_tile, tid);
+    lin1_request(w, n, Kp1, n_tile, tid);
     if (wave < B) {
         const int row = wave;
         PrepIn in;
@@ -164,7 +208,7 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
     }
     __syncthreads();
     RC_LT(0, 2);
-    lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+    lin1_tile(w, n, H, Kp1, n_tile, B, s_x, s_part, tid);
     RC_LT(0, 3);
 }
 
@@ -172,25 +216,35 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
 // Grid: column tiles of rnn6, rnn3, rnn7, rnn8. Every workgroup sums the partials it needs (rnn6: rnn4's output, rnn3: rnn2's,
 // rnn7 / rnn8: both, then the fuse of L154-167 with the arithmetic of rc_fuse_kernel) and builds its input rows in LDS.
 extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) {
+    live_warm_kernargs<(int)sizeof(LiveFrame)>();
     __shared__ __attribute__((aligned(16))) float s_x[RC_LIVE_MAXB][LIVE_XLD];
     __shared__ __attribute__((aligned(16))) float s_part[4][16][20];
     __shared__ __attribute__((aligned(16))) float s_red[2048];
     __shared__ __attribute__((aligned(16))) float s_y4[RC_LIVE_MAXB][72], s_y2[RC_LIVE_MAXB][72];
     const int tid = threadIdx.x;
     const int B = F.B;
-    const int t6 = F.net[LN6].H / 16, t3 = F.net[LN3].H / 16, t7 = F.net[LN7].H / 16;
+    constexpr int t6 = LIVE_H6 / 16, t3 = LIVE_H5 / 16, t7 = LIVE_H5 / 16;
     const int b = blockIdx.x;
     const int ni = b < t6 ? LN6 : (b < t6 + t3 ? LN3 : (b < t6 + t3 + t7 ? LN7 : LN8));
     const int n_tile = ni == LN6 ? b : (ni == LN3 ? b - t6 : (ni == LN7 ? b - t6 - t3 : b - t6 - t3 - t7));
     const LiveNet& n = F.net[ni];
+    const int H = ni == LN6 ? LIVE_H6 : LIVE_H5;
     RC_LT(1, 0);
     Lin1W w;
-    lin1_request(w, n, n_tile, tid);
+    lin1_request(w, n, 256, n_tile, tid);
     // the prefix of the input rows (written by K1's first workgroup) and the alternative row of rnn6 -- requested before the sums
     float xin[RC_LIVE_MAXB], xalt[RC_LIVE_MAXB];
     int st_old[RC_LIVE_MAXB];
 #pragma unroll
     for (int r = 0; r < RC_LIVE_MAXB; ++r) st_old[r] = (r < B && n_tile == 0 && tid == 0) ? n.steps[r] : 0;
+    // column c = (tid - 72) % 3 of the root orientation Rcr (fuse; the copy K1 left in the rnn6 input row: x6[18 + 45 ..], not the
+    // pinned host buffer), requested with everything else
+    float rcr[RC_LIVE_MAXB][3];
+#pragma unroll
+    for (int r = 0; r < RC_LIVE_MAXB; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            rcr[r][q] = (r < B && (ni == LN7 || ni == LN8) && tid >= 72 && tid < 141) ? F.fb.x6[rc_pk(r, 18 + 45 + 3 * q + (tid - 72) % 3, LD_X6)] : 0.f;
     const float* xsrc = ni == LN6 ? F.fb.x6 : (ni == LN3 ? F.fb.x3 : F.fb.x78);
 #pragma unroll
     for (int r = 0; r < RC_LIVE_MAXB; ++r) {
@@ -202,7 +256,7 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
     for (int r = 0; r < B; ++r) {                                         // both sums of a row behind one batch of loads
         LiveSum<72, 23> s4;
         LiveSum<72, 10> s2;
-        const int nt4 = n4.H / (4 * F.nc), nt2 = n2.H / (4 * F.nc);
+        const int nt4 = LIVE_H4 / (4 * F.nc), nt2 = LIVE_H5 / (4 * F.nc);
         if (ni != LN3) s4.request(n4.part, nt4, r, tid);
         if (ni != LN6) s2.request(n2.part, nt2, r, tid);
         const float b4 = tid < n4.out ? n4.b2[tid] : 0.f, b2 = tid < n2.out ? n2.b2[tid] : 0.f;
@@ -227,13 +281,12 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
         } else {                                                           // [accr, orir | j3dr], L169-170: rc_fuse_kernel's arithmetic
             if (tid < 72) v = xin[r];
             else if (tid < 141) {
-                const int e = tid - 72, j = e / 3, c = e - 3 * j;
+                const int e = tid - 72, j = e / 3;
                 const float vi = s_y2[r][e];
                 if (regime == 0) v = vi;
                 else {
-                    const float* R = F.io.ori + r * F.io.s_ori + 45;
                     const float vc0 = s_y4[r][3 * j], vc1 = s_y4[r][3 * j + 1], vc2 = s_y4[r][3 * j + 2];
-                    const float vv = (vc0 * R[c] + vc1 * R[3 + c]) + vc2 * R[6 + c];      // j3dc.view(23,3).mm(Rcr), L154
+                    const float vv = (vc0 * rcr[r][0] + vc1 * rcr[r][1]) + vc2 * rcr[r][2];   // j3dc.view(23,3).mm(Rcr), L154
                     if (regime == 2) v = vv;
                     else {                                                 // lerp with a python-double weight, L163-164
                         const double k = F.fb.kconf[r];
@@ -258,30 +311,50 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
     }
     __syncthreads();
     RC_LT(1, 3);
-    lin1_tile(w, n, n_tile, B, s_x, s_part, tid);
+    lin1_tile(w, n, H, 256, n_tile, B, s_x, s_part, tid);
     RC_LT(1, 4);
 }
 
 // ========================================================================================= K2 / K3 / K5 / K6: one LSTM layer step
-template <int LAYER, int NC>
+template <int STAGE, int LAYER, int NC>
 __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGrid& G) {
     constexpr int D = NC == 1 ? 8 : 4, UT = 4 * NC, NT = 16 * NC, LD = NT + 16;
     __shared__ __attribute__((aligned(16))) float s_part[4 * 16 * LD];
     __shared__ __attribute__((aligned(16))) float s_h[RC_LIVE_MAXB][UT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
-    const int B = F.B;
-    int pi = 0;
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-        if (q < G.n && (int)blockIdx.x >= G.base[q]) pi = q;
-    const LiveNet& n = F.net[G.net[pi]];
-    const int mask = G.mask[pi], n_tile = (int)blockIdx.x - G.base[pi];
-    const int H = n.H;
+    // problem (order: stage 1 rnn4, rnn2; stage 2 rnn6, rnn3, rnn7, rnn8 -- longest K first) and tile from the block id alone
+    const int b = (int)blockIdx.x;
+    constexpr int TB = (STAGE == 1 ? LIVE_H4 : LIVE_H6) / UT, TS = LIVE_H5 / UT;   // tiles of the big net / of an H = 512 net
+    const int pi = b < TB ? 0 : 1 + (b - TB) / TS;
+    const int ni = STAGE == 1 ? (pi == 0 ? LN4 : LN2) : (pi == 0 ? LN6 : (pi == 1 ? LN3 : (pi == 2 ? LN7 : LN8)));
+    const int H = pi == 0 ? (STAGE == 1 ? LIVE_H4 : LIVE_H6) : LIVE_H5;
+    const int n_tile = pi == 0 ? b : (b - TB) - (pi - 1) * TS;
+    const int mask = pi == 0 ? (STAGE == 1 ? (int)RC_ROW2_M4 : (int)RC_ROW2_M6) : 0;
+    const LiveNet& n = F.net[ni];
     RC_LT(3, 0 + 5 * LAYER);
+    // ---- every kernel-argument word this workgroup needs, in ONE batch of scalar loads. (Left to itself hipcc loads each group where
+    // it is first used and waits for it there: a chain of ~8 scalar-cache round trips, ~3 us at the top of every launch -- ISA and
+    // tools/live_trace.py. The empty asm "uses" all of them at one point, so they are requested together and waited for once.)
+    const int B = F.B;
+    const float* const Wl = n.Wl[LAYER];
+    const float* const bl = n.bl[LAYER];
+    float* const cbase = n.c;
+    float* const hbase = n.h;
+    const float* const x1 = n.x1;
+    const float* const W2 = n.W2;
+    float* const part = n.part;
+    const int* const steps = n.steps;
+    const long long BpH = n.BpH;
+    const int out = n.out, outp = n.outp, hot = G.hot;
+    const int hs0 = G.st[pi][0], hs1 = G.st[pi][1], hs2 = G.st[pi][2], hs3 = G.st[pi][3];
+    const int ha0 = G.act[pi][0], ha1 = G.act[pi][1], ha2 = G.act[pi][2], ha3 = G.act[pi][3];
+    const unsigned char* const flags2 = F.fb.flags2;
+    asm volatile("; kernel arguments in" ::"s"(B), "s"(Wl), "s"(bl), "s"(cbase), "s"(hbase), "s"(x1), "s"(W2), "s"(part), "s"(steps), "s"(BpH),
+                 "s"(out), "s"(outp), "s"(hot), "s"(hs0), "s"(hs1), "s"(hs2), "s"(hs3), "s"(ha0), "s"(ha1), "s"(ha2), "s"(ha3), "s"(flags2));
     // ---- the weight stream first: it depends on nothing but the block id
     const int Q = 2 * H / 16, Qw = Q / 4;                                  // chunks per wave: 16 / 32 / 40 (multiples of D)
     const long long bstride = (long long)Q * 256;
-    const float* pb = n.Wl[LAYER] + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
+    const float* pb = Wl + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
     f32x4 fa[D], fw[D][NC];
 #define LB(d, qi) do { _Pragma("unroll") for (int j_ = 0; j_ < NC; ++j_) fw[d][j_] = ldg_nt(pb + (long long)(qi) * 256 + j_ * bstride); } while (0)
 #pragma unroll
@@ -292,39 +365,35 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     const bool e_on = tid < 16 * UT && er < B;
     int st_a, st_e;
     unsigned amask = 0;                                                    // rows that take this step (wave-uniform)
-    if (G.hot) {                                                           // in the kernel arguments (written by K1 / K4): no global read
-        const int* hs = G.st[pi];
-        const int* ha = G.act[pi];
-        const int s0 = hs[0], s1 = hs[1], s2 = hs[2], s3 = hs[3];
-        st_a = ri == 0 ? s0 : (ri == 1 ? s1 : (ri == 2 ? s2 : s3));
-        st_e = er == 0 ? s0 : (er == 1 ? s1 : (er == 2 ? s2 : s3));
-#pragma unroll
-        for (int r = 0; r < RC_LIVE_MAXB; ++r)
-            if (r < B && ha[r]) amask |= 1u << r;
+    if (hot) {                                                             // in the kernel arguments (written by K1 / K4): no global read
+        st_a = ri == 0 ? hs0 : (ri == 1 ? hs1 : (ri == 2 ? hs2 : hs3));
+        st_e = er == 0 ? hs0 : (er == 1 ? hs1 : (er == 2 ? hs2 : hs3));
+        amask = (ha0 ? 1u : 0u) | (ha1 ? 2u : 0u) | (ha2 ? 4u : 0u) | (ha3 ? 8u : 0u);
+        amask &= (1u << B) - 1u;
     } else {
-        st_a = n.steps[ri];
-        st_e = e_on ? n.steps[er] : 0;
+        st_a = steps[ri];
+        st_e = e_on ? steps[er] : 0;
 #pragma unroll
         for (int r = 0; r < RC_LIVE_MAXB; ++r)
-            if (r < B && (mask == 0 || (F.fb.flags2[r] & mask))) amask |= 1u << r;
+            if (r < B && (mask == 0 || (flags2[r] & mask))) amask |= 1u << r;
     }
-    float* cst = n.c + (long long)LAYER * B * H;
+    float* cst = cbase + (long long)LAYER * B * H;
     const float c_prev = e_on ? cst[(long long)er * H + n_tile * UT + eu] : 0.f;
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&n.bl[LAYER][n_tile * NT + 4 * (tid % UT)]);
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(&bl[n_tile * NT + 4 * (tid % UT)]);
     f32x4 w2[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) w2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (LAYER == 1 && tid < n.out) {
+    if (LAYER == 1 && tid < out) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) w2[j] = ldg_nt(n.W2 + (long long)tid * H + n_tile * UT + 4 * j);
+        for (int j = 0; j < NC; ++j) w2[j] = ldg_nt(W2 + (long long)tid * H + n_tile * UT + 4 * j);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (amask == 0) return;                                                // (nothing steps: e.g. rnn4 of occluded rows with the updater off)
     // ---- A pointers: layer 0 reads relu(linear1) | own h of the previous step; layer 1 reads h of layer 0 (just written) | own h
     // (st + 2) % 3 = (st - 1) % 3 for every row that has stepped; a row that never has reads a valid copy
     const long long aoff = rc_pk(ri, 4 * kq, H);
-    const float* pa0 = (LAYER == 0 ? n.x1 : n.h + (long long)(st_a % RC_HBUF) * n.BpH) + aoff;
-    const float* pa1 = n.h + (long long)(LAYER * RC_HBUF + (st_a + 2) % RC_HBUF) * n.BpH + aoff;
+    const float* pa0 = (LAYER == 0 ? x1 : hbase + (long long)(st_a % RC_HBUF) * BpH) + aoff;
+    const float* pa1 = hbase + (long long)(LAYER * RC_HBUF + (st_a + 2) % RC_HBUF) * BpH + aoff;
     const int kbase = wave * Qw * 16;
 #define LA(d, qi) do { const int k_ = kbase + (qi) * 16; fa[d] = k_ < H ? *reinterpret_cast<const f32x4*>(pa0 + (long long)k_ * 16) \
                                                                         : *reinterpret_cast<const f32x4*>(pa1 + (long long)(k_ - H) * 16); } while (0)
@@ -371,20 +440,20 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
         if (on) {
             const int unit = n_tile * UT + eu;
             cst[(long long)er * H + unit] = cn;
-            n.h[(long long)(LAYER * RC_HBUF + st_e % RC_HBUF) * n.BpH + rc_pk(er, unit, H)] = hn;
+            hbase[(long long)(LAYER * RC_HBUF + st_e % RC_HBUF) * BpH + rc_pk(er, unit, H)] = hn;
         }
         if (LAYER == 1) s_h[er][eu] = hn;
     }
     if (LAYER == 1) {                                                      // linear2: this tile's units times their columns of W2
         __syncthreads();
-        if (tid < n.outp) {
+        if (tid < outp) {
 #pragma unroll
             for (int r = 0; r < RC_LIVE_MAXB; ++r) {
                 if (!((amask >> r) & 1u)) continue;
                 float p = w2[0][0] * s_h[r][0];
 #pragma unroll
                 for (int u = 1; u < UT; ++u) p = fmaf(w2[u >> 2][u & 3], s_h[r][u], p);
-                n.part[((long long)n_tile * RC_LIVE_MAXB + r) * n.outp + tid] = p;
+                part[((long long)n_tile * RC_LIVE_MAXB + r) * outp + tid] = p;
             }
         }
     }
@@ -396,14 +465,15 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
 // constants, the row's own words (tail_request) -- is requested in ONE batch; the four waves sum the partials, then wave 0 runs the
 // tail of the row (rc_frame_dev.h: tail_impl) on the sub-net outputs in LDS.
 extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) {
+    live_warm_kernargs<(int)sizeof(LiveFrame)>();
     __shared__ WaveScratch s_all[1];
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
-    __shared__ __attribute__((aligned(16))) float s_red[1008 + 3 * 128];
+    __shared__ __attribute__((aligned(16))) float s_red[1008];
     __shared__ __attribute__((aligned(16))) LiveSub sub;
     const int tid = threadIdx.x, row = blockIdx.x, lane = tid & 63;
     const int ut = 4 * F.nc;
     const LiveNet &n7 = F.net[LN7], &n6 = F.net[LN6], &n3 = F.net[LN3], &n8 = F.net[LN8];
-    const int nt7 = n7.H / ut, nt6 = n6.H / ut, nt3 = n3.H / ut, nt8 = n8.H / ut;
+    const int nt7 = LIVE_H5 / ut, nt6 = LIVE_H6 / ut, nt3 = LIVE_H5 / ut, nt8 = LIVE_H5 / ut;
     RC_LT(2, 0);
     TailRegs tr;
     tr.gv = 0.f; tr.bv = 0u; tr.acc_l = 0.f; tr.ori_l = 0.f;
@@ -415,24 +485,25 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) 
     s6.request(n6.part, nt6, row, tid);
     s3.request(n3.part, nt3, row, tid - 64);
     s8.request(n8.part, nt8, row, tid - 128);
-    float bias_t = 0.f;                                                   // bias of the output this thread finishes (see below)
-    if (tid < n7.out) bias_t = n7.b2[tid];
-    else if (tid >= 192 && tid < 192 + n6.out) bias_t = n6.b2[tid - 192];
-    else if (tid >= 200 && tid < 200 + n3.out) bias_t = n3.b2[tid - 200];
-    else if (tid >= 208 && tid < 208 + n8.out) bias_t = n8.b2[tid - 208];
+    const float bias_t = tid < n7.out ? n7.b2[tid] : 0.f;                 // bias of the output this thread finishes
+    // the narrow sums: wave 0 -> rnn6 (pc), wave 1 -> rnn3 (vr), wave 2 -> rnn8 (contact); lane e < out adds the bias and writes
+    const int wv = tid >> 6;
+    const float* nb = wv == 0 ? n6.b2 : (wv == 1 ? n3.b2 : n8.b2);
+    const int nout = wv == 0 ? n6.out : (wv == 1 ? n3.out : n8.out);
+    const float bias_n = (wv < 3 && lane < nout) ? nb[lane] : 0.f;
     BodyStage<256> bsa;
     bsa.load(F.body, tid);
     bsa.store(&s_body, tid);
     s7.slices(nt7, s_red, tid);
-    s6.slices(nt6, s_red + 1008, tid);
-    s3.slices(nt3, s_red + 1008 + 128, tid - 64);
-    s8.slices(nt8, s_red + 1008 + 256, tid - 128);
+    {
+        const f32x4 t6 = s6.wave_total(nt6, tid), t3 = s3.wave_total(nt3, tid - 64), t8 = s8.wave_total(nt8, tid - 128);
+        const f32x4 tt = wv == 0 ? t6 : (wv == 1 ? t3 : t8);
+        float* dst = wv == 0 ? sub.pc : (wv == 1 ? sub.vr : sub.ct);
+        if (wv < 3 && lane < nout) dst[lane] = (lane == 0 ? tt[0] : (lane == 1 ? tt[1] : tt[2])) + bias_n;
+    }
     __syncthreads();
     RC_LT(2, 1);
     LiveSum<144, 19>::finish(s_red, bias_t, n7.out, sub.r6d, tid);
-    LiveSum<4, 8>::finish(s_red + 1008, bias_t, n6.out, sub.pc, tid - 192);             // (wave 3: idle in the line above from thread 144)
-    LiveSum<4, 4>::finish(s_red + 1008 + 128, bias_t, n3.out, sub.vr, tid - 200);
-    LiveSum<4, 4>::finish(s_red + 1008 + 256, bias_t, n8.out, sub.ct, tid - 208);
     __syncthreads();
     RC_LT(2, 2);
     if (tid >= 64) return;
@@ -440,10 +511,11 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) 
 }
 
 // (plain names: the AQL path of rc_aql.cpp finds the kernels by symbol)
-extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l0(const LiveFrame F, const LiveGrid G) { live_lstm_body<0, 1>(F, G); }
-extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l1(const LiveFrame F, const LiveGrid G) { live_lstm_body<1, 1>(F, G); }
-extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l0w(const LiveFrame F, const LiveGrid G) { live_lstm_body<0, 2>(F, G); }
-extern "C" __global__ __launch_bounds__(256, 4) void rc_live_lstm_l1w(const LiveFrame F, const LiveGrid G) { live_lstm_body<1, 2>(F, G); }
+#define LIVE_LSTM(NAME, STAGE, LAYER, NC) \
+    extern "C" __global__ __launch_bounds__(256, 4) void NAME(const LiveFrame F, const LiveGrid G) { live_lstm_body<STAGE, LAYER, NC>(F, G); }
+LIVE_LSTM(rc_live_s1_l0, 1, 0, 1) LIVE_LSTM(rc_live_s1_l1, 1, 1, 1) LIVE_LSTM(rc_live_s2_l0, 2, 0, 1) LIVE_LSTM(rc_live_s2_l1, 2, 1, 1)
+LIVE_LSTM(rc_live_s1_l0w, 1, 0, 2) LIVE_LSTM(rc_live_s1_l1w, 1, 1, 2) LIVE_LSTM(rc_live_s2_l0w, 2, 0, 2) LIVE_LSTM(rc_live_s2_l1w, 2, 1, 2)
+#undef LIVE_LSTM
 
 #ifdef RC_LIVE_TRACE
 extern "C" int rc_live_trace_read(unsigned long long* out) {      // [4][16] stamps of the last frame (probe builds only)
@@ -453,29 +525,24 @@ extern "C" int rc_live_trace_read(unsigned long long* out) {      // [4][16] sta
 
 // ============================================================================================================= the frame's launches
 int rc_live_plan(const LiveFrame& F, LiveKernel* k) {
-    const int ut = 4 * F.nc;
-    LiveGrid g1{};
-    g1.n = 2;
-    g1.net[0] = LN4; g1.base[0] = 0; g1.mask[0] = (int)RC_ROW2_M4;
-    g1.net[1] = LN2; g1.base[1] = F.net[LN4].H / ut; g1.mask[1] = 0;
-    const unsigned wg1 = (unsigned)((F.net[LN4].H + F.net[LN2].H) / ut);
-    LiveGrid g2{};
-    g2.n = 4;
-    const int order[4] = {LN6, LN3, LN7, LN8};
-    unsigned wg2 = 0;
-    for (int q = 0; q < 4; ++q) { g2.net[q] = order[q]; g2.base[q] = (int)wg2; g2.mask[q] = order[q] == LN6 ? (int)RC_ROW2_M6 : 0; wg2 += (unsigned)(F.net[order[q]].H / ut); }
+    for (int i = 0; i < 6; ++i)
+        if (F.net[i].H != live_H(i)) return 0;                             // not the architecture these kernels are compiled for
+    if (F.net[LN2].Kp1 != 128) return 0;
+    for (int i : {LN3, LN4, LN6, LN7, LN8}) if (F.net[i].Kp1 != 256) return 0;
+    const unsigned ut = 4u * (unsigned)F.nc;
+    const unsigned wg1 = (LIVE_H4 + LIVE_H5) / ut, wg2 = (LIVE_H6 + 3 * LIVE_H5) / ut;
     const bool w = F.nc == 2;
-    auto set = [&](int i, const void* fn, const char* name, unsigned grid, const LiveGrid* g) {
-        k[i].fn = fn; k[i].name = name; k[i].grid = grid; k[i].F = F; k[i].G = g ? *g : LiveGrid{}; k[i].has_grid = g ? 1 : 0;
+    auto set = [&](int i, const void* fn, const char* name, unsigned grid, int has_grid) {
+        k[i].fn = fn; k[i].name = name; k[i].grid = grid; k[i].F = F; k[i].G = LiveGrid{}; k[i].has_grid = has_grid;
     };
-    set(0, (const void*)rc_live_k1, "rc_live_k1", (unsigned)((F.net[LN4].H + F.net[LN2].H) / 16), nullptr);
-    set(1, w ? (const void*)rc_live_lstm_l0w : (const void*)rc_live_lstm_l0, w ? "rc_live_lstm_l0w" : "rc_live_lstm_l0", wg1, &g1);
-    set(2, w ? (const void*)rc_live_lstm_l1w : (const void*)rc_live_lstm_l1, w ? "rc_live_lstm_l1w" : "rc_live_lstm_l1", wg1, &g1);
-    set(3, (const void*)rc_live_k4, "rc_live_k4", (unsigned)((F.net[LN6].H + F.net[LN3].H + F.net[LN7].H + F.net[LN8].H) / 16), nullptr);
-    set(4, k[1].fn, k[1].name, wg2, &g2);
-    set(5, k[2].fn, k[2].name, wg2, &g2);
-    set(6, (const void*)rc_live_k7, "rc_live_k7", (unsigned)F.B, nullptr);
-    return 7;
+    set(0, (const void*)rc_live_k1, "rc_live_k1", (LIVE_H4 + LIVE_H5) / 16, 0);
+    set(1, w ? (const void*)rc_live_s1_l0w : (const void*)rc_live_s1_l0, w ? "rc_live_s1_l0w" : "rc_live_s1_l0", wg1, 1);
+    set(2, w ? (const void*)rc_live_s1_l1w : (const void*)rc_live_s1_l1, w ? "rc_live_s1_l1w" : "rc_live_s1_l1", wg1, 1);
+    set(3, (const void*)rc_live_k4, "rc_live_k4", (LIVE_H6 + 3 * LIVE_H5) / 16, 0);
+    set(4, w ? (const void*)rc_live_s2_l0w : (const void*)rc_live_s2_l0, w ? "rc_live_s2_l0w" : "rc_live_s2_l0", wg2, 1);
+    set(5, w ? (const void*)rc_live_s2_l1w : (const void*)rc_live_s2_l1, w ? "rc_live_s2_l1w" : "rc_live_s2_l1", wg2, 1);
+    set(6, (const void*)rc_live_k7, "rc_live_k7", (unsigned)F.B, 0);
+    return RC_LIVE_KERNELS;
 }
 
 void rc_launch_live_frame(const LiveFrame& F, hipStream_t st) {

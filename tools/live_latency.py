@@ -102,7 +102,7 @@ def main():
         del net
     if variants:
         out["variants"] = {}
-        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}),
+        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}), ("lean_edge_agent", {"RC_AQL_EDGE_SCOPE": "agent"}),
                           ("lean_direct_launches", {"RC_LIVE_EAGER": "1"}), ("lean_again", {})):
             net = make(sd, body, m, env=env)
             out["variants"][name] = stats(run_c(net, m, min(n, 4000)))
