@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline). The K-
 ``ms_per_step`` are those of the MEDIAN repetition (``timing`` carries min / max). ``variants`` carries the other
 configurations of BASELINE.json on the same box: ``high`` (all-visible, same K), ``fp32_mfma``, ``mixed_long`` /
 ``high_long`` (256 frames per call whatever --steps is: the wavefront engine's steady state), ``occ1024`` (config 4) and
-``live_b1`` (config 5: p50 / p99 of the hipGraph-captured batch-1 frame). The roofline pass and the side legs are guarded: a
+``live_b1`` (config 5: p50 / p99 of the captured batch-1 frame; ``graph_replay`` = the same capture through hipGraphLaunch). The roofline pass and the side legs are guarded: a
 failure there is recorded as {"error": ...} and the line is still printed.
 """
 import argparse
@@ -51,17 +51,18 @@ CPU_FRAMES_SINGLE = 48
 CPU_SAMPLES = 3
 
 
-def pmc_traffic(batch, conf):
-    """Fabric-side bytes per gate-GEMM launch from a committed rocprofv3 PMC pass of THIS workload (batch and
-    confidence schedule must match the keys stored with the measurement), else None: PMC counters cannot be read
-    from inside this process, and a figure measured on another batch is not evidence for this run."""
+def pmc_traffic(batch, conf, steps):
+    """Fabric-side bytes per gate-GEMM launch from a committed rocprofv3 PMC pass of THIS workload (batch, confidence
+    schedule AND frames per call must match the keys stored with the measurement: the launch population -- launches per
+    step, FLOPs per launch -- changes with the call length), else None: PMC counters cannot be read from inside this
+    process, and a figure measured on another workload is not evidence for this run."""
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
         if not (name.endswith(".json") and "pmc_traffic" in name):
             continue
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            if int(d.get("batch", -1)) == batch and d.get("conf") == conf:
+            if int(d.get("batch", -1)) == batch and d.get("conf") == conf and int(d.get("steps", -1)) == steps:
                 return float(d["traffic_bytes_per_launch"]), name
         except (OSError, KeyError, ValueError, TypeError):
             continue
@@ -230,7 +231,7 @@ class Workload:
         ach = flop_per_launch * launches / (busy_ms * 1e-3) / 1e12
         ach_launch = flop_per_launch / avg_s / 1e12
         path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
-        traffic, src = pmc_traffic(B, self.conf)
+        traffic, src = pmc_traffic(B, self.conf, K)
         issued_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if self.split else PEAK_FP32_MFMA_TFLOPS
         wave, stepped, ticks = net.sequence_stats()
         return {"bound": "mfma", "kernel": "rc_gemm_split_kernel" if self.split else "rc_gemm_kernel", "achieved": round(ach, 2),
@@ -240,7 +241,7 @@ class Workload:
                 "traffic": traffic,
                 "traffic_note": (f"fabric-side L2 miss bytes per gate-GEMM launch, rocprofv3 PMC pass of this batch/schedule "
                                  f"(profiles/{src})" if src else
-                                 "no PMC pass committed for this batch/schedule (profiles/*pmc_traffic*.json are keyed by batch + conf)"),
+                                 "no PMC pass committed for this batch / schedule / frames per call (profiles/*pmc_traffic*.json are keyed by all three)"),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches, "launches_per_step": round(launches / K, 2),
                 "busy_ms": round(busy_ms, 3), "concurrency": round(ms / busy_ms, 3),
                 "per_launch": {"achieved": round(ach_launch, 2), "frac": round(ach_launch / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -258,6 +259,24 @@ class Workload:
                         "frame incl. the weight-streaming 16-row launches and the per-frame logic kernels"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher (WORLD_SIZE unset): one process per GPU via torch.distributed.run on a
+    free local port -- the same command line the driver uses for N > 1. Fails loudly when fewer than N devices are visible
+    (RC_DIST_SHARE_DEVICE=1, dry runs on a 1-GPU box, lets the ranks share device 0)."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("RC_DIST_SHARE_DEVICE") != "1":
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible to this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def rate(dts, K, bodies_total, what):
     """variant record from the sorted times of its repetitions (median = the value)."""
     med = dts[len(dts) // 2]
@@ -266,36 +285,62 @@ def rate(dts, K, bodies_total, what):
 
 
 def live_b1(sd, body, frames=2000):
-    """BASELINE config 5: batch 1, one hipGraph-captured frame per host round trip through the C ABI (rc_live_step on
-    host tensors, like live_server.py:40-48 hands them over): p50 / p99 latency of `frames` frames."""
+    """BASELINE config 5: batch 1, one captured frame per host round trip through the C ABI (rc_live_step on host tensors, like
+    live_server.py:40-48 hands them over): p50 / p99 latency of `frames` frames. The steady-state frame is the lean seven-launch
+    capture (csrc/rc_live.hip), dispatched as a pre-built AQL packet chain (csrc/rc_aql.cpp); `graph_replay` = the same capture
+    replayed with hipGraphLaunch (RC_LIVE_AQL=0), fewer frames."""
     import ctypes as C_
     from robustcap_amd.net.sig_mp import Net
     m = synth.make_motion(7, 1, 600, body, conf="mixed")
     t = torch.from_numpy
-    net = Net(body=body, batch=1)
-    net.load_state_dict(sd)
-    net.gravityc = t(m["gravityc"])
-    net.use_graph = True
     T = m["j2dc"].shape[1]
     ins = [(t(m["j2dc"][0, k]).contiguous(), t(m["accc"][0, k]).contiguous(), t(m["oric"][0, k]).contiguous()) for k in range(T)]
-    pose, tran = torch.empty(1, 24, 3, 3), torch.empty(1, 3)
-    net.forward_online(*ins[0], first_frame=True)                       # captures the frame
-    fn, ctx = net._lib.rc_live_step, net._ctx
-    pp, pt = C_.c_void_p(pose.data_ptr()), C_.c_void_p(tran.data_ptr())
-    ptrs = [(C_.c_void_p(a.data_ptr()), C_.c_void_p(b.data_ptr()), C_.c_void_p(c.data_ptr())) for a, b, c in ins]
-    lat = np.empty(frames + 50)
-    for i in range(frames + 50):
-        a, b, c = ptrs[1 + i % (T - 1)]
-        t0 = time.perf_counter()
-        rc = fn(ctx, a, b, c, None, 0, pp, pt)
-        lat[i] = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError(f"rc_live_step failed ({rc})")
-    lat = lat[50:] * 1e6
-    return {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
-            "mean_us": round(float(lat.mean()), 1), "frames": frames, "value": round(1e6 / float(lat.mean()), 1),
-            "unit": "body-frames/s", "weight_stream_floor_us": 38.6,
-            "workload": "BASELINE config 5: batch 1, hipGraph-captured frame, host tensors in / out through rc_live_step"}
+
+    def run(n_frames, env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            net = Net(body=body, batch=1)                                   # the switches are read when the context is created
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        net.load_state_dict(sd)
+        net.gravityc = t(m["gravityc"])
+        net.use_graph = True
+        pose, tran = torch.empty(1, 24, 3, 3), torch.empty(1, 3)
+        net.forward_online(*ins[0], first_frame=True)                       # captures the frame
+        fn, ctx = net._lib.rc_live_step, net._ctx
+        pp, pt = C_.c_void_p(pose.data_ptr()), C_.c_void_p(tran.data_ptr())
+        ptrs = [(C_.c_void_p(a.data_ptr()), C_.c_void_p(b.data_ptr()), C_.c_void_p(c.data_ptr())) for a, b, c in ins]
+        lat = np.empty(n_frames + 50)
+        for i in range(n_frames + 50):
+            a, b, c = ptrs[1 + i % (T - 1)]
+            t0 = time.perf_counter()
+            rc = fn(ctx, a, b, c, None, 0, pp, pt)
+            lat[i] = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError(f"rc_live_step failed ({rc})")
+        lat = lat[50:] * 1e6
+        lean, full = net.live_stats()
+        cap, aql, note = C_.c_int32(0), C_.c_int32(0), C_.create_string_buffer(256)
+        net._lib.rc_get_live_backend(net._ctx, C_.byref(cap), C_.byref(aql), note, 256)
+        return lat, lean, full, bool(cap.value), bool(aql.value), note.value.decode()
+
+    lat, lean, full, cap, aql, note = run(frames, {})
+    out = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+           "mean_us": round(float(lat.mean()), 1), "frames": frames, "value": round(1e6 / float(lat.mean()), 1),
+           "unit": "body-frames/s", "weight_stream_floor_us": 38.6,
+           "lean_frames": lean, "full_frames": full, "launches_per_lean_frame": 7 if cap else None,
+           "dispatch": "AQL packet chain on the context's own HSA queue" if aql else ("hipGraphLaunch" + (f" ({note})" if note else "")),
+           "workload": "BASELINE config 5: batch 1, captured frame (steady state: seven kernels), host tensors in / out through rc_live_step"}
+    if aql:
+        lat2 = run(max(200, frames // 4), {"RC_LIVE_AQL": "0"})[0]
+        out["graph_replay"] = {"p50_us": round(float(np.percentile(lat2, 50)), 1), "p99_us": round(float(np.percentile(lat2, 99)), 1),
+                               "frames": len(lat2)}
+    return out
 
 
 def main():
@@ -315,9 +360,17 @@ def main():
     if args.steps < 1 or args.warmup < 0 or args.batch < 1 or args.reps < 1:
         ap.error("--steps >= 1, --warmup >= 0, --batch >= 1, --reps >= 1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)              # does not return: re-executes this command line under torch.distributed.run
     rank, world, local = rdist.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     torch.cuda.set_device(local if world > 1 else 0)
+    ranks_seen = None
+    if world > 1:                           # every rank is really there: a sum of ones over the job's own collective backend
+        one = torch.ones(1, dtype=torch.int32, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
 
     K, W = args.steps, args.warmup
     if args.scaling == "strong":
@@ -365,6 +418,27 @@ def main():
                 if long_frames:
                     v["high_long"] = variant(hw, long_frames, f"config 2a at {long_frames} frames per call")
                 del hw
+        if world > 1 and args.scaling == "weak":
+            # the same bodies-in-total as ONE GPU's batch, split over the ranks (dist.shard_range): what strong scaling of the
+            # headline workload gives; the weak figure above keeps --batch bodies on every rank
+            def strong():
+                if args.batch < world:                                    # (the same verdict on every rank: no rank may skip a collective)
+                    raise RuntimeError(f"{args.batch} bodies cannot be split over {world} ranks")
+                a, b = rdist.shard_range(args.batch, rank, world)
+                sw = Workload(sd, body, args.conf, b - a, W, max(K, long_frames), rank, world, 3, Net.default_gemm_mode(args.batch))
+                tot = args.batch if args.batch % world else None
+                r = {"k": rate(sw.timed_reps(K, 3, tot), K, args.batch, f"strong scaling: {args.batch} bodies in total over {world} ranks, "
+                                                                       f"{K} frames per call")}
+                if long_frames:
+                    r["long"] = rate(sw.timed_reps(long_frames, 3, tot), long_frames, args.batch, f"the same at {long_frames} frames per call")
+                return r
+            sv = guarded(strong)
+            if "k" in sv:
+                v["strong"] = sv["k"]
+                if "long" in sv:
+                    v["strong_long"] = sv["long"]
+            else:
+                v["strong"] = sv
         if world == 1:
             def occ():
                 w = Workload(sd, body, "occ", 1024, 8, 64, 0, 1)
@@ -392,6 +466,7 @@ def main():
                                    f"confidence schedule '{args.conf}', seeded random weights (63.4 M params)",
                        "batch_per_gpu": B, "bodies_total": bodies_total, "frames": K, "conf": args.conf,
                        "parallelism": f"dp{world} (sequence sharding)"},
+            "rccl": None if world == 1 else {"backend": torch.distributed.get_backend(), "ranks_seen": ranks_seen},
             "roofline": roof, "cpu_baseline": cpu, "variants": variants}), flush=True)
     if world > 1:
         torch.distributed.barrier()          # rank 0 may still be in its instrumented pass

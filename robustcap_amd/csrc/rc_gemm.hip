@@ -42,10 +42,6 @@ extern "C" int rc_trace_tiles_set(unsigned long long* buf, unsigned long long ca
 #endif
 #define RC_LDS_HEAD 192       // ints in front of the partial sums: active rows of the tile [128], per-wave counts [4]
 
-#ifndef RC_ABLATE
-#define RC_ABLATE 0           // tools/gemm_probe.cpp: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA
-#endif
-
 #include "rc_gates.h"
 __device__ __forceinline__ float sigmoidf_(float x) { return rc_gate_sigmoid(x); }
 __device__ __forceinline__ float tanhf_(float x) { return rc_gate_tanh(x); }
@@ -61,10 +57,10 @@ __device__ __forceinline__ void load_chunk(Frag<MR, NC>& f, const float* const (
                                            long long bstride) {
 #pragma unroll
     for (int r = 0; r < MR; ++r)
-        if (!(RC_ABLATE & 1) || RC_ABLATE == 4) f.a[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
+        f.a[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
 #pragma unroll
     for (int j = 0; j < NC; ++j)
-        if (!(RC_ABLATE & 2) || RC_ABLATE == 4) {
+        {
             if constexpr (NTL) f.b[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pb + j * bstride));
             else f.b[j] = *reinterpret_cast<const f32x4*>(pb + j * bstride);
         }
@@ -78,11 +74,7 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
         for (int j = 0; j < NC; ++j) {
 #pragma unroll
             for (int r = 0; r < MR; ++r) {
-#if RC_ABLATE == 4
-                acc[r][j][s] += f.a[r][s] + f.b[j][s];
-#else
                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[r][s], f.b[j][s], acc[r][j], 0, 0, 0);
-#endif
             }
         }
     }
@@ -101,9 +93,6 @@ __device__ __forceinline__ void mma_chunk(const Frag<MR, NC>& f, f32x4 (&acc)[MR
 #ifndef RC_SPLIT_PRODUCTS
 #define RC_SPLIT_PRODUCTS 6
 #endif
-#ifndef RC_ABL_SPLIT
-#define RC_ABL_SPLIT 0        // timing-only probe builds (wrong results), bit mask: 1 = weight loads hit one k-block only (cache
-#endif                        // resident), 2 = no operand split (constant operands), 4 = activation loads hit one k-block only, 8 = no loads at all
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -120,12 +109,6 @@ struct FragS {                // one k-block (32 k): fp32 activations (two float
 template <int MR, int NC>
 __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const u32x4* pb,
                                             long long bstride) {
-#if RC_ABL_SPLIT & 8
-    return;                       // fragments keep their initial (zero) contents
-#endif
-#if RC_ABL_SPLIT & 4
-    aoff = 0;
-#endif
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
@@ -188,11 +171,7 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         u32x4 uh, um, ul;
-#if RC_ABL_SPLIT & 2
-        uh = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} ^ (__builtin_bit_cast(u32x4, f.a0[r]) & 0x00010001u); um = uh; ul = uh;   // ~1.0: finite
-#else
         split3(f.a0[r], f.a1[r], uh, um, ul);
-#endif
         const bf16x8 ah = __builtin_bit_cast(bf16x8, uh), am = __builtin_bit_cast(bf16x8, um), al = __builtin_bit_cast(bf16x8, ul);
         // small terms first; consecutive MFMAs go to different accumulators (NC of them between two uses of one)
 #define RC_PROD(AV, PL)                                                                                                  \
@@ -295,7 +274,7 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     const long long bs = (long long)Qs * KBU;                       // uint4 between consecutive 16-column blocks
     const u32x4* pbs = reinterpret_cast<const u32x4*>(RC_SPLIT_W32 ? (const void*)P.W : P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
     constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 4 * RC_WPL) * 3 + (RC_SPLIT_W32 ? NC * 12 : 0) + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
-    if constexpr (SPLIT && !(RC_ABL_SPLIT & 9)) {
+    if constexpr (SPLIT) {
         load_kblock_b<MR, NC>(fa, pbs, bs);
         if constexpr (DEEP) load_kblock_b<MR, NC>(fb, pbs + (long long)min(1, Qws - 1) * KBU, bs);
     }
@@ -346,15 +325,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define LOADS_A(F, QI)                                                                                              \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (RC_ABL_SPLIT & 9) LOADS(F, QI);                                                                         \
-        else if (k_ < K0) load_kblock_a<MR, NC>(F, pa0, (long long)k_ * 16);                                        \
+        if (k_ < K0) load_kblock_a<MR, NC>(F, pa0, (long long)k_ * 16);                                        \
         else load_kblock_a<MR, NC>(F, pa1, (long long)(k_ - K0) * 16);                                              \
     } while (0)
 #define LOADS(F, QI)                                                                                                \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * KBU, bs);              \
-        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)((RC_ABL_SPLIT & 1) ? 0 : (QI)) * KBU, bs);               \
+        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)(QI) * KBU, bs);              \
+        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)(QI) * KBU, bs);               \
     } while (0)
         // With the MFMA time cut 2.7x the K loop is bound by what a wave keeps in flight (one k-block = 23 KiB for a 64 x 80
         // tile; 4 waves x 23 KiB / ~2 us of L2 / fabric latency = the 47 GB/s per CU the two-buffer loop was measured at):

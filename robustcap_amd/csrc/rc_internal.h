@@ -299,8 +299,8 @@ struct SmplifyArgs {
 };
 void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t s);
 // vector kernels of the device-resident L-BFGS (rc_smplify.hip)
-#define RC_LBFGS_MAX_PAIRS 32
-struct VecComb { const float* v[2 * RC_LBFGS_MAX_PAIRS + 1]; float c[2 * RC_LBFGS_MAX_PAIRS + 1]; int n_vec; };
+#define RC_LBFGS_MAX_PAIRS 100             // history of the device-resident L-BFGS = torch.optim.LBFGS's default history_size
+struct VecComb { const float* v[2 * RC_LBFGS_MAX_PAIRS + 1]; float c[2 * RC_LBFGS_MAX_PAIRS + 1]; int n_vec; };   // 2.4 KB kernel argument
 struct VecJob { const float* a; const float* b; int op; int pad_; };     // op 0: sum a b, 1: max |a|, 2: sum |a|
 void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t s);
 void rc_launch_vec_pair(const float* g_new, const float* g_old, const float* d, float t, float* y, float* sv, long long n, hipStream_t s);

@@ -135,6 +135,13 @@ double total_loss(const float* terms, int64_t T) {
 // 45,000-element host vectors (10 of the 13.8 ms per 600-frame row).
 const int kSlots = 6, kSlotJobs = 4;
 
+// RC_LBFGS_HISTORY: curvature pairs kept (default: torch's history_size, 100); read per call, by both formulations
+int lbfgs_history_env() {
+    const char* v = std::getenv("RC_LBFGS_HISTORY");
+    const int h = v && *v ? std::atoi(v) : 100;
+    return h < 1 ? 1 : h;
+}
+
 int reserve_lbfgs(rc_ctx* ctx, SmplifyState* s, int64_t T, int pairs) {
     if (T <= s->lb_cap && pairs <= s->lb_pairs) return RC_OK;
     for (float** p : {&s->xt, &s->dir, &s->gslot, &s->Sv, &s->Yv})
@@ -166,8 +173,12 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
                        int max_iter, hipStream_t st, DevResult& res) {
     const size_t n = (size_t)T * 75;
     const int nb = (int)((n + 4095) / 4096);
-    const int M = std::min(max_iter, RC_LBFGS_MAX_PAIRS);
-    if (int rc = reserve_lbfgs(ctx, s, T, M)) return rc;
+    // History: the last M curvature pairs (torch.optim.LBFGS: history_size = 100, old_dirs.pop(0) when full). M + 1 physical slots:
+    // the candidate pair of an iteration goes to the spare one, so that rejecting it (y.s <= 1e-10) leaves the oldest pair alone;
+    // accepting it into a full history makes the oldest pair's slot the next spare. RC_LBFGS_HISTORY shrinks M (A/B tests).
+    const int M = std::max(1, std::min(std::min(max_iter, RC_LBFGS_MAX_PAIRS), lbfgs_history_env()));
+    const int P = M + 1;
+    if (int rc = reserve_lbfgs(ctx, s, T, P)) return rc;
     const int max_eval = max_iter * 5 / 4;
     const float tolerance_grad = 1e-7f, tolerance_change = 1e-9f;
     const unsigned long long ign = rc_ctx_ign_mask(ctx);
@@ -223,11 +234,12 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
     int evals = 1;
     if (gmax <= tolerance_grad) { res.n_eval = evals; return RC_OK; }
 
-    // inner products among the basis {s_0.., y_0.., g}: index i -> s_i, M + i -> y_i, 2M -> g
-    const int NB = 2 * M + 1;
-    std::vector<double> G((size_t)NB * NB, 0.0), ro(M, 0.0), al(M, 0.0), delta(NB, 0.0);
+    // inner products among the basis {s_0.., y_0.., g} by PHYSICAL slot: index i -> s_i, P + i -> y_i, 2P -> g
+    const int NB = 2 * P + 1, IG = 2 * P;
+    std::vector<double> G((size_t)NB * NB, 0.0), ro(P, 0.0), al(P, 0.0), delta(NB, 0.0);
     auto Gat = [&](int a, int b) -> double& { return G[(size_t)a * NB + b]; };
-    int m = 0;                                                          // curvature pairs kept
+    std::vector<int> order;                                             // physical slots of the pairs kept, oldest first
+    int spare = 0;                                                      // physical slot of the next candidate
     double H_diag = 1.0;
     float t = 0.0f, prev_loss = loss, gtd = 0.0f, d_max = 0.0f;
     int prev_base = base;
@@ -239,22 +251,20 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
         if (n_iter == 1) {
             comb.n_vec = 1; comb.v[0] = slot(base); comb.c[0] = -1.0f;     // d = -g
         } else {
-            // candidate pair m: y = g - prev_g, s = t d
-            float* yv = s->Yv + (size_t)m * n;
-            float* sv = s->Sv + (size_t)m * n;
-            if (m < M) rc_launch_vec_pair(slot(base), slot(prev_base), s->dir, t, yv, sv, (long long)n, st);
-            // inner products: the candidate against the basis, the gradient against the basis
+            // candidate pair (slot `spare`): y = g - prev_g, s = t d
+            const int c = spare;
+            rc_launch_vec_pair(slot(base), slot(prev_base), s->dir, t, s->Yv + (size_t)c * n, s->Sv + (size_t)c * n, (long long)n, st);
+            // inner products: the candidate against the pairs kept (and itself), the gradient against all of them
             struct Want { int a, b; };
             std::vector<Want> want;
-            const int mc = m < M ? m + 1 : m;                             // pairs incl. the candidate
-            if (m < M) {
-                for (int j = 0; j <= m; ++j) { want.push_back({m, j}); want.push_back({m, M + j}); want.push_back({M + m, M + j}); }
-                for (int j = 0; j < m; ++j) want.push_back({M + m, j});
-            }
-            for (int j = 0; j < mc; ++j) { want.push_back({2 * M, j}); want.push_back({2 * M, M + j}); }
-            want.push_back({2 * M, 2 * M});
+            std::vector<int> with_c(order);
+            with_c.push_back(c);
+            for (int j : with_c) { want.push_back({c, j}); want.push_back({c, P + j}); want.push_back({P + c, P + j}); }
+            for (int j : order) want.push_back({P + c, j});
+            for (int j : with_c) { want.push_back({IG, j}); want.push_back({IG, P + j}); }
+            want.push_back({IG, IG});
             auto vec_of = [&](int idx) -> const float* {
-                return idx == 2 * M ? slot(base) : (idx >= M ? s->Yv + (size_t)(idx - M) * n : s->Sv + (size_t)idx * n);
+                return idx == IG ? slot(base) : (idx >= P ? s->Yv + (size_t)(idx - P) * n : s->Sv + (size_t)idx * n);
             };
             for (size_t q = 0; q < want.size(); ++q) s->jobs_h[var0 + q] = VecJob{vec_of(want[q].a), vec_of(want[q].b), 0, 0};
             herr = hipMemcpyAsync(s->jobs_d + var0, s->jobs_h + var0, want.size() * sizeof(VecJob), hipMemcpyHostToDevice, st);
@@ -267,32 +277,40 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
                 const double v = job_sum(var0 + (int)q, false);
                 Gat(want[q].a, want[q].b) = v; Gat(want[q].b, want[q].a) = v;
             }
-            if (m < M) {
-                const double ys = Gat(m, M + m);
+            {
+                const double ys = Gat(c, P + c);
                 if ((float)ys > 1e-10f) {                                 // keep the pair (torch: ys > 1e-10)
-                    H_diag = ys / Gat(M + m, M + m);
-                    ro[m] = 1.0 / ys;
-                    ++m;
+                    H_diag = ys / Gat(P + c, P + c);
+                    ro[c] = 1.0 / ys;
+                    if ((int)order.size() == M) {                         // history full: the oldest pair goes (old_dirs.pop(0)),
+                        spare = order.front();                            // its slot takes the next candidate
+                        order.erase(order.begin());
+                        order.push_back(c);
+                    } else {
+                        order.push_back(c);
+                        spare = (int)order.size();                        // slots are handed out in order until the history is full
+                    }
                 }
             }
+            const int m = (int)order.size();
             // two-loop recursion on coefficients: q = sum_k delta[k] basis[k], starting from q = -g
             std::fill(delta.begin(), delta.end(), 0.0);
-            delta[2 * M] = -1.0;
+            delta[IG] = -1.0;
             auto dot_q = [&](int idx) {
-                double r = delta[2 * M] * Gat(2 * M, idx);
-                for (int i = 0; i < m; ++i) r += delta[i] * Gat(i, idx) + delta[M + i] * Gat(M + i, idx);
+                double r = delta[IG] * Gat(IG, idx);
+                for (int j : order) r += delta[j] * Gat(j, idx) + delta[P + j] * Gat(P + j, idx);
                 return r;
             };
-            for (int i = m - 1; i >= 0; --i) { al[i] = dot_q(i) * ro[i]; delta[M + i] -= al[i]; }
+            for (int i = m - 1; i >= 0; --i) { const int j = order[i]; al[j] = dot_q(j) * ro[j]; delta[P + j] -= al[j]; }
             for (double& v : delta) v *= H_diag;
-            for (int i = 0; i < m; ++i) { const double be = dot_q(M + i) * ro[i]; delta[i] += al[i] - be; }
+            for (int i = 0; i < m; ++i) { const int j = order[i]; const double be = dot_q(P + j) * ro[j]; delta[j] += al[j] - be; }
             comb.n_vec = 0;
-            for (int i = 0; i < m; ++i) {
-                comb.v[comb.n_vec] = s->Sv + (size_t)i * n; comb.c[comb.n_vec++] = (float)delta[i];
-                comb.v[comb.n_vec] = s->Yv + (size_t)i * n; comb.c[comb.n_vec++] = (float)delta[M + i];
+            for (int j : order) {
+                comb.v[comb.n_vec] = s->Sv + (size_t)j * n; comb.c[comb.n_vec++] = (float)delta[j];
+                comb.v[comb.n_vec] = s->Yv + (size_t)j * n; comb.c[comb.n_vec++] = (float)delta[P + j];
             }
-            comb.v[comb.n_vec] = slot(base); comb.c[comb.n_vec++] = (float)delta[2 * M];
-            gtd = (float)dot_q(2 * M);
+            comb.v[comb.n_vec] = slot(base); comb.c[comb.n_vec++] = (float)delta[IG];
+            gtd = (float)dot_q(IG);
         }
         rc_launch_vec_comb(comb, s->dir, (long long)n, st);
         prev_base = base;
@@ -557,6 +575,7 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
     opt.lr = lr;
     opt.max_iter = max_iter;
     opt.max_eval = max_iter * 5 / 4;
+    opt.history_size = lbfgs_history_env();
     const L::Result r = L::minimize(closure, x, opt);
     if (hip_rc != RC_OK) return hip_rc;
 

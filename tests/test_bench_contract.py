@@ -35,14 +35,15 @@ def test_guarded_records_the_error_instead_of_raising():
 
 def test_pmc_traffic_is_keyed_by_batch_and_schedule():
     import bench
-    v, src = bench.pmc_traffic(12345, "mixed")                 # no PMC pass of such a batch is committed
+    v, src = bench.pmc_traffic(12345, "mixed", 128)            # no PMC pass of such a batch is committed
     assert v is None and src is None
     for name in os.listdir(os.path.join(ROOT, "profiles")):
         if "pmc_traffic" in name and name.endswith(".json"):
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if "batch" in d and "conf" in d:
-                v, src = bench.pmc_traffic(int(d["batch"]), d["conf"])
+            if "batch" in d and "conf" in d and "steps" in d:      # (records of earlier rounds carry no frames-per-call key: never quoted)
+                v, src = bench.pmc_traffic(int(d["batch"]), d["conf"], int(d["steps"]))
                 assert v is not None and v > 0
+                assert bench.pmc_traffic(int(d["batch"]), d["conf"], int(d["steps"]) + 1) == (None, None)
 
 
 @pytest.mark.gpu
@@ -64,7 +65,8 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     roof = d["roofline"]
     # (against the fp32-input roof, which the bf16 MFMAs the split kernel issues do not have: an all-visible run on a fast box
     # reaches 1.0; the mixed default stays near 0.8 -- frac_issued is the utilisation figure)
-    assert "error" not in roof and 0 < roof["frac"] < 1.2 and roof["frac_issued"] < 1 and roof["bound"] == "mfma"
+    # hard bound: the rate against the roof of the instructions the kernel issues; frac (against the fp32-input roof) is informational
+    assert "error" not in roof and 0 < roof["frac_issued"] < 1 and roof["frac"] > 0 and roof["bound"] == "mfma"
     assert roof["traffic"] is None or roof["traffic"] > 0
     assert roof["frac_issued"] <= roof["frac"] and roof["peak_issued"] > roof["peak"]      # split products: the bf16 roof / 6
     # launches on two streams overlap: the kernel's busy time is at most the sum of the launch durations, at least half of it
@@ -77,7 +79,11 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     for k in ("high", "fp32_mfma", "mixed_long", "high_long", "occ1024"):
         assert "error" not in var[k] and var[k]["value"] > 0, (k, var[k])
     assert var["mixed_long"]["frames"] >= 128 and var["high_long"]["frames"] >= 128
-    assert "error" not in var["live_b1"] and 0 < var["live_b1"]["p50_us"] <= var["live_b1"]["p99_us"]
+    lv = var["live_b1"]
+    assert "error" not in lv and 0 < lv["p50_us"] <= lv["p99_us"]
+    assert lv["lean_frames"] > 0.9 * lv["frames"] and lv["launches_per_lean_frame"] == 7 and lv["dispatch"]
+    if "graph_replay" in lv:
+        assert 0 < lv["graph_replay"]["p50_us"] <= lv["graph_replay"]["p99_us"]
     if not extra:
         cpu = d["cpu_baseline"]
         assert "error" not in cpu and cpu["value"] > 0 and cpu["kind"] == "port"

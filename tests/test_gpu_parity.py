@@ -345,6 +345,29 @@ def test_error_behaviour(synth_assets):
         Net(body=synth_assets["body"], batch=1, device="cpu")
 
 
+def test_default_construction_reads_the_smpl_pickle(synth_assets, tmp_path, monkeypatch):
+    """`Net()` with no body= (net/sig_mp.py:19-20 -> articulate/model.py:29-40): models/SMPL_male.pkl of the working directory,
+    official layout, through body.load_smpl_pickle -- the same outputs as the net built from the dict; no pickle -> loud error."""
+    from oracle.capture_reference import _write_body_pickle
+    from robustcap_amd import synth
+    from robustcap_amd.net.sig_mp import Net
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        Net()
+    _write_body_pickle(str(tmp_path / "models" / "SMPL_male.pkl"), synth_assets["body"])
+    a = Net()
+    a.load_state_dict(synth_assets["state_dict"])
+    b = make_net(synth_assets, 1)
+    m = synth.make_motion(99, 1, 12, synth_assets["body"], conf="mixed")
+    m["j2dc"][0, 4:9, :, 2] = 0.4                                 # occluded frames: the landmark skinning (w33 / v33 of the pickle) feeds the updater
+    a.gravityc = b.gravityc = t(m["gravityc"])
+    for i in range(12):
+        args = (t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+        pa, ta = a.forward_online(*args, first_frame=(i == 0))
+        pb, tb = b.forward_online(*args, first_frame=(i == 0))
+        assert torch.equal(pa, pb) and torch.equal(ta, tb), i
+
+
 def test_live_graph_step_equals_eager(synth_assets, monkeypatch):
     """config 5: the hipGraph-captured frame-stepped frame (host tensors in/out) == the ordinary enqueue path, bitwise.
     (RC_LIVE_LEAN=0: every live frame on the frame-stepped captures; the lean seven-launch capture that batch <= 4 replays for

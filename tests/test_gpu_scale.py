@@ -140,3 +140,12 @@ def test_strong_split_over_two_ranks_equals_one_rank():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["bodies_total"] == 96 and d["variants"]["high"]["value"] > 0
     assert d["roofline"] is not None and d["cpu_baseline"] is None
+    # `python bench.py --gpus 2` with NO launcher: the bench starts its own ranks (torch.distributed.run on a free port), the line
+    # says n_gpus 2, every rank answered the collective, and the strong split of the headline batch sits beside the weak figure
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--batch", "48",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root,
+                       env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl"]["ranks_seen"] == 2 and d["config"]["bodies_total"] == 96
+    assert d["variants"]["strong"]["value"] > 0 and "48 bodies in total over 2 ranks" in d["variants"]["strong"]["workload"]

@@ -159,6 +159,37 @@ def test_device_resident_lbfgs_against_the_host_formulation(g, runner, monkeypat
     assert dev["final_loss"] < 0.45 * dev["first_loss"]
 
 
+def test_lbfgs_history_slides_like_torch(g, runner, monkeypatch):
+    """More iterations than curvature pairs fit (round-3 advice: the device-resident optimiser used to freeze its history once
+    it was full). torch.optim.LBFGS drops the OLDEST pair (old_dirs.pop(0)); so does the host formulation (rc_lbfgs.h, pinned
+    against torch in tests/test_lbfgs_host.py). With a history of 4 and 40 iterations both formulations spend the same
+    evaluation budget and end in the same range, the run differs from the one with the full history (eviction is live), and
+    more than 100 iterations (torch's history_size) run through."""
+    from robustcap_amd.smplify import smplify_runner
+    T = int(g["run_T"])
+    args = (t(g["run_pose0"]), t(g["run_tran0"]), t(g["run_kp"]), t(g["run_imu_ori"]), T, t(g["run_K"]))
+    out = {}
+    for hist in ("4", "100"):
+        for mode in ("0", "1"):
+            monkeypatch.setenv("RC_LBFGS_HISTORY", hist)
+            monkeypatch.setenv("RC_SMPLIFY_HOST_LBFGS", mode)
+            runner.run(*args[:4], args[5], lr=0.001, max_iter=40)
+            out[hist, mode] = dict(runner.last_info)
+    for hist in ("4", "100"):
+        dev, host = out[hist, "0"], out[hist, "1"]
+        assert dev["status"] == host["status"] == 1 and dev["first_loss"] == host["first_loss"]
+        assert abs(dev["n_eval"] - host["n_eval"]) <= 2 and abs(dev["n_iter"] - host["n_iter"]) <= 2, (hist, dev, host)
+        assert dev["n_iter"] > 8                                         # well past a 4-pair history
+        assert abs(dev["final_loss"] - host["final_loss"]) < 0.1 * host["first_loss"]
+        assert dev["final_loss"] < 0.45 * dev["first_loss"]
+    assert out["4", "0"]["final_loss"] != out["100", "0"]["final_loss"]  # the short history really evicts
+    monkeypatch.delenv("RC_LBFGS_HISTORY")
+    monkeypatch.setenv("RC_SMPLIFY_HOST_LBFGS", "0")
+    runner.run(*args[:4], args[5], lr=0.001, max_iter=130)
+    long_run = dict(runner.last_info)
+    assert long_run["status"] == 1 and long_run["final_loss"] <= out["100", "0"]["final_loss"] * 1.05
+
+
 def test_runner_gate_and_errors(g, runner, synth_assets):
     from robustcap_amd import _lib
     from robustcap_amd.smplify import TemporalSMPLify, smplify_runner

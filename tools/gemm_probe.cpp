@@ -1,6 +1,13 @@
-// Ablation probe of rc_gemm_kernel (not part of the product): times one LSTM-layer launch of rnn4-like shape
-// (B rows, H hidden) with parts of the kernel compiled out (-DRC_ABLATE=n, see rc_gemm.hip).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRC_ABLATE=0 -I robustcap_amd/csrc tools/gemm_probe.cpp -o tools/probe0
+// Ablation probe of rc_gemm_kernel (not part of the product): times one LSTM-layer launch of rnn4-like shape (B rows, H hidden).
+// The ablation switches (-DRC_ABLATE=n: 1 = no A loads, 2 = no B loads, 3 = no loads, 4 = no MFMA; -DRC_ABL_SPLIT=mask for the
+// split-bf16 K loop) are NOT in the product source -- timing-only builds that compute wrong results must not be one stray -D away
+// from a library that passes the ABI test. They live in profiles/r04_gemm_ablation_macros.diff: apply it to a COPY of rc_gemm.hip
+//   cp robustcap_amd/csrc/rc_gemm.hip /tmp/rc_gemm_probe.hip && patch /tmp/rc_gemm_probe.hip profiles/r04_gemm_ablation_macros.diff
+// and include that copy here instead. Unpatched, this file times the product kernel (RC_ABLATE reads 0):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I robustcap_amd/csrc tools/gemm_probe.cpp -o tools/probe0
+#ifndef RC_ABLATE
+#define RC_ABLATE 0
+#endif
 #include "../robustcap_amd/csrc/rc_gemm.hip"
 #include <cstdio>
 #include <cstdlib>

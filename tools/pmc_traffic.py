@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Reduce the rocprofv3 --pmc databases written by tools/pmc_traffic.sh to fabric-side bytes per launch of the dominant
 kernel (the wide-tile gate GEMM: rc_gemm_split_kernel, or rc_gemm_kernel in fp32-MFMA mode), keyed by the workload
-(batch, confidence schedule) so that bench.py only quotes it for the run it belongs to.
-    python tools/pmc_traffic.py gpurun_out/pmc [batch] [conf] > profiles/rNN_pmc_traffic.json"""
+(batch, confidence schedule, frames per call) so that bench.py only quotes it for the run it belongs to.
+    python tools/pmc_traffic.py gpurun_out/pmc128 [batch] [conf] [steps] > profiles/rNN_pmc_traffic_steps128.json"""
 import glob
 import json
 import os
@@ -12,6 +12,7 @@ import sys
 root = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 conf = sys.argv[3] if len(sys.argv) > 3 else "mixed"
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 
 
 def per_launch(tag, counters):
@@ -39,10 +40,10 @@ wide = next((k for k in ("rc_gemm_split_kernel", "rc_gemm_kernel") if k in res.g
 if wide and wide in res.get("WRITE_SIZE", {}):
     f, n = res["FETCH_SIZE"][wide]
     w, _ = res["WRITE_SIZE"][wide]
-    out = {"batch": batch, "conf": conf, "kernel": wide,
+    out = {"batch": batch, "conf": conf, "steps": steps, "kernel": wide,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in three separate passes with --kernel-trace only "
-                     "(tools/pmc_traffic.sh: bench.py --steps 128 --warmup 16 --reps 1 --no-cpu-baseline --no-variants), per-launch average over "
-                     "%d launches of %s" % (n, wide),
+                     "(tools/pmc_traffic.sh: bench.py --steps %d --reps 1 --no-cpu-baseline --no-variants), per-launch average over "
+                     "%d launches of %s" % (steps, n, wide),
            "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
            "traffic_bytes_per_launch": (2 * f + w) * 1024,
            "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated",
