@@ -312,6 +312,17 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
                    const float* K_host, int64_t T, float lr, int32_t max_iter, float loss_threshold, float* pose_out,
                    float* tran_out, uint8_t* update_host, rc_smplify_info* info, void* stream);
 
+/* The same for n_rows independent (sequence, camera) rows at once (evaluate.py:86-90 loops them): every row runs the optimiser
+ * of rc_smplify_run on a host thread of its own, the device work of all rows goes out in lock-step rounds -- one launch per kind
+ * of operation over all rows, one read-back and one synchronisation per round -- so 72 rows cost about what the longest row's ~46
+ * rounds cost. Per row the arithmetic is that of rc_smplify_run (same n_iter / n_eval / losses). Arrays of n_rows: T, DEVICE
+ * pointers pose / tran / kp / imu_ori / pose_out / tran_out, HOST pointers update (uint8[T_r] each), HOST K[n_rows,9], infos
+ * (host_ms / device_ms are those of the whole batch; reserved = rounds). Rows rejected by the pre-check are copied through. */
+int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, const float* const* pose, const float* const* tran,
+                         const float* const* kp, const float* const* imu_ori, const float* K_host, float lr, int32_t max_iter,
+                         float loss_threshold, float* const* pose_out, float* const* tran_out, uint8_t* const* update_host,
+                         rc_smplify_info* infos, void* stream);
+
 /* The optimiser alone, in float64, on a caller-supplied objective (HOST): same algorithm object as rc_smplify_run
  * with Real = double. tests/ pin it against torch.optim.LBFGS evaluation by evaluation. objective returns the loss
  * at x[n] and fills grad[n]. x is updated in place; losses_out (capacity cap) receives every objective value in

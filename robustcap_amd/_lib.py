@@ -95,6 +95,7 @@ SIGNATURES = {
     "rc_smplify_set_ref3d": (_I32, [_P, _P]),
     "rc_smplify_loss_grad": (_I32, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(C.c_double), _P, _P]),
     "rc_smplify_run": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _F, _I32, _F, _P, _P, _P, C.POINTER(RcSmplifyInfo), _P]),
+    "rc_smplify_run_batch": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _F, _I32, _F, _P, _P, _P, _P, _P]),
     "rc_lbfgs_minimize": (_I32, [OBJECTIVE_FN, _P, _I64, C.POINTER(C.c_double), C.c_double, _I32, _I32, _I32, C.c_double,
                                  C.c_double, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(C.c_double), _I64]),
     "rc_camera_inputs": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -302,6 +302,14 @@ void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t 
 #define RC_LBFGS_MAX_PAIRS 100             // history of the device-resident L-BFGS = torch.optim.LBFGS's default history_size
 struct VecComb { const float* v[2 * RC_LBFGS_MAX_PAIRS + 1]; float c[2 * RC_LBFGS_MAX_PAIRS + 1]; int n_vec; };   // 2.4 KB kernel argument
 struct VecJob { const float* a; const float* b; int op; int pad_; };     // op 0: sum a b, 1: max |a|, 2: sum |a|
+// the same for all rows of a lock-step round of the batched optimiser (descriptor tables in device memory, the row from blockIdx.y)
+struct VecOp { const float* a; const float* b; const float* c; float* out; float* out2; float t; int kind; long long n; };   // kind 0 axpy, 1 pair
+struct VecCombRow { VecComb c; float* out; long long n; };
+struct VecJobN { const float* a; const float* b; int op; int pad_; long long n; };
+void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t s);
+void rc_launch_vec_ops(const VecOp* ops_dev, int n_ops, long long n_max, hipStream_t s);
+void rc_launch_vec_comb_rows(const VecCombRow* rows_dev, int n_rows, long long n_max, hipStream_t s);
+void rc_launch_vec_dots_rows(const VecJobN* jobs_dev, int n_jobs, int nb_max, double* partial, hipStream_t s);
 void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t s);
 void rc_launch_vec_pair(const float* g_new, const float* g_old, const float* d, float t, float* y, float* sv, long long n, hipStream_t s);
 void rc_launch_vec_comb(const VecComb& c, float* out, long long n, hipStream_t s);

@@ -77,11 +77,11 @@ __device__ __forceinline__ void frame_primal(const BodyConst* body, WaveScratch&
 }
 
 // ============================================================================================== forward pass
-__global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
+__device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const BodyConst* __restrict__ body_g, const int t) {
     __shared__ WaveScratch s;
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
     __shared__ float s_d[SM_DIM];
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     stage_body(&s_body, body_g, lane, 64);
     __syncthreads();
     const BodyConst* body = &s_body;
@@ -151,16 +151,27 @@ __global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const
     if (lane == 0) { A.frame_loss[t] = loss; A.imu_loss[t] = imu; A.argmin[t] = bi; }
 }
 
-// ============================================================================================= gradient pass
-#define TAN_LD 80     // tangent threads (72) padded: [joint][component][thread] layout keeps LDS accesses conflict-free
+__global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
+    smplify_fwd_frame(A, body_g, (int)blockIdx.x);
+}
+// all rows of a lock-step round of the batched optimiser (rc_smplify_api.cpp: RowBatch) in one launch: grid (T_max, rows)
+__global__ __launch_bounds__(64) void rc_smplify_fwd_rows_kernel(const SmplifyArgs* __restrict__ rows, const BodyConst* __restrict__ body_g) {
+    const SmplifyArgs A = rows[blockIdx.y];
+    if ((int)blockIdx.x >= A.T) return;
+    smplify_fwd_frame(A, body_g, (int)blockIdx.x);
+}
 
-__global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
+// ============================================================================================= gradient pass
+// Round 4: the chain rule through the kinematic tree runs in REVERSE (adjoints pulled from the leaves to the root, one pass by tree
+// level) instead of pushing 72 tangents forward through the descendants of their joints. Round 3 kept those tangents in 92 KB of
+// LDS -- one 128-thread workgroup per CU, 2 waves on a 256-CU chip per 600-frame evaluation: 72 rows x 600 frames x 26 evaluations
+// took ~200 ms however they were batched. Now 2 KB of adjoints; the kernel is no longer limited to one workgroup per CU.
+__device__ __forceinline__ void smplify_grad_frame(const SmplifyArgs& A, const BodyConst* __restrict__ body_g, const int t) {
     __shared__ WaveScratch s;
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
     __shared__ float s_lam[33][3];
-    __shared__ float s_M[24][9], s_m[24][3], s_o[24][3];
-    __shared__ float s_dG[24 * 9 * TAN_LD], s_dP[24 * 3 * TAN_LD];
-    const int t = blockIdx.x, tid = threadIdx.x, T = A.T;
+    __shared__ float s_Gb[24][9], s_pb[24][3];        // adjoints of the loss w.r.t. a joint's global rotation / position
+    const int tid = threadIdx.x, T = A.T;
     stage_body(&s_body, body_g, tid, 128);
     __syncthreads();
     const BodyConst* body = &s_body;
@@ -242,53 +253,65 @@ __global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, con
                 for (int b = 0; b < 3; ++b) M[3 * a + b] += w * s_lam[v][a] * body->v33[v][b];
             }
         }
+        // L depends on joint i through <M, G_i> + m . (P_i - G_i jrest_i) + o . P_i  (model.py:235: T_i = P_i - G_i jrest_i):
+        // own adjoints  Gb_i = M - m jrest_i^T,  pb_i = m + o
+        const float* jr = body->jrest[i];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) s_M[i][q] = M[q];
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { s_m[i][c] = m3[c]; s_o[i][c] = o3[c]; }
+            for (int b = 0; b < 3; ++b) s_Gb[i][3 * a + b] = M[3 * a + b] - m3[a] * jr[b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_pb[i][c] = m3[c] + o3[c];
     }
     __syncthreads();
+    // ---- reverse sweep: G_c = G_i Rl_c, P_c = P_i + G_i bone_c  =>  Gb_i += Gb_c Rl_c^T + pb_c bone_c^T,  pb_i += pb_c for every
+    // child c of i. A joint PULLS from its children (final once their level is done): no two lanes write the same adjoint.
+    {
+        const int lvl = tid < 24 ? body->level[tid] : -1;
+        for (int l = 8; l >= 0; --l) {
+            if (lvl == l) {
+                const int i = tid;
+                float Gb[9], pb[3];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Gb[q] = s_Gb[i][q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pb[q] = s_pb[i][q];
+                for (int c = i + 1; c < 24; ++c) {
+                    if (body->parent[c] != i) continue;
+                    const float* Gc = s_Gb[c];
+                    const float* Rc = s.Rl[c];
+                    const float* pc = s_pb[c];
+                    const float* bc = body->bone[c];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b)     // (Gb_c Rl_c^T)[a][b] = sum_k Gb_c[a][k] Rl_c[b][k]
+                            Gb[3 * a + b] += ((Gc[3 * a] * Rc[3 * b] + Gc[3 * a + 1] * Rc[3 * b + 1]) + Gc[3 * a + 2] * Rc[3 * b + 2]) + pc[a] * bc[b];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) pb[q] += pc[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) s_Gb[i][q] = Gb[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) s_pb[i][q] = pb[q];
+            }
+            __syncthreads();
+        }
+    }
 
     float* gout = A.grad_aa + (long long)t * 72;
     if (tid < 72) {
-        // ---- one tangent per thread: d/d aa[joint j][axis a] through Rodrigues and the descendants of j --------
+        // ---- d/d aa[joint j][axis a] = <G_parent^T Gb_j, d Rl_j / d aa_a>  (G_j = G_parent Rl_j; the root's parent is the identity)
         const int j = tid / 3, a = tid % 3, k = tid;
-        float dRl[9];
+        float dRl[9], Rb[9];
         batch_rodrigues_tangent(aa + 3 * j, a, dRl);
-        unsigned moved = 0u;
+        if (j == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Rb[q] = s_Gb[0][q];
+        } else mat3T_mul(s.G[body->parent[j]], s_Gb[j], Rb);
         float g = 0.0f;
-        for (int i = j; i < 24; ++i) {
-            const int p = body->parent[i];
-            float dG[9], dP[3];
-            if (i == j) {
-                if (j == 0) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) dG[q] = dRl[q];
-                } else mat3_mul(s.G[p], dRl, dG);
-                dP[0] = dP[1] = dP[2] = 0.0f;
-            } else if (moved & (1u << p)) {
-                float dGp[9], dPp[3];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) dGp[q] = s_dG[(p * 9 + q) * TAN_LD + k];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dPp[q] = s_dP[(p * 3 + q) * TAN_LD + k];
-                mat3_mul(dGp, s.Rl[i], dG);
-                mat3_vec(dGp, body->bone[i], dP);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dP[q] += dPp[q];
-            } else continue;
-            moved |= 1u << i;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s_dG[(i * 9 + q) * TAN_LD + k] = dG[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) s_dP[(i * 3 + q) * TAN_LD + k] = dP[q];
-            float gj[3];
-            mat3_vec(dG, body->jrest[i], gj);                         // dT = dP - dG * jrest   (model.py:235)
-#pragma unroll
-            for (int q = 0; q < 9; ++q) g += s_M[i][q] * dG[q];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) g += s_m[i][q] * (dP[q] - gj[q]) + s_o[i][q] * dP[q];
-        }
+        for (int q = 0; q < 9; ++q) g += Rb[q] * dRl[q];
         // priors act on the 69 non-root components
         if (k >= 3) {
             const int m = A.argmin[t], i = k - 3;
@@ -311,10 +334,24 @@ __global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, con
     }
 }
 
+__global__ __launch_bounds__(128) void rc_smplify_grad_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
+    smplify_grad_frame(A, body_g, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(128) void rc_smplify_grad_rows_kernel(const SmplifyArgs* __restrict__ rows, const BodyConst* __restrict__ body_g) {
+    const SmplifyArgs A = rows[blockIdx.y];
+    if ((int)blockIdx.x >= A.T) return;
+    smplify_grad_frame(A, body_g, (int)blockIdx.x);
+}
+
 void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t st) {
     if (A.T <= 0) return;
     hipLaunchKernelGGL(rc_smplify_fwd_kernel, dim3(A.T), dim3(64), 0, st, A, body);
     hipLaunchKernelGGL(rc_smplify_grad_kernel, dim3(A.T), dim3(128), 0, st, A, body);
+}
+void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t st) {
+    if (n_rows <= 0 || T_max <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_fwd_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body);
+    hipLaunchKernelGGL(rc_smplify_grad_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(128), 0, st, rows_dev, body);
 }
 
 // ================================================================= vector kernels of the device-resident L-BFGS
@@ -367,6 +404,65 @@ __global__ __launch_bounds__(256) void rc_vec_dots_kernel(const VecJob* __restri
         for (int w = 1; w < 4; ++w) r = jb.op == 1 ? fmax(r, s_red[w]) : r + s_red[w];
         partial[(long long)blockIdx.y * n_blocks + blockIdx.x] = r;
     }
+}
+
+// ---- the same operations for ALL rows of a lock-step round: one launch each, the row from blockIdx.y (descriptor tables in device memory)
+__global__ void rc_vec_ops_kernel(const VecOp* __restrict__ ops) {
+    const VecOp o = ops[blockIdx.y];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= o.n) return;
+    if (o.kind == 0) o.out[i] = o.a[i] + o.t * o.b[i];                   // axpy (out may be a)
+    else { o.out[i] = o.a[i] - o.b[i]; o.out2[i] = o.c[i] * o.t; }       // curvature pair: y = g_new - g_old, s = t d
+}
+__global__ void rc_vec_comb_rows_kernel(const VecCombRow* __restrict__ rows) {
+    const VecCombRow* r = rows + blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r->n) return;
+    const int nv = r->c.n_vec;
+    float acc = 0.0f;
+    for (int k = 0; k < nv; ++k) acc += r->c.c[k] * r->c.v[k][i];
+    r->out[i] = acc;
+}
+__global__ __launch_bounds__(256) void rc_vec_dots_rows_kernel(const VecJobN* __restrict__ jobs, int nb_max, double* __restrict__ partial) {
+    __shared__ double s_red[4];
+    const VecJobN jb = jobs[blockIdx.y];
+    const long long lo = (long long)blockIdx.x * 4096;
+    if (lo >= jb.n) return;                                              // (the host adds the first ceil(n / 4096) partials of a job)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int q = 0; q < 16; ++q) {
+        const long long i = lo + q * 256 + threadIdx.x;
+        if (i < jb.n) {
+            const double a = jb.a[i];
+            if (jb.op == 0) acc += a * (double)jb.b[i];
+            else if (jb.op == 1) acc = fmax(acc, fabs(a));
+            else acc += fabs(a);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(acc, off);
+        acc = jb.op == 1 ? fmax(acc, o) : acc + o;
+    }
+    if (lane == 0) s_red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = s_red[0];
+        for (int w = 1; w < 4; ++w) r = jb.op == 1 ? fmax(r, s_red[w]) : r + s_red[w];
+        partial[(long long)blockIdx.y * nb_max + blockIdx.x] = r;
+    }
+}
+void rc_launch_vec_ops(const VecOp* ops_dev, int n_ops, long long n_max, hipStream_t st) {
+    if (n_ops <= 0 || n_max <= 0) return;
+    hipLaunchKernelGGL(rc_vec_ops_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)n_ops), dim3(256), 0, st, ops_dev);
+}
+void rc_launch_vec_comb_rows(const VecCombRow* rows_dev, int n_rows, long long n_max, hipStream_t st) {
+    if (n_rows <= 0 || n_max <= 0) return;
+    hipLaunchKernelGGL(rc_vec_comb_rows_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)n_rows), dim3(256), 0, st, rows_dev);
+}
+void rc_launch_vec_dots_rows(const VecJobN* jobs_dev, int n_jobs, int nb_max, double* partial, hipStream_t st) {
+    if (n_jobs <= 0 || nb_max <= 0) return;
+    hipLaunchKernelGGL(rc_vec_dots_rows_kernel, dim3((unsigned)nb_max, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, nb_max, partial);
 }
 
 void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t st) {

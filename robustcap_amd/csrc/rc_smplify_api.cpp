@@ -11,6 +11,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -411,6 +414,399 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
     return RC_OK;
 }
 
+
+// ================================================================== lock-step batch of rows (rc_smplify_run_batch, round 4)
+// evaluate.py:86-90 refines the (sequence, camera) rows of an evaluation one after another; they are independent optimisation
+// problems. Round 3 drove them from host threads, one context and stream each: ~300 HIP calls per row contend for the runtime,
+// 72 rows of 600 frames took 0.19-0.23 s however many threads ran. Here every row's optimiser (the algorithm of
+// minimize_on_device, unchanged, on a host thread of its own) hands its next device request -- "evaluate the closure at x + t d
+// into gradient slot k", or "form the curvature pair and these inner products" -- to ONE executor; when every live row has asked,
+// the executor runs all requests with one launch per kind over all rows (descriptor tables in device memory, the row from
+// blockIdx.y), one read-back, one synchronisation, and wakes the rows. A round costs what its largest kernel costs; per row the
+// arithmetic is the same chain of operations as alone, so n_iter / n_eval / losses are those of the one-row-at-a-time run.
+struct RowBuf {                       // device vectors of one row (carved from the batch's arena)
+    int64_t T = 0;
+    size_t n = 0;                     // 75 T
+    int nb = 0;                       // 4,096-element blocks of a vector
+    float *x = nullptr, *xt = nullptr, *dir = nullptr, *gslot = nullptr, *Sv = nullptr, *Yv = nullptr;
+    float *ref3d = nullptr, *imu_aa = nullptr, *mj = nullptr, *proj = nullptr, *joint = nullptr, *res0 = nullptr, *res1 = nullptr, *Kd = nullptr;
+    float* terms = nullptr;           // [3 T] frame | imu | smooth, device (inside the terms arena)
+    const float* terms_h = nullptr;   // the same region of the pinned copy
+    int* argmin = nullptr;
+    float* h_res = nullptr;           // pinned [66 T]
+    float K[9];
+    const float* kp = nullptr;
+};
+
+struct RowReq {
+    int kind = 0;                     // 1: closure evaluation, 2: curvature pair + inner products, 3: pending update of x only
+    bool has_comb = false;            // dir = combination, in front of everything else (start of a line search)
+    VecComb comb{};
+    bool accept = false;              // x += accept_t * dir (the step the previous line search accepted)
+    float accept_t = 0.0f;
+    float t = 0.0f;                   // kind 1: evaluate at x + t * dir into gradient slot k
+    int k = 0;
+    const float *g_new = nullptr, *g_old = nullptr;   // kind 2: y = g_new - g_old -> yv, s = pair_t * dir -> sv
+    float *yv = nullptr, *sv = nullptr;
+    float pair_t = 0.0f;
+    std::vector<VecJobN> jobs;        // inner products wanted (kind 1: the slot's five, kind 2: the Gram entries)
+    int job0 = 0;                     // filled by the executor: first job of this row in the round's table
+};
+
+class RowBatch {
+  public:
+    rc_ctx* ctx = nullptr;
+    const BodyConst* body = nullptr;
+    SmplifyState* prior = nullptr;
+    hipStream_t st = nullptr;
+    unsigned long long ign = 0;
+    std::vector<RowBuf> row;
+    int T_max = 0, nb_max = 0, max_jobs = 0;
+    size_t n_max = 0;
+    // arenas
+    char* dev = nullptr; size_t dev_bytes = 0;
+    char* pin = nullptr; size_t pin_bytes = 0;
+    SmplifyArgs *args_d = nullptr, *args_h = nullptr;
+    VecOp *ops_d = nullptr, *ops_h = nullptr;
+    VecCombRow *comb_d = nullptr, *comb_h = nullptr;
+    VecJobN *jobs_d = nullptr, *jobs_h = nullptr;
+    double *part_d = nullptr, *part_h = nullptr;
+    float *terms_d = nullptr, *terms_h = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double device_ms = 0.0;
+    int rounds = 0;
+    // rendezvous
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<RowReq*> pending;
+    int n_live = 0, n_wait = 0;
+    unsigned long long gen = 0;
+    hipError_t herr = hipSuccess;
+
+    ~RowBatch() {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+    double job_sum(const RowReq& q, int j, int nb, bool is_max) const {
+        const double* p = part_h + (size_t)(q.job0 + j) * nb_max;
+        double r = p[0];
+        for (int b = 1; b < nb; ++b) r = is_max ? std::max(r, p[b]) : r + p[b];
+        return r;
+    }
+    // hand in the row's request and sleep until the round it belongs to has run; false = a HIP call failed
+    bool submit(int r, RowReq* q) {
+        std::unique_lock<std::mutex> lk(mu);
+        pending[r] = q;
+        ++n_wait;
+        if (n_wait == n_live) run_round();
+        else { const unsigned long long g = gen; cv.wait(lk, [&] { return gen != g; }); }
+        return herr == hipSuccess;
+    }
+    void leave(int r) {
+        std::unique_lock<std::mutex> lk(mu);
+        pending[r] = nullptr;
+        --n_live;
+        if (n_live > 0 && n_wait == n_live) run_round();
+    }
+
+  private:
+    void run_round() {                                                   // (mu held; every live row is waiting)
+        int n_args = 0, n_ops = 0, n_comb = 0, n_jobs = 0;
+        for (size_t r = 0; r < row.size(); ++r) {
+            RowReq* q = pending[r];
+            if (!q) continue;
+            const RowBuf& b = row[r];
+            if (q->has_comb) { comb_h[n_comb].c = q->comb; comb_h[n_comb].out = b.dir; comb_h[n_comb].n = (long long)b.n; ++n_comb; }
+            if (q->accept) ops_h[n_ops++] = VecOp{b.x, b.dir, nullptr, b.x, nullptr, q->accept_t, 0, (long long)b.n};
+            if (q->kind == 1) {
+                const float* xp = b.x;
+                if (q->t != 0.0f) { ops_h[n_ops++] = VecOp{b.x, b.dir, nullptr, b.xt, nullptr, q->t, 0, (long long)b.n}; xp = b.xt; }
+                SmplifyArgs A{};
+                A.aa = xp; A.tran = xp + b.T * 72;
+                A.kp = b.kp; A.ref3d = b.ref3d; A.imu_aa = b.imu_aa;
+                A.means = prior->means; A.prec = prior->prec; A.lognll = prior->lognll;
+                A.mj = b.mj; A.proj = b.proj;
+                A.frame_loss = b.terms; A.imu_loss = b.terms + b.T; A.smooth_loss = b.terms + 2 * b.T;
+                A.argmin = b.argmin;
+                float* g = b.gslot + (size_t)q->k * b.n;
+                A.grad_aa = g; A.grad_tran = g + b.T * 72;
+                for (int e = 0; e < 9; ++e) A.K[e] = b.K[e];
+                A.ign_mask = ign; A.T = (int)b.T;
+                args_h[n_args++] = A;
+            } else if (q->kind == 2) {
+                ops_h[n_ops++] = VecOp{q->g_new, q->g_old, b.dir, q->yv, q->sv, q->pair_t, 1, (long long)b.n};
+            }
+            q->job0 = n_jobs;
+            for (const VecJobN& j : q->jobs) jobs_h[n_jobs++] = j;
+        }
+        auto up = [&](void* d, const void* h, size_t bytes) {
+            if (bytes && herr == hipSuccess) herr = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st);
+        };
+        up(comb_d, comb_h, (size_t)n_comb * sizeof(VecCombRow));
+        up(ops_d, ops_h, (size_t)n_ops * sizeof(VecOp));
+        up(args_d, args_h, (size_t)n_args * sizeof(SmplifyArgs));
+        up(jobs_d, jobs_h, (size_t)n_jobs * sizeof(VecJobN));
+        // A row's accept / evaluation-point / pair operations read dir: the combination that WRITES dir goes first. Within the
+        // op table a row's accept (x += t d) stands in front of whatever reads x.
+        rc_launch_vec_comb_rows(comb_d, n_comb, (long long)n_max, st);
+        // two op launches: updates of x first (the evaluation point x + t d of the same request reads the new x)
+        {
+            int n_acc = 0;
+            for (int i = 0; i < n_ops; ++i) if (ops_h[i].kind == 0 && ops_h[i].out == ops_h[i].a) ++n_acc;
+            if (n_acc > 0 && n_acc < n_ops) {                            // partition: in-place updates | the rest (stable)
+                std::vector<VecOp> a, b;
+                for (int i = 0; i < n_ops; ++i) ((ops_h[i].kind == 0 && ops_h[i].out == ops_h[i].a) ? a : b).push_back(ops_h[i]);
+                std::copy(a.begin(), a.end(), ops_h);
+                std::copy(b.begin(), b.end(), ops_h + a.size());
+                up(ops_d, ops_h, (size_t)n_ops * sizeof(VecOp));
+                rc_launch_vec_ops(ops_d, n_acc, (long long)n_max, st);
+                rc_launch_vec_ops(ops_d + n_acc, n_ops - n_acc, (long long)n_max, st);
+            } else rc_launch_vec_ops(ops_d, n_ops, (long long)n_max, st);
+        }
+        if (n_args > 0) {
+            if (herr == hipSuccess) herr = hipEventRecord(ev0, st);
+            rc_launch_smplify_rows(args_d, n_args, T_max, body, st);
+            if (herr == hipSuccess) herr = hipEventRecord(ev1, st);
+        }
+        rc_launch_vec_dots_rows(jobs_d, n_jobs, nb_max, part_d, st);
+        if (n_jobs > 0 && herr == hipSuccess)
+            herr = hipMemcpyAsync(part_h, part_d, (size_t)n_jobs * nb_max * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (n_args > 0 && herr == hipSuccess)
+            herr = hipMemcpyAsync(terms_h, terms_d, row.size() * (size_t)3 * T_max * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess) herr = hipStreamSynchronize(st);
+        if (herr == hipSuccess) herr = hipGetLastError();
+        if (n_args > 0 && herr == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
+        }
+        ++rounds;
+        n_wait = 0;
+        ++gen;
+        cv.notify_all();
+    }
+};
+
+// minimize_on_device for row r of a batch: the same algorithm, the device work requested from the batch's executor
+void lbfgs_row(RowBatch& B, const int r, const float lr, const int max_iter, DevResult& res, bool& ok) {
+    ok = false;
+    struct Leave { RowBatch& B; int r; ~Leave() { B.leave(r); } } on_exit{B, r};
+    const RowBuf& b = B.row[r];
+    const size_t n = b.n;
+    const int nb = b.nb;
+    const int M = std::max(1, std::min(std::min(max_iter, RC_LBFGS_MAX_PAIRS), lbfgs_history_env()));
+    const int P = M + 1;
+    const int max_eval = max_iter * 5 / 4;
+    const float tolerance_grad = 1e-7f, tolerance_change = 1e-9f;
+    auto slot = [&](int k) { return b.gslot + (size_t)k * n; };
+    // per evaluation five inner products: g.d, max |g|, sum |g|, max |d|, g.g
+    struct Eval { float f, gtd, gmax, gsum, dmax, gg; };
+    float slot_gmax[kSlots] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};           // |g|_inf of the last evaluation into each gradient slot
+    RowReq q;
+    bool have_comb = false, have_accept = false;
+    VecComb comb{};
+    float accept_t = 0.0f;
+    auto attach = [&]() {
+        q.has_comb = have_comb; if (have_comb) q.comb = comb;
+        q.accept = have_accept; q.accept_t = accept_t;
+        have_comb = false; have_accept = false;
+    };
+    auto eval = [&](float t, int k, Eval& e) -> bool {
+        q.kind = 1; q.t = t; q.k = k;
+        attach();
+        q.jobs.clear();
+        q.jobs.push_back(VecJobN{slot(k), b.dir, 0, 0, (long long)n});
+        q.jobs.push_back(VecJobN{slot(k), nullptr, 1, 0, (long long)n});
+        q.jobs.push_back(VecJobN{slot(k), nullptr, 2, 0, (long long)n});
+        q.jobs.push_back(VecJobN{b.dir, nullptr, 1, 0, (long long)n});
+        q.jobs.push_back(VecJobN{slot(k), slot(k), 0, 0, (long long)n});
+        if (!B.submit(r, &q)) return false;
+        e.f = (float)total_loss(b.terms_h, b.T);
+        e.gtd = (float)B.job_sum(q, 0, nb, false);
+        e.gmax = (float)B.job_sum(q, 1, nb, true);
+        e.gsum = (float)B.job_sum(q, 2, nb, false);
+        e.dmax = (float)B.job_sum(q, 3, nb, true);
+        e.gg = (float)B.job_sum(q, 4, nb, false);
+        slot_gmax[k] = e.gmax;
+        return true;
+    };
+
+    int base = 0;
+    Eval e0;
+    if (!eval(0.0f, base, e0)) return;
+    float loss = e0.f, gmax = e0.gmax, gsum = e0.gsum, gg0 = e0.gg;
+    res.first_loss = res.loss = loss;
+    int evals = 1;
+    ok = true;
+    if (gmax <= tolerance_grad) { res.n_eval = evals; return; }
+
+    const int NB = 2 * P + 1, IG = 2 * P;
+    std::vector<double> G((size_t)NB * NB, 0.0), ro(P, 0.0), al(P, 0.0), delta(NB, 0.0);
+    auto Gat = [&](int a, int c) -> double& { return G[(size_t)a * NB + c]; };
+    std::vector<int> order;
+    int spare = 0;
+    double H_diag = 1.0;
+    float t = 0.0f, prev_loss = loss, gtd = 0.0f, d_max = 0.0f;
+    int prev_base = base;
+    int n_iter = 0;
+    cubic_fn cubic = rc::Lbfgs<float>::cubic;
+    ok = false;
+    while (n_iter < max_iter) {
+        ++n_iter;
+        if (n_iter == 1) {
+            comb = VecComb{};
+            comb.n_vec = 1; comb.v[0] = slot(base); comb.c[0] = -1.0f;     // d = -g
+            gtd = -gg0;                                                     // g.d of d = -g
+        } else {
+            const int c = spare;
+            struct Want { int a, b; };
+            std::vector<Want> want;
+            std::vector<int> with_c(order);
+            with_c.push_back(c);
+            for (int j : with_c) { want.push_back({c, j}); want.push_back({c, P + j}); want.push_back({P + c, P + j}); }
+            for (int j : order) want.push_back({P + c, j});
+            for (int j : with_c) { want.push_back({IG, j}); want.push_back({IG, P + j}); }
+            want.push_back({IG, IG});
+            auto vec_of = [&](int idx) -> const float* {
+                return idx == IG ? slot(base) : (idx >= P ? b.Yv + (size_t)(idx - P) * n : b.Sv + (size_t)idx * n);
+            };
+            q.kind = 2;
+            attach();
+            q.g_new = slot(base); q.g_old = slot(prev_base); q.pair_t = t;
+            q.yv = b.Yv + (size_t)c * n; q.sv = b.Sv + (size_t)c * n;
+            q.jobs.clear();
+            for (const Want& w : want) q.jobs.push_back(VecJobN{vec_of(w.a), vec_of(w.b), 0, 0, (long long)n});
+            if (!B.submit(r, &q)) return;
+            for (size_t i = 0; i < want.size(); ++i) {
+                const double v = B.job_sum(q, (int)i, nb, false);
+                Gat(want[i].a, want[i].b) = v; Gat(want[i].b, want[i].a) = v;
+            }
+            {
+                const double ys = Gat(c, P + c);
+                if ((float)ys > 1e-10f) {
+                    H_diag = ys / Gat(P + c, P + c);
+                    ro[c] = 1.0 / ys;
+                    if ((int)order.size() == M) { spare = order.front(); order.erase(order.begin()); order.push_back(c); }
+                    else { order.push_back(c); spare = (int)order.size(); }
+                }
+            }
+            const int m = (int)order.size();
+            std::fill(delta.begin(), delta.end(), 0.0);
+            delta[IG] = -1.0;
+            auto dot_q = [&](int idx) {
+                double rr = delta[IG] * Gat(IG, idx);
+                for (int j : order) rr += delta[j] * Gat(j, idx) + delta[P + j] * Gat(P + j, idx);
+                return rr;
+            };
+            for (int i = m - 1; i >= 0; --i) { const int j = order[i]; al[j] = dot_q(j) * ro[j]; delta[P + j] -= al[j]; }
+            for (double& v : delta) v *= H_diag;
+            for (int i = 0; i < m; ++i) { const int j = order[i]; const double be = dot_q(P + j) * ro[j]; delta[j] += al[j] - be; }
+            comb = VecComb{};
+            comb.n_vec = 0;
+            for (int j : order) {
+                comb.v[comb.n_vec] = b.Sv + (size_t)j * n; comb.c[comb.n_vec++] = (float)delta[j];
+                comb.v[comb.n_vec] = b.Yv + (size_t)j * n; comb.c[comb.n_vec++] = (float)delta[P + j];
+            }
+            comb.v[comb.n_vec] = slot(base); comb.c[comb.n_vec++] = (float)delta[IG];
+            gtd = (float)dot_q(IG);
+        }
+        have_comb = true;                                                 // formed in front of the line search's first evaluation
+        prev_base = base;
+        prev_loss = loss;
+        t = n_iter == 1 ? std::min(1.0f, 1.0f / gsum) * lr : lr;
+        if (gtd > -tolerance_change) break;
+
+        // ---- strong-Wolfe line search (rc_lbfgs.h: strong_wolfe) on gradient slots: the code of minimize_on_device
+        struct Pt { float t, f, gtd; int k; };
+        const int max_ls = max_eval - evals;
+        auto free_slot = [&](std::initializer_list<int> live) {
+            for (int k = 0; k < kSlots; ++k) { bool used = false; for (int v : live) used = used || v == k; if (!used) return k; }
+            return -1;
+        };
+        const float c1 = 1e-4f, c2 = 0.9f;
+        Pt cur{t, 0, 0, free_slot({base})};
+        Eval ev;
+        if (!eval(cur.t, cur.k, ev)) return;
+        int ls_evals = 1;
+        cur.f = ev.f; cur.gtd = ev.gtd; d_max = ev.dmax;
+        Pt prev{0, loss, gtd, base};
+        Pt br[2] = {prev, prev};
+        int n_br = 0, ls_iter = 0;
+        bool done = false;
+        while (ls_iter < max_ls) {
+            if (cur.f > (loss + c1 * cur.t * gtd) || (ls_iter > 1 && cur.f >= prev.f)) { br[0] = prev; br[1] = cur; n_br = 2; break; }
+            if (std::fabs(cur.gtd) <= -c2 * gtd) { br[0] = cur; n_br = 1; done = true; break; }
+            if (cur.gtd >= 0) { br[0] = prev; br[1] = cur; n_br = 2; break; }
+            const float min_step = cur.t + 0.01f * (cur.t - prev.t), max_step = cur.t * 10;
+            const float tn = cubic(prev.t, prev.f, prev.gtd, cur.t, cur.f, cur.gtd, true, min_step, max_step);
+            prev = cur;
+            cur.t = tn;
+            cur.k = free_slot({base, prev.k});
+            if (!eval(tn, cur.k, ev)) return;
+            cur.f = ev.f; cur.gtd = ev.gtd;
+            ++ls_evals;
+            ++ls_iter;
+        }
+        if (ls_iter == max_ls) { br[0] = Pt{0, loss, gtd, base}; br[1] = cur; n_br = 2; }
+        bool insuf = false;
+        int lo = 0, hi = 1;
+        if (n_br == 2 && !(br[0].f <= br[1].f)) { lo = 1; hi = 0; }
+        while (!done && ls_iter < max_ls) {
+            if (std::fabs(br[1].t - br[0].t) * d_max < tolerance_change) break;
+            float tn = cubic(br[0].t, br[0].f, br[0].gtd, br[1].t, br[1].f, br[1].gtd, false, 0, 0);
+            const float bmax = std::max(br[0].t, br[1].t), bmin = std::min(br[0].t, br[1].t);
+            const float eps = 0.1f * (bmax - bmin);
+            if (std::min(bmax - tn, tn - bmin) < eps) {
+                if (insuf || tn >= bmax || tn <= bmin) {
+                    tn = (std::fabs(tn - bmax) < std::fabs(tn - bmin)) ? bmax - eps : bmin + eps;
+                    insuf = false;
+                } else insuf = true;
+            } else insuf = false;
+            cur.t = tn;
+            cur.k = free_slot({base, br[0].k, br[1].k});
+            if (!eval(tn, cur.k, ev)) return;
+            cur.f = ev.f; cur.gtd = ev.gtd;
+            ++ls_evals;
+            ++ls_iter;
+            if (cur.f > (loss + c1 * tn * gtd) || cur.f >= br[lo].f) {
+                br[hi] = cur;
+                if (br[0].f <= br[1].f) { lo = 0; hi = 1; } else { lo = 1; hi = 0; }
+            } else {
+                if (std::fabs(cur.gtd) <= -c2 * gtd) done = true;
+                else if (cur.gtd * (br[hi].t - br[lo].t) >= 0) br[hi] = br[lo];
+                br[lo] = cur;
+            }
+        }
+        if (n_br == 1) lo = 0;
+        t = br[lo].t;
+        loss = br[lo].f;
+        const int new_base = br[lo].k;
+        have_accept = true; accept_t = t;                                 // x += t d: with the next request (or the final flush)
+        // |g|_inf of the accepted point: from the evaluation that produced it (kept per slot)
+        base = new_base;
+        gmax = base == prev_base ? gmax : slot_gmax[base];
+        const bool opt_cond = gmax <= tolerance_grad;
+        evals += ls_evals;
+        if (n_iter == max_iter) break;
+        if (evals >= max_eval) break;
+        if (opt_cond) break;
+        if (d_max * std::fabs(t) <= tolerance_change) break;
+        if (std::fabs(loss - prev_loss) < tolerance_change) break;
+    }
+    if (have_accept) {                                                    // the last accepted step
+        q.kind = 3;
+        have_comb = false;
+        attach();
+        q.jobs.clear();
+        if (!B.submit(r, &q)) return;
+    }
+    res.n_iter = n_iter;
+    res.n_eval = evals;
+    res.loss = loss;
+    ok = true;
+}
+
 }  // namespace
 
 void rc_smplify_free(SmplifyState* s) {
@@ -596,6 +992,161 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
     info->final_loss = r.loss;
     info->device_ms = s->device_ms;
     info->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return RC_OK;
+}
+
+int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, const float* const* pose, const float* const* tran,
+                         const float* const* kp, const float* const* imu_ori, const float* K_host, float lr, int32_t max_iter,
+                         float loss_threshold, float* const* pose_out, float* const* tran_out, uint8_t* const* update_host,
+                         rc_smplify_info* infos, void* stream) {
+    if (!ctx) return RC_ERR_INVALID;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const BodyConst* body = rc_ctx_body(ctx);
+    if (!body) return rc_ctx_fail(ctx, RC_ERR_STATE, "rc_smplify_run_batch: body not set");
+    SmplifyState* s0 = nullptr;
+    if (int rc = state_of(ctx, &s0)) return rc;
+    if (!s0->have_prior) return rc_ctx_fail(ctx, RC_ERR_STATE, "rc_smplify_run_batch: prior not set (rc_smplify_set_prior)");
+    if (n_rows < 0 || max_iter < 1 || !(lr >= 0.0f)) return rc_ctx_fail(ctx, RC_ERR_INVALID, "rc_smplify_run_batch: bad arguments");
+    if (n_rows == 0) return RC_OK;
+    if (!T_rows || !pose || !tran || !kp || !imu_ori || !K_host || !pose_out || !tran_out || !update_host || !infos)
+        return rc_ctx_fail(ctx, RC_ERR_INVALID, "rc_smplify_run_batch: null buffer");
+    for (int r = 0; r < n_rows; ++r)
+        if (T_rows[r] <= 0 || T_rows[r] > 0x7fffffff / 99 || !pose[r] || !tran[r] || !kp[r] || !imu_ori[r] || !pose_out[r] || !tran_out[r] || !update_host[r])
+            return rc_ctx_fail(ctx, RC_ERR_INVALID, "rc_smplify_run_batch: bad row");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = std::max(1, std::min(std::min((int)max_iter, RC_LBFGS_MAX_PAIRS), lbfgs_history_env()));
+    const int P = M + 1;
+
+    RowBatch B;
+    B.ctx = ctx; B.body = body; B.prior = s0; B.st = st; B.ign = rc_ctx_ign_mask(ctx);
+    B.row.resize((size_t)n_rows);
+    B.pending.assign((size_t)n_rows, nullptr);
+    B.max_jobs = 6 * P + 8;
+    for (int r = 0; r < n_rows; ++r) {
+        RowBuf& b = B.row[r];
+        b.T = T_rows[r]; b.n = (size_t)b.T * 75; b.nb = (int)((b.n + 4095) / 4096);
+        for (int e = 0; e < 9; ++e) b.K[e] = K_host[9 * r + e];
+        b.kp = kp[r];
+        B.T_max = std::max(B.T_max, (int)b.T);
+        B.n_max = std::max(B.n_max, b.n);
+        B.nb_max = std::max(B.nb_max, b.nb);
+    }
+    // ---- two arenas (device, pinned), carved: two allocations for the whole batch
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t dev_need = 0, pin_need = 0;
+    auto dtake = [&](size_t bytes) { const size_t o = dev_need; dev_need += al(bytes); return o; };
+    auto ptake = [&](size_t bytes) { const size_t o = pin_need; pin_need += al(bytes); return o; };
+    struct Off { size_t x, xt, dir, gs, Sv, Yv, ref, imu, mj, proj, joint, r0, r1, Kd, am, hres; };
+    std::vector<Off> off((size_t)n_rows);
+    for (int r = 0; r < n_rows; ++r) {
+        const size_t n = B.row[r].n, T = (size_t)B.row[r].T;
+        Off& o = off[r];
+        o.x = dtake(n * 4); o.xt = dtake(n * 4); o.dir = dtake(n * 4); o.gs = dtake(kSlots * n * 4);
+        o.Sv = dtake((size_t)P * n * 4); o.Yv = dtake((size_t)P * n * 4);
+        o.ref = dtake(T * 99 * 4); o.imu = dtake(T * 18 * 4); o.mj = dtake(T * 99 * 4); o.proj = dtake(T * 66 * 4); o.joint = dtake(T * 72 * 4);
+        o.r0 = dtake(T * 33 * 4); o.r1 = dtake(T * 33 * 4); o.Kd = dtake(64); o.am = dtake(T * 4);
+        o.hres = ptake(T * 66 * 4);
+    }
+    const size_t nr = (size_t)n_rows;
+    const size_t o_args = dtake(nr * sizeof(SmplifyArgs)), o_ops = dtake(3 * nr * sizeof(VecOp)), o_comb = dtake(nr * sizeof(VecCombRow));
+    const size_t o_jobs = dtake(nr * B.max_jobs * sizeof(VecJobN)), o_part = dtake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
+    const size_t o_terms = dtake(nr * 3 * (size_t)B.T_max * 4);
+    const size_t p_args = ptake(nr * sizeof(SmplifyArgs)), p_ops = ptake(3 * nr * sizeof(VecOp)), p_comb = ptake(nr * sizeof(VecCombRow));
+    const size_t p_jobs = ptake(nr * B.max_jobs * sizeof(VecJobN)), p_part = ptake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
+    const size_t p_terms = ptake(nr * 3 * (size_t)B.T_max * 4);
+    SM_TRY(ctx, hipMalloc((void**)&B.dev, dev_need));
+    SM_TRY(ctx, hipHostMalloc((void**)&B.pin, pin_need, hipHostMallocDefault));
+    B.dev_bytes = dev_need; B.pin_bytes = pin_need;
+    SM_TRY(ctx, hipEventCreate(&B.ev0));
+    SM_TRY(ctx, hipEventCreate(&B.ev1));
+    B.args_d = (SmplifyArgs*)(B.dev + o_args); B.ops_d = (VecOp*)(B.dev + o_ops); B.comb_d = (VecCombRow*)(B.dev + o_comb);
+    B.jobs_d = (VecJobN*)(B.dev + o_jobs); B.part_d = (double*)(B.dev + o_part); B.terms_d = (float*)(B.dev + o_terms);
+    B.args_h = (SmplifyArgs*)(B.pin + p_args); B.ops_h = (VecOp*)(B.pin + p_ops); B.comb_h = (VecCombRow*)(B.pin + p_comb);
+    B.jobs_h = (VecJobN*)(B.pin + p_jobs); B.part_h = (double*)(B.pin + p_part); B.terms_h = (float*)(B.pin + p_terms);
+    for (int r = 0; r < n_rows; ++r) {
+        RowBuf& b = B.row[r];
+        const Off& o = off[r];
+        auto f = [&](size_t q) { return (float*)(B.dev + q); };
+        b.x = f(o.x); b.xt = f(o.xt); b.dir = f(o.dir); b.gslot = f(o.gs); b.Sv = f(o.Sv); b.Yv = f(o.Yv);
+        b.ref3d = f(o.ref); b.imu_aa = f(o.imu); b.mj = f(o.mj); b.proj = f(o.proj); b.joint = f(o.joint); b.res0 = f(o.r0); b.res1 = f(o.r1);
+        b.Kd = f(o.Kd); b.argmin = (int*)(B.dev + o.am);
+        b.h_res = (float*)(B.pin + o.hres);
+        b.terms = B.terms_d + (size_t)r * 3 * B.T_max;
+        b.terms_h = B.terms_h + (size_t)r * 3 * B.T_max;
+    }
+    // ---- pre-check of every row (run.py:24-29): mean residual of its FIRST frame against the threshold
+    for (int r = 0; r < n_rows; ++r) {
+        RowBuf& b = B.row[r];
+        std::memset(&infos[r], 0, sizeof(infos[r]));
+        std::memset(update_host[r], 0, (size_t)b.T);
+        SM_TRY(ctx, hipMemcpyAsync(b.Kd, b.K, 9 * sizeof(float), hipMemcpyHostToDevice, st));
+        rc_launch_residual(body, pose[r], tran[r], kp[r], b.Kd, 100.0f, B.ign, b.res0, b.T, st);
+        SM_TRY(ctx, hipMemcpyAsync(b.h_res, b.res0, (size_t)b.T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    SM_TRY(ctx, hipStreamSynchronize(st));
+    auto frame_mean = [](const float* v) {
+        float acc = 0.0f;
+        for (int q = 0; q < 33; ++q) acc += v[q];
+        return acc / 33.0f;
+    };
+    std::vector<int> live;
+    for (int r = 0; r < n_rows; ++r) {
+        RowBuf& b = B.row[r];
+        if (frame_mean(b.h_res) > loss_threshold) {
+            if (pose_out[r] != pose[r]) SM_TRY(ctx, hipMemcpyAsync(pose_out[r], pose[r], (size_t)b.T * 216 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (tran_out[r] != tran[r]) SM_TRY(ctx, hipMemcpyAsync(tran_out[r], tran[r], (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            infos[r].status = 0;
+            continue;
+        }
+        live.push_back(r);
+        rc_launch_R2aa(pose[r], b.x, b.T * 24, st);                       // temporal_smplify.py:111-139
+        SM_TRY(ctx, hipMemcpyAsync(b.x + b.T * 72, tran[r], (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc_launch_R2aa(imu_ori[r], b.imu_aa, b.T * 6, st);
+        rc_launch_body_fk(body, pose[r], tran[r], nullptr, b.joint, b.ref3d, b.T, st);
+    }
+    SM_TRY(ctx, hipStreamSynchronize(st));
+    SM_TRY(ctx, hipGetLastError());
+    // ---- the optimisers: a host thread per row, the device work in lock-step rounds
+    std::vector<DevResult> res((size_t)n_rows);
+    std::vector<char> ok((size_t)n_rows, 0);
+    B.n_live = (int)live.size();
+    if (live.size() == 1) {
+        bool k = false;
+        lbfgs_row(B, live[0], lr, max_iter, res[live[0]], k);
+        ok[live[0]] = k;
+    } else if (!live.empty()) {
+        std::vector<std::thread> th;
+        th.reserve(live.size());
+        for (int r : live) th.emplace_back([&, r] { bool k = false; lbfgs_row(B, r, lr, max_iter, res[r], k); ok[r] = k; });
+        for (std::thread& t : th) t.join();
+    }
+    if (B.herr != hipSuccess) return rc_ctx_fail(ctx, RC_ERR_HIP, (std::string("smplify batch: ") + hipGetErrorString(B.herr)).c_str());
+    for (int r : live) if (!ok[r]) return rc_ctx_fail(ctx, RC_ERR_HIP, "smplify batch: a row's optimiser did not finish");
+    // ---- results: rotations, residual after, per-frame update mask (run.py:31-34)
+    for (int r : live) {
+        RowBuf& b = B.row[r];
+        rc_launch_aa2R(b.x, pose_out[r], b.T * 24, st);
+        SM_TRY(ctx, hipMemcpyAsync(tran_out[r], b.x + b.T * 72, (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc_launch_residual(body, pose_out[r], tran_out[r], kp[r], b.Kd, 100.0f, B.ign, b.res1, b.T, st);
+        SM_TRY(ctx, hipMemcpyAsync(b.h_res + b.T * 33, b.res1, (size_t)b.T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    SM_TRY(ctx, hipStreamSynchronize(st));
+    SM_TRY(ctx, hipGetLastError());
+    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int r = 0; r < n_rows; ++r) {
+        infos[r].host_ms = host_ms;                                       // of the whole batch
+        infos[r].device_ms = B.device_ms;
+    }
+    for (int r : live) {
+        RowBuf& b = B.row[r];
+        for (int64_t t = 0; t < b.T; ++t) update_host[r][t] = frame_mean(b.h_res + (b.T + t) * 33) < frame_mean(b.h_res + t * 33) ? 1 : 0;
+        infos[r].status = 1;
+        infos[r].n_iter = res[r].n_iter;
+        infos[r].n_eval = res[r].n_eval;
+        infos[r].first_loss = res[r].first_loss;
+        infos[r].final_loss = res[r].loss;
+        infos[r].reserved = B.rounds;
+    }
     return RC_OK;
 }
 

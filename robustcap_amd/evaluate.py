@@ -12,6 +12,7 @@
                     SMPL joints and global joint-angle error. The reference's H36M-14 MPJPE / PVE / PA-MPJPE need
                     the full 6890-vertex mesh and ``J_regressor_h36m.npy`` (absent): SURVEY.md section 8(f) rank 2.
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -191,16 +192,35 @@ def shard_rows(all_rows, Tmax, compute, device="cuda"):
 
 
 def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, workers):
-    """smplify over the rows of this rank (evaluate.py:86-90), ``workers`` rows in flight: each host thread owns a
-    TemporalSMPLify context and a HIP stream; the C call releases the GIL, so the threads' line searches interleave."""
-    import threading
+    """smplify over the rows of this rank (evaluate.py:86-90 loops them one after another): ONE batched call -- every row's
+    optimiser advances in lock-step rounds on the device (TemporalSMPLify.run_batch / rc_smplify_run_batch). ``workers`` = 0
+    selects round 3's scheme instead (that many host threads, a context and a stream each; RC_SMPLIFY_WORKERS overrides)."""
     from .smplify import TemporalSMPLify
     torch.cuda.synchronize()
-    workers = max(1, min(int(workers), len(mine)))
+    scale = torch.tensor([float(image_size[0]), float(image_size[1]), 1.0])
+    threads = int(os.environ.get("RC_SMPLIFY_WORKERS", "0"))                  # > 0: the thread-per-row scheme (A/B runs)
+    if threads <= 0:
+        runner = TemporalSMPLify(body=body, gmm=gmm, device=device)
+        if not runner.has_prior:
+            raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")
+        rows = []
+        for r, (i, j) in enumerate(mine):
+            T = len(dataset["pose"][i])
+            kp_pix = torch.as_tensor(dataset["joint2d_mp"][i][j], dtype=torch.float32) * scale      # evaluate.py:43-44 -> :87
+            rows.append((out_p[r, :T], out_t[r, :T], kp_pix, ori[r, :T], dataset["cam_K"][i][j]))
+        res = runner.run_batch(rows, lr=0.001)
+        for r, (i, j) in enumerate(mine):
+            T = len(dataset["pose"][i])
+            out_p[r, :T], out_t[r, :T] = res[r][0], res[r][1]
+            if smplify_info is not None:
+                smplify_info[(i, j)] = dict(runner.last_batch_info[r])
+        torch.cuda.synchronize()
+        return
+    import threading
+    workers = max(1, min(threads, len(mine)))
     runners = [TemporalSMPLify(body=body, gmm=gmm, device=device) for _ in range(workers)]
     if not runners[0].has_prior:
         raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")
-    scale = torch.tensor([float(image_size[0]), float(image_size[1]), 1.0])
     errors = []
 
     def work(w):
@@ -218,10 +238,10 @@ def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device
         except Exception as e:  # noqa: BLE001 - re-raised on the calling thread
             errors.append(e)
 
-    threads = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
-    for th in threads:
+    ths = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for th in ths:
         th.start()
-    for th in threads:
+    for th in ths:
         th.join()
     if errors:
         raise errors[0]

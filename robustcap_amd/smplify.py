@@ -126,6 +126,33 @@ class TemporalSMPLify:
         return pose_out, tran_out, (torch.from_numpy(update.astype(bool)) if info.status == 1 else None)
 
 
+    def run_batch(self, rows, lr=1.0, max_iter=20, loss_threshold=20000):
+        """The same as ``run`` for a list of independent rows ``(pose, tran, keypoints_2d, imu_ori, cam_k)`` at once
+        (evaluate.py:86-90 loops them): the rows' optimisers advance in lock-step rounds on the device, one launch per kind of
+        operation over all rows (rc_smplify_run_batch). Returns a list of (pose, tran, update | None) and fills
+        ``last_batch_info`` (one dict per row). Mean shape only (``set_shape`` rows go through ``run``)."""
+        if self._shaped:
+            raise NotImplementedError("run_batch: rows with shape=... go through run() one at a time")
+        dev = self.device
+        n = len(rows)
+        prep, Ks = [], np.empty((n, 9), np.float32)
+        for r, (pose, tran, kp, ori, cam_k) in enumerate(rows):
+            pose = _body._f32c(pose, dev).view(-1, 24, 3, 3)
+            T = pose.shape[0]
+            prep.append((pose, _body._f32c(tran, dev).view(T, 3), _body._f32c(kp, dev).view(T, 33, 3), _body._f32c(ori, dev).view(T, 6, 3, 3),
+                         torch.empty_like(pose), torch.empty(T, 3, device=dev), np.zeros(T, dtype=np.uint8)))
+            Ks[r] = np.asarray(torch.as_tensor(cam_k).detach().cpu().numpy(), np.float32).reshape(9)
+        Tn = (C.c_int64 * n)(*[p[0].shape[0] for p in prep])
+        arr = lambda k: (C.c_void_p * n)(*[p[k].data_ptr() for p in prep])
+        upd = (C.c_void_p * n)(*[p[6].ctypes.data for p in prep])
+        infos = (_lib.RcSmplifyInfo * n)()
+        rc = self._lib.rc_smplify_run_batch(self._ctx, n, Tn, arr(0), arr(1), arr(2), arr(3), Ks.ctypes.data_as(C.c_void_p), C.c_float(lr),
+                                            int(max_iter), C.c_float(loss_threshold), arr(4), arr(5), upd, infos, _lib.stream_ptr())
+        _lib.check(self._ctx, rc, "rc_smplify_run_batch")
+        self.last_batch_info = [{("rounds" if k == "reserved" else k): getattr(infos[r], k) for k, _ in infos[r]._fields_} for r in range(n)]
+        return [(p[4], p[5], torch.from_numpy(p[6].astype(bool)) if infos[r].status == 1 else None) for r, p in enumerate(prep)]
+
+
 ResidualRunner = TemporalSMPLify        # earlier name of the residual-only object
 
 

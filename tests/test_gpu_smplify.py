@@ -3,6 +3,7 @@
 tests/golden/smplify.npz holds, from the reference itself (oracle/capture_smplify.py): loss and gradient of the
 closure at one point (ev_*) and one full smplify_runner call (run_*)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -188,6 +189,40 @@ def test_lbfgs_history_slides_like_torch(g, runner, monkeypatch):
     runner.run(*args[:4], args[5], lr=0.001, max_iter=130)
     long_run = dict(runner.last_info)
     assert long_run["status"] == 1 and long_run["final_loss"] <= out["100", "0"]["final_loss"] * 1.05
+
+
+def test_batched_rows_equal_one_row_at_a_time(runner, synth_assets):
+    """rc_smplify_run_batch: the rows of an evaluation (evaluate.py:86-90) optimised in lock-step rounds on the device -- per row
+    the same iterations, evaluations, losses and outputs as rc_smplify_run on that row alone; ragged lengths, different cameras,
+    and a row the pre-check rejects (run.py:27-29) is copied through."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import smplify_bench as sb
+    body = synth_assets["body"]
+    rows = []
+    for seed, T in ((11, 64), (23, 100), (31, 37), (47, 64), (53, 80)):
+        pose0, tran0, kp, ori, K = sb.make_case(runner, body, T, seed=seed)
+        K = K.clone()
+        K[0, 0] += seed                                                   # a camera of its own per row
+        rows.append((pose0, tran0, kp, ori, K))
+    bad = list(rows[2])
+    bad[2] = bad[2].clone()
+    bad[2][..., :2] += 5.0e4                                              # keypoints far off: the robust residual saturates near 16,000 per landmark
+    rows.append(tuple(bad))
+    single = []
+    for r in rows:
+        p, tr, upd = runner.run(*r, lr=0.001, loss_threshold=1000.0)
+        single.append((p.clone(), tr.clone(), None if upd is None else upd.clone(), dict(runner.last_info)))
+    out = runner.run_batch(rows, lr=0.001, loss_threshold=1000.0)
+    info = runner.last_batch_info
+    assert single[-1][2] is None and out[-1][2] is None and info[-1]["status"] == 0
+    assert torch.equal(out[-1][0], rows[-1][0].to(out[-1][0].device)) and torch.equal(out[-1][1], rows[-1][1].to(out[-1][1].device))
+    for r in range(len(rows) - 1):
+        a, b = single[r][3], info[r]
+        assert b["status"] == 1 and (a["n_iter"], a["n_eval"]) == (b["n_iter"], b["n_eval"]), (r, a, b)
+        assert a["first_loss"] == b["first_loss"] and abs(a["final_loss"] - b["final_loss"]) <= 1e-6 * abs(a["final_loss"]), (r, a, b)
+        assert float((single[r][0] - out[r][0]).abs().max()) <= 1e-6 and float((single[r][1] - out[r][1]).abs().max()) <= 1e-6
+        assert torch.equal(single[r][2], out[r][2])
+    assert 20 <= info[0]["rounds"] <= 60                                   # lock-step: rounds of the longest row, not their sum
 
 
 def test_runner_gate_and_errors(g, runner, synth_assets):

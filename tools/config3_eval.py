@@ -42,7 +42,12 @@ def main():
         out[key] = {"seconds": round(dt, 3), "body_frames_per_s": round(rows * T / dt, 1)}
         if smp and info:
             out[key]["smplify_rows_optimised"] = int(sum(1 for v in info.values() if v["status"] == 1))
-            out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
+            v0 = next(iter(info.values()))
+            if "rounds" in v0:      # one lock-step batch over all rows (rc_smplify_run_batch): host_ms / device_ms are the batch's
+                out[key]["smplify_batch"] = {"call_ms": round(v0["host_ms"], 2), "closure_kernels_ms": round(v0["device_ms"], 2), "rounds": v0["rounds"],
+                                             "n_eval_min_max": [min(v["n_eval"] for v in info.values()), max(v["n_eval"] for v in info.values())]}
+            else:
+                out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
     if rank == 0 and world == 1:     # where the net-only time goes: the harness's three steps timed one by one
         mine = ev.rows_of(ds)
         net = nets[rows][0]
