@@ -38,6 +38,9 @@ struct SmplifyState {
     VecJob *jobs_d = nullptr, *jobs_h = nullptr;                      // device / pinned
     double *part_d = nullptr, *part_h = nullptr;
     const float* ref3d_override = nullptr;                            // rc_smplify_set_ref3d: caller-owned [T,33,3], next run only
+    // arenas of rc_smplify_run_batch (grow-only: a second evaluation of the same size allocates nothing)
+    char *batch_dev = nullptr, *batch_pin = nullptr;
+    size_t batch_dev_cap = 0, batch_pin_cap = 0;
 };
 
 namespace {
@@ -483,9 +486,7 @@ class RowBatch {
     unsigned long long gen = 0;
     hipError_t herr = hipSuccess;
 
-    ~RowBatch() {
-        if (dev) (void)hipFree(dev);
-        if (pin) (void)hipHostFree(pin);
+    ~RowBatch() {                                                         // (the arenas belong to the context's SmplifyState)
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
     }
@@ -812,6 +813,8 @@ void lbfgs_row(RowBatch& B, const int r, const float lr, const int max_iter, Dev
 void rc_smplify_free(SmplifyState* s) {
     if (!s) return;
     free_work(s);
+    if (s->batch_dev) (void)hipFree(s->batch_dev);
+    if (s->batch_pin) (void)hipHostFree(s->batch_pin);
     for (float** p : {&s->means, &s->prec, &s->lognll, &s->Kd})
         if (*p) (void)hipFree(*p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -1054,8 +1057,19 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     const size_t p_args = ptake(nr * sizeof(SmplifyArgs)), p_ops = ptake(3 * nr * sizeof(VecOp)), p_comb = ptake(nr * sizeof(VecCombRow));
     const size_t p_jobs = ptake(nr * B.max_jobs * sizeof(VecJobN)), p_part = ptake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
     const size_t p_terms = ptake(nr * 3 * (size_t)B.T_max * 4);
-    SM_TRY(ctx, hipMalloc((void**)&B.dev, dev_need));
-    SM_TRY(ctx, hipHostMalloc((void**)&B.pin, pin_need, hipHostMallocDefault));
+    if (dev_need > s0->batch_dev_cap) {
+        if (s0->batch_dev) (void)hipFree(s0->batch_dev);
+        s0->batch_dev = nullptr; s0->batch_dev_cap = 0;
+        SM_TRY(ctx, hipMalloc((void**)&s0->batch_dev, dev_need));
+        s0->batch_dev_cap = dev_need;
+    }
+    if (pin_need > s0->batch_pin_cap) {
+        if (s0->batch_pin) (void)hipHostFree(s0->batch_pin);
+        s0->batch_pin = nullptr; s0->batch_pin_cap = 0;
+        SM_TRY(ctx, hipHostMalloc((void**)&s0->batch_pin, pin_need, hipHostMallocDefault));
+        s0->batch_pin_cap = pin_need;
+    }
+    B.dev = s0->batch_dev; B.pin = s0->batch_pin;
     B.dev_bytes = dev_need; B.pin_bytes = pin_need;
     SM_TRY(ctx, hipEventCreate(&B.ev0));
     SM_TRY(ctx, hipEventCreate(&B.ev1));
