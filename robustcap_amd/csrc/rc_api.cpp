@@ -986,7 +986,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
 // grow-only device scratch of the mesh sweeps (rc_metrics.hip); a reallocation waits for whatever still reads the old one
 int sweep_scratch(rc_ctx* ctx, size_t floats, hipStream_t st) {
     if (floats <= ctx->sweep_scratch_cap) return RC_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    (void)st;
+    HIP_TRY(ctx, hipDeviceSynchronize());          // the scratch is shared by entry points that take independent stream arguments
     if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
     ctx->sweep_scratch = nullptr; ctx->sweep_scratch_cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->sweep_scratch, floats * sizeof(float)));
@@ -1461,7 +1462,8 @@ int rc_set_gemm_mode(rc_ctx* ctx, int32_t mode) {
     return RC_OK;
 }
 int rc_get_gemm_mode(const rc_ctx* ctx) { return ctx ? (ctx->gemm_split ? 1 : 0) : RC_ERR_INVALID; }
-int rc_default_gemm_mode(int32_t total_rows) { return total_rows >= RC_SPLIT_MIN_BATCH ? 1 : 0; }
+// (honours RC_GEMM_SPLIT like rc_create does: a sharded run pins every shard to this value)
+int rc_default_gemm_mode(int32_t total_rows) { return tune_env("RC_GEMM_SPLIT", total_rows >= RC_SPLIT_MIN_BATCH ? 1 : 0) != 0 ? 1 : 0; }
 
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames) {
     if (!ctx || mode < 0 || mode > 2 || min_frames < 1) return ctx ? fail(ctx, RC_ERR_INVALID, "rc_set_sequence_mode: mode 0|1|2, min_frames >= 1") : RC_ERR_INVALID;

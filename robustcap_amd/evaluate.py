@@ -150,7 +150,8 @@ def run_dataset(dataset, state_dict, body, use_first_tran=True, use_flat_floor=T
                 nets[n] = (net, state_dict)
         else:
             net.reset_states()
-        net.set_gemm_mode(split)
+        if bool(net.gemm_mode) != bool(split):                  # (only when it differs: a switch drops a captured live frame)
+            net.set_gemm_mode(split)
         net.use_flat_floor = use_flat_floor
         net.gravityc = grav
         out_p, out_t = net.forward_sequence(j2d, acc, ori, first_tran=ft if use_first_tran else None, first_frame=not use_first_tran)

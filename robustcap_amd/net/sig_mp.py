@@ -130,7 +130,13 @@ class Net:
 
     def load_state_dict(self, state_dict, strict=True):
         """Same key names / shapes as the reference ``Net.state_dict()``. Values: torch tensors or
-        numpy arrays. Repacks to the kernel layout and uploads."""
+        numpy arrays. Repacks to the kernel layout and uploads.
+
+        Aliasing contract (unlike torch, which copies into its parameters): float32 CPU tensors / contiguous arrays are kept BY
+        REFERENCE until the next load, so that a later partial (``strict=False``) load can re-send the rest without this object
+        holding a second 254 MB copy. Editing such a tensor in place after loading it therefore shows up in the NEXT load that
+        re-sends it -- pass a copy if the caller's tensor is going to change. (Other dtypes / devices are converted, and the
+        converted copy is what is kept.)"""
         want = dict(cfg.state_dict_spec())
         missing = [k for k in want if k not in state_dict]
         unexpected = [k for k in state_dict if k not in want]
