@@ -1308,6 +1308,11 @@ int rc_set_body(rc_ctx* ctx, const int32_t* parent, const float* J, const float*
         if (i > 0 && (parent[i] < 0 || parent[i] >= i)) return fail(ctx, RC_ERR_INVALID, "rc_set_body: parent[i] must be in [0, i)");
         b.level[i] = i == 0 ? 0 : b.level[parent[i]] + 1;
         if (b.level[i] > 9) return fail(ctx, RC_ERR_INVALID, "rc_set_body: kinematic tree deeper than 9");
+        if (i > 0) {
+            int& n = b.nchild[parent[i]];
+            if (n >= 4) return fail(ctx, RC_ERR_INVALID, "rc_set_body: a joint with more than 4 children");
+            b.child[parent[i]][n++] = i;
+        }
     }
     for (int i = 0; i < 24; ++i)
         for (int c = 0; c < 3; ++c) {

@@ -106,6 +106,8 @@ struct BodyConst {          // device copy of the body constants the path needs
     float w33[33][24];
     float v33[33][3];       // landmark vertices, root-relative
     int override_joint[33]; // sync_mp3d: landmark row -> joint id, or -1
+    int nchild[24];         // children of a joint, ascending (the reverse sweep of the smplify gradient pulls from them)
+    int child[24][4];
 };
 
 struct FrameBuffers {       // device pointers owned by the context (all [B, ld] row-major)
@@ -283,14 +285,18 @@ struct SmplifyArgs {
     const float* ref3d;     // [T,33,3] landmarks of the initial prediction
     const float* imu_aa;    // [T,18] axis-angle of the measured IMU orientations
     const float* means;     // [8,69]
-    const float* prec;      // [8,69,69]
+    const float* prec;      // [8,69,72] precision matrices, rows padded (rc_smplify_set_prior)
+    const float* prec_sym;  // [8,69,72] P + P^T, rows padded
     const float* lognll;    // [8] log(nll_weights)
     float* mj;              // [T,33,3] out (fwd) / in (grad)
     float* proj;            // [T,33,2]
     float* frame_loss;      // [T] reprojection + prior + angle + 3D of frame t
     float* imu_loss;        // [T] 0.25 * |aa(imu) - aa(G[ji])|^2
     float* smooth_loss;     // [T] smoothness terms of the pair (t-1, t)
-    int* argmin;            // [T] mixture component of the prior
+    int* argmin;            // [T] mixture component of the prior            } written by the prior kernel,
+    float* prior_ll;        // [T] min_m 0.5 d^T P_m d - log(nll_w_m)        } read by the forward / gradient kernels
+    float* prior_g;         // [T,69] (P_m + P_m^T) d of that mixture        }
+    float* fk;              // [T,2,24,9] local and global rotations of the forward kernel's primal, read by the gradient kernel
     float* grad_aa;         // [T,72]  } one flat vector [T*72 | T*3], the optimiser's parameter order
     float* grad_tran;       // [T,3]   } (temporal_smplify.py:141: [body_pose, tran])
     float K[9];

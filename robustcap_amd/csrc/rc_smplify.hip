@@ -6,8 +6,9 @@
 //   net/smplify/losses.py:15-87              the objective (reprojection GMoF, GMM pose prior, angle prior, 3D term,
 //                                            gradient-dead IMU term, temporal smoothness in 2D and 3D)
 //   net/smplify/prior.py:164-179             MaxMixturePrior.merged_log_likelihood
-// Here: parameters x = [T, 72 axis-angle + 3 translation]. Two kernels per evaluation, one workgroup per frame:
-//   rc_smplify_fwd_kernel   primal: rotations, FK, 33 landmarks, projection, per-frame loss terms, prior argmin
+// Here: parameters x = [T, 72 axis-angle + 3 translation]. Three kernels per evaluation:
+//   rc_smplify_prior_kernel GMM pose prior of 64 frames per workgroup (lane = frame, wave = mixture): value, argmin, gradient rows
+//   rc_smplify_fwd_kernel   one workgroup per frame; primal: rotations, FK, 33 landmarks, projection, per-frame loss terms
 //   rc_smplify_grad_kernel  wave 0 forms the adjoint lambda = dL/d(landmark) of its frame (incl. the smoothness terms
 //                           that couple it to frames t-1 and t+1) and contracts it with the constant skinning data
 //                           into per-joint co-factors; 72 threads then push one TANGENT each (d/d axis-angle
@@ -76,11 +77,112 @@ __device__ __forceinline__ void frame_primal(const BodyConst* body, WaveScratch&
     wave_body_fk(body, s, tran, lane);
 }
 
+// ================================================================================================ GMM pose prior
+// prior.py:164-179 (MaxMixturePrior.merged_log_likelihood) and its gradient for every frame, ahead of the forward kernel.
+// Rounds 1-4 formed the eight 69 x 69 quadratic forms inside the per-frame forward workgroup: 152 KB of precision rows through the
+// L1 per frame and evaluation (lanes = rows of P, 276 B apart) -- 0.8 of the forward kernel's 830 us on config 3's 43,200 frames.
+// Here a LANE is a FRAME and a WAVE a MIXTURE: the frame's 69 differences d = x - mean_m stay in VGPRs, a row of P_m is wave-uniform
+// and arrives through the scalar cache (s_load into SGPRs: one v_fma per element, no LDS, no vector memory in the loop). The
+// arithmetic is the per-frame kernel's operation for operation -- r_i = sum_j P[i][j] d_j as one fma chain in j, lane sums
+// q_l = r_l d_l (+ r_{l+64} d_{l+64}), and wave_sum's xor butterfly as the pairwise tree it is: the leaves taken in bit-reversed
+// order, partial sums on a six-deep stack -- so losses, argmin and gradients are bitwise what they were.
+// Rows of P and of S = P + P^T are padded to SM_PLD floats (rc_smplify_set_prior) so that every row starts 32-byte aligned.
+#define SM_PLD 72
+#define RC_CONST4 __attribute__((address_space(4)))
+
+template <int N>
+__device__ __forceinline__ float prior_row_dot(const RC_CONST4 float* __restrict__ row, const float (&d)[N]) {
+    float r = 0.0f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r = __builtin_fmaf(row[j], d[j], r);       // (explicit: the SLP vectoriser would pair the tail into v_pk_mul + adds)
+    return r;
+}
+
+__device__ __forceinline__ void smplify_prior_block(const SmplifyArgs& A, const int t0) {
+    __shared__ float s_x[SM_DIM][65];         // pose components [j][frame]; after the argmin: the selected gradient rows
+    __shared__ float s_ll[SM_NG][64];
+    __shared__ int s_arg[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);               // mixture of this wave
+    const int nf = min(64, A.T - t0);
+    for (int e = tid; e < 64 * 72; e += 512) {
+        const int f = e / 72, c = e % 72;
+        if (c >= 3) s_x[c - 3][f] = (f < nf) ? A.aa[(long long)t0 * 72 + e] : 0.0f;
+    }
+    __syncthreads();
+    const RC_CONST4 float* mean = (const RC_CONST4 float*)(A.means + w * SM_DIM);
+    const RC_CONST4 float* Pw = (const RC_CONST4 float*)(A.prec + (long long)w * SM_DIM * SM_PLD);
+    const RC_CONST4 float* Sw = (const RC_CONST4 float*)(A.prec_sym + (long long)w * SM_DIM * SM_PLD);
+    float d[SM_DIM];
+#pragma unroll
+    for (int j = 0; j < SM_DIM; ++j) d[j] = s_x[j][lane] - mean[j];
+    // ---- 0.5 d^T P d: leaves q_l in bit-reversed order, pairwise sums on a stack = wave_sum's butterfly over l = 0..63
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, total = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 64; ++k) {
+        const int i = (int)(__builtin_bitreverse32((unsigned)k) >> 26);
+        const float r = prior_row_dot(Pw + i * SM_PLD, d);
+        float q = __builtin_fmaf(r, s_x[i][lane] - mean[i], 0.0f);
+        if (i + 64 < SM_DIM) {
+            const float r2 = prior_row_dot(Pw + (i + 64) * SM_PLD, d);
+            q = __builtin_fmaf(r2, s_x[i + 64][lane] - mean[i + 64], q);
+        }
+        float v = q;
+        if (k & 1) {
+            v = s0 + v;
+            if (k & 2) {
+                v = s1 + v;
+                if (k & 4) {
+                    v = s2 + v;
+                    if (k & 8) {
+                        v = s3 + v;
+                        if (k & 16) {
+                            v = s4 + v;
+                            if (k & 32) total = s5 + v; else s5 = v;
+                        } else s4 = v;
+                    } else s3 = v;
+                } else s2 = v;
+            } else s1 = v;
+        } else s0 = v;
+    }
+    s_ll[w][lane] = 0.5f * total - ((const RC_CONST4 float*)A.lognll)[w];
+    __syncthreads();
+    if (w == 0) {
+        float best = s_ll[0][lane];
+        int bi = 0;
+        for (int m = 1; m < SM_NG; ++m) {
+            const float ll = s_ll[m][lane];
+            if (ll < best) { best = ll; bi = m; }
+        }
+        s_arg[lane] = bi;
+        if (lane < nf) { A.prior_ll[t0 + lane] = best; A.argmin[t0 + lane] = bi; }
+    }
+    __syncthreads();
+    // ---- gradient rows (P + P^T) d of the frames whose mixture this wave is (a wave none of whose frames chose it has nothing to do)
+    const bool mine = (s_arg[lane] == w) && (lane < nf);
+    __syncthreads();                                                      // every d is in registers: s_x becomes the output tile
+    if (__ballot(mine) != 0ull) {
+#pragma unroll 1
+        for (int i = 0; i < SM_DIM; ++i) {
+            const float r = prior_row_dot(Sw + i * SM_PLD, d);
+            if (mine) s_x[i][lane] = r;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nf * SM_DIM; e += 512) A.prior_g[(long long)t0 * SM_DIM + e] = s_x[e % SM_DIM][e / SM_DIM];
+}
+
+__global__ __launch_bounds__(512) void rc_smplify_prior_kernel(SmplifyArgs A) { smplify_prior_block(A, (int)blockIdx.x * 64); }
+__global__ __launch_bounds__(512) void rc_smplify_prior_rows_kernel(const SmplifyArgs* __restrict__ rows) {
+    const SmplifyArgs A = rows[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= A.T) return;
+    smplify_prior_block(A, (int)blockIdx.x * 64);
+}
+
 // ============================================================================================== forward pass
 __device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const BodyConst* __restrict__ body_g, const int t) {
     __shared__ WaveScratch s;
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
-    __shared__ float s_d[SM_DIM];
     const int lane = threadIdx.x;
     stage_body(&s_body, body_g, lane, 64);
     __syncthreads();
@@ -88,6 +190,12 @@ __device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const Bo
     const float* aa = A.aa + (long long)t * 72;
     const float tr[3] = {A.tran[t * 3], A.tran[t * 3 + 1], A.tran[t * 3 + 2]};
     frame_primal(body, s, aa, tr, lane);
+    {   // the rotations of the primal for the gradient kernel (it used to redo Rodrigues and the FK sweep)
+        float* fk = A.fk + (long long)t * 432;
+        const float* rl = &s.Rl[0][0];
+        const float* gg = &s.G[0][0];
+        for (int e = lane; e < 216; e += 64) { fk[e] = rl[e]; fk[216 + e] = gg[e]; }
+    }
 
     // landmarks, projection, reprojection + 3D terms
     float part = 0.0f;
@@ -120,24 +228,8 @@ __device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const Bo
         part = (15.2f * 15.2f) * (e * e);
     } else part = 0.0f;
     loss += wave_sum(part);
-    // GMM prior (prior.py:164-179): min_m 0.5 d^T P_m d - log(nll_w_m)
-    float best = 0.0f;
-    int bi = 0;
-    for (int m = 0; m < SM_NG; ++m) {
-        __syncthreads();
-        for (int i = lane; i < SM_DIM; i += 64) s_d[i] = aa[3 + i] - A.means[m * SM_DIM + i];
-        __syncthreads();
-        float q = 0.0f;
-        for (int i = lane; i < SM_DIM; i += 64) {
-            const float* pr = A.prec + ((long long)m * SM_DIM + i) * SM_DIM;
-            float r = 0.0f;
-            for (int j = 0; j < SM_DIM; ++j) r += pr[j] * s_d[j];
-            q += r * s_d[i];
-        }
-        const float ll = 0.5f * wave_sum(q) - A.lognll[m];
-        if (m == 0 || ll < best) { best = ll; bi = m; }
-    }
-    loss += 0.01f * best;                                                               // pose_prior_weight ** 2
+    // GMM prior (prior.py:164-179): min_m 0.5 d^T P_m d - log(nll_w_m), formed for all frames by rc_smplify_prior_kernel
+    loss += 0.01f * A.prior_ll[t];                                                      // pose_prior_weight ** 2
     // gradient-dead IMU term (losses.py:39-40): value only
     part = 0.0f;
     if (lane < 6) {
@@ -148,7 +240,7 @@ __device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const Bo
         for (int c = 0; c < 3; ++c) { const float d = A.imu_aa[t * 18 + 3 * lane + c] - a3[c]; part += d * d; }
     }
     const float imu = 0.25f * wave_sum(part);
-    if (lane == 0) { A.frame_loss[t] = loss; A.imu_loss[t] = imu; A.argmin[t] = bi; }
+    if (lane == 0) { A.frame_loss[t] = loss; A.imu_loss[t] = imu; }
 }
 
 __global__ __launch_bounds__(64) void rc_smplify_fwd_kernel(SmplifyArgs A, const BodyConst* __restrict__ body_g) {
@@ -167,23 +259,28 @@ __global__ __launch_bounds__(64) void rc_smplify_fwd_rows_kernel(const SmplifyAr
 // LDS -- one 128-thread workgroup per CU, 2 waves on a 256-CU chip per 600-frame evaluation: 72 rows x 600 frames x 26 evaluations
 // took ~200 ms however they were batched. Now 2 KB of adjoints; the kernel is no longer limited to one workgroup per CU.
 __device__ __forceinline__ void smplify_grad_frame(const SmplifyArgs& A, const BodyConst* __restrict__ body_g, const int t) {
-    __shared__ WaveScratch s;
     __shared__ __attribute__((aligned(16))) BodyConst s_body;
-    __shared__ float s_lam[33][3];
+    __shared__ float s_Rl[24][9], s_G[24][9], s_J33[33][3];   // the forward kernel's primal of this frame
+    __shared__ float s_lam[33][3], s_e3[33][3];
     __shared__ float s_Gb[24][9], s_pb[24][3];        // adjoints of the loss w.r.t. a joint's global rotation / position
     const int tid = threadIdx.x, T = A.T;
     stage_body(&s_body, body_g, tid, 128);
+    {
+        const float* fk = A.fk + (long long)t * 432;
+        float* rl = &s_Rl[0][0];
+        float* gg = &s_G[0][0];
+        for (int e = tid; e < 216; e += 128) { rl[e] = fk[e]; gg[e] = fk[216 + e]; }
+        if (tid < 99) (&s_J33[0][0])[tid] = A.mj[(long long)t * 99 + tid];
+    }
     __syncthreads();
     const BodyConst* body = &s_body;
     const float* aa = A.aa + (long long)t * 72;
-    const float tr[3] = {A.tran[t * 3], A.tran[t * 3 + 1], A.tran[t * 3 + 2]};
-    frame_primal(body, s, aa, tr, tid < 64 ? tid : 64);              // every thread hits the barriers inside
 
     // ---- adjoint of the loss with respect to the 33 landmarks of THIS frame ---------------------------------
     float sm = 0.0f;
     if (tid < 33) {
         const int v = tid;
-        const float x = s.J33[v][0], y = s.J33[v][1], z = s.J33[v][2];
+        const float x = s_J33[v][0], y = s_J33[v][1], z = s_J33[v][2];
         const float* k3 = A.kp + ((long long)t * 33 + v) * 3;
         const float cf = ((A.ign_mask >> v) & 1ull) ? 0.0f : k3[2], c2 = cf * cf;
         const float u = A.proj[((long long)t * 33 + v) * 2], w = A.proj[((long long)t * 33 + v) * 2 + 1];
@@ -212,13 +309,17 @@ __device__ __forceinline__ void smplify_grad_frame(const SmplifyArgs& A, const B
         lam[0] += dxn / z;
         lam[1] += dyn / z;
         lam[2] += -(dxn * x + dyn * y) / (z * z);
+        float e3[3] = {0.f, 0.f, 0.f};
         if (v >= 1) {                                                                  // 3D term, own part
             const float* r = A.ref3d + (long long)t * 99;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) lam[c] += 2.0f * ((s.J33[v][c] - s.J33[0][c]) - (r[3 * v + c] - r[c]));
+            for (int c = 0; c < 3; ++c) {
+                e3[c] = (s_J33[v][c] - s_J33[0][c]) - (r[3 * v + c] - r[c]);
+                lam[c] += 2.0f * e3[c];
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_lam[v][c] = lam[c];
+        for (int c = 0; c < 3; ++c) { s_lam[v][c] = lam[c]; s_e3[v][c] = e3[c]; }
     }
     if (tid < 64) {
         const float tot = wave_sum(sm);
@@ -226,60 +327,52 @@ __device__ __forceinline__ void smplify_grad_frame(const SmplifyArgs& A, const B
     }
     __syncthreads();
     if (tid < 3) {                                                                     // 3D term, landmark 0 part
-        const float* r = A.ref3d + (long long)t * 99;
         float acc = 0.0f;
-        for (int v = 1; v < 33; ++v) acc += 2.0f * ((s.J33[v][tid] - s.J33[0][tid]) - (r[3 * v + tid] - r[tid]));
+        for (int v = 1; v < 33; ++v) acc += 2.0f * s_e3[v][tid];
         s_lam[0][tid] -= acc;
     }
     __syncthreads();
-    // ---- contract lambda with the constant skinning data into per-joint co-factors ---------------------------
-    if (tid < 24) {
-        const int i = tid;
-        float M[9], m3[3], o3[3];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) M[q] = 0.0f;
-        m3[0] = m3[1] = m3[2] = o3[0] = o3[1] = o3[2] = 0.0f;
+    // ---- contract lambda with the constant skinning data into per-joint co-factors: thread (joint i, row a) --
+    if (tid < 72) {
+        const int i = tid / 3, a = tid % 3;
+        float Ma[3] = {0.f, 0.f, 0.f}, m = 0.0f, o = 0.0f;
         for (int v = 0; v < 33; ++v) {
             const int oj = body->override_joint[v];
+            const float la = s_lam[v][a];
             if (oj >= 0) {
-                if (oj == i) { o3[0] += s_lam[v][0]; o3[1] += s_lam[v][1]; o3[2] += s_lam[v][2]; }
+                if (oj == i) o += la;
                 continue;
             }
             const float w = body->w33[v][i];
+            m += w * la;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                m3[a] += w * s_lam[v][a];
-#pragma unroll
-                for (int b = 0; b < 3; ++b) M[3 * a + b] += w * s_lam[v][a] * body->v33[v][b];
-            }
+            for (int b = 0; b < 3; ++b) Ma[b] += w * la * body->v33[v][b];
         }
         // L depends on joint i through <M, G_i> + m . (P_i - G_i jrest_i) + o . P_i  (model.py:235: T_i = P_i - G_i jrest_i):
         // own adjoints  Gb_i = M - m jrest_i^T,  pb_i = m + o
         const float* jr = body->jrest[i];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) s_Gb[i][3 * a + b] = M[3 * a + b] - m3[a] * jr[b];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s_pb[i][c] = m3[c] + o3[c];
+        for (int b = 0; b < 3; ++b) s_Gb[i][3 * a + b] = Ma[b] - m * jr[b];
+        s_pb[i][a] = m + o;
     }
     __syncthreads();
     // ---- reverse sweep: G_c = G_i Rl_c, P_c = P_i + G_i bone_c  =>  Gb_i += Gb_c Rl_c^T + pb_c bone_c^T,  pb_i += pb_c for every
     // child c of i. A joint PULLS from its children (final once their level is done): no two lanes write the same adjoint.
     {
         const int lvl = tid < 24 ? body->level[tid] : -1;
+        const int nc = tid < 24 ? body->nchild[tid] : 0;
         for (int l = 8; l >= 0; --l) {
-            if (lvl == l) {
+            if (lvl == l && nc > 0) {
                 const int i = tid;
                 float Gb[9], pb[3];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) Gb[q] = s_Gb[i][q];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) pb[q] = s_pb[i][q];
-                for (int c = i + 1; c < 24; ++c) {
-                    if (body->parent[c] != i) continue;
+                for (int ci = 0; ci < nc; ++ci) {
+                    const int c = body->child[i][ci];
                     const float* Gc = s_Gb[c];
-                    const float* Rc = s.Rl[c];
+                    const float* Rc = s_Rl[c];
                     const float* pc = s_pb[c];
                     const float* bc = body->bone[c];
 #pragma unroll
@@ -308,19 +401,14 @@ __device__ __forceinline__ void smplify_grad_frame(const SmplifyArgs& A, const B
         if (j == 0) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) Rb[q] = s_Gb[0][q];
-        } else mat3T_mul(s.G[body->parent[j]], s_Gb[j], Rb);
+        } else mat3T_mul(s_G[body->parent[j]], s_Gb[j], Rb);
         float g = 0.0f;
 #pragma unroll
         for (int q = 0; q < 9; ++q) g += Rb[q] * dRl[q];
         // priors act on the 69 non-root components
         if (k >= 3) {
-            const int m = A.argmin[t], i = k - 3;
-            const float* pr = A.prec + ((long long)m * SM_DIM) * SM_DIM;
-            float r = 0.0f;
-            for (int q = 0; q < SM_DIM; ++q) {
-                const float d = aa[3 + q] - A.means[m * SM_DIM + q];
-                r += (pr[i * SM_DIM + q] + pr[q * SM_DIM + i]) * d;   // d/dx of x^T P x  =  (P + P^T) x
-            }
+            // d/dx of x^T P x = (P + P^T) x for the frame's mixture: row k - 3 of it from rc_smplify_prior_kernel
+            const float r = A.prior_g[(long long)t * SM_DIM + (k - 3)];
             g += 0.01f * 0.5f * r;
             const float sg = (k == 55) ? 1.0f : ((k == 58 || k == 12 || k == 15) ? -1.0f : 0.0f);
             if (sg != 0.0f) { const float e = expf(aa[k] * sg); g += (15.2f * 15.2f) * 2.0f * (e * e) * sg; }
@@ -345,11 +433,13 @@ __global__ __launch_bounds__(128) void rc_smplify_grad_rows_kernel(const Smplify
 
 void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t st) {
     if (A.T <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_prior_kernel, dim3((A.T + 63) / 64), dim3(512), 0, st, A);
     hipLaunchKernelGGL(rc_smplify_fwd_kernel, dim3(A.T), dim3(64), 0, st, A, body);
     hipLaunchKernelGGL(rc_smplify_grad_kernel, dim3(A.T), dim3(128), 0, st, A, body);
 }
 void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t st) {
     if (n_rows <= 0 || T_max <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_prior_rows_kernel, dim3((unsigned)(T_max + 63) / 64, (unsigned)n_rows), dim3(512), 0, st, rows_dev);
     hipLaunchKernelGGL(rc_smplify_fwd_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body);
     hipLaunchKernelGGL(rc_smplify_grad_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(128), 0, st, rows_dev, body);
 }

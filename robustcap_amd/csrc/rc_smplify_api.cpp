@@ -19,14 +19,18 @@
 #include <string>
 #include <vector>
 
+constexpr size_t kPriorLd = 72, kPriorMat = 8 * 69 * kPriorLd;   // rc_smplify.hip: SM_PLD
+
 struct SmplifyState {
-    float *means = nullptr, *prec = nullptr, *lognll = nullptr;     // device
+    float *means = nullptr, *prec = nullptr, *lognll = nullptr;     // device; prec = [2][8][69][72]: P, then P + P^T, rows padded
     bool have_prior = false;
     int64_t cap = 0;                                                  // frames the buffers below hold
     float *x = nullptr, *grad = nullptr;                              // [cap*75] flat [aa | tran]
     float *ref3d = nullptr, *imu_aa = nullptr, *mj = nullptr, *proj = nullptr, *joint = nullptr;
     float *terms = nullptr;                                           // [3*cap] frame | imu | smooth losses
     int* argmin = nullptr;
+    float *prior_ll = nullptr, *prior_g = nullptr;                    // [cap], [cap*69]: outputs of the prior kernel
+    float* fk = nullptr;                                              // [cap*432]: rotations of the forward kernel's primal
     float *res0 = nullptr, *res1 = nullptr, *Kd = nullptr;            // residuals [cap,33] before / after, K on the device
     float *h_x = nullptr, *h_grad = nullptr, *h_terms = nullptr, *h_res = nullptr;   // pinned
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -54,7 +58,7 @@ typedef float (*cubic_fn)(float, float, float, float, float, float, bool, float,
     } while (0)
 
 void free_work(SmplifyState* s) {
-    for (float** p : {&s->x, &s->grad, &s->ref3d, &s->imu_aa, &s->mj, &s->proj, &s->joint, &s->terms, &s->res0, &s->res1})
+    for (float** p : {&s->x, &s->grad, &s->ref3d, &s->imu_aa, &s->mj, &s->proj, &s->joint, &s->terms, &s->res0, &s->res1, &s->prior_ll, &s->prior_g, &s->fk})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (s->argmin) { (void)hipFree(s->argmin); s->argmin = nullptr; }
     for (float** p : {&s->h_x, &s->h_grad, &s->h_terms, &s->h_res})
@@ -74,7 +78,7 @@ int state_of(rc_ctx* ctx, SmplifyState** out) {
     if (!s) {
         s = new SmplifyState();
         SM_TRY(ctx, hipMalloc((void**)&s->means, 8 * 69 * sizeof(float)));
-        SM_TRY(ctx, hipMalloc((void**)&s->prec, 8 * 69 * 69 * sizeof(float)));
+        SM_TRY(ctx, hipMalloc((void**)&s->prec, 2 * kPriorMat * sizeof(float)));
         SM_TRY(ctx, hipMalloc((void**)&s->lognll, 8 * sizeof(float)));
         SM_TRY(ctx, hipMalloc((void**)&s->Kd, 9 * sizeof(float)));
         SM_TRY(ctx, hipEventCreate(&s->ev0));
@@ -97,6 +101,9 @@ int reserve(rc_ctx* ctx, SmplifyState* s, int64_t T) {
     SM_TRY(ctx, hipMalloc((void**)&s->joint, n * 72 * sizeof(float)));
     SM_TRY(ctx, hipMalloc((void**)&s->terms, n * 3 * sizeof(float)));
     SM_TRY(ctx, hipMalloc((void**)&s->argmin, n * sizeof(int)));
+    SM_TRY(ctx, hipMalloc((void**)&s->prior_ll, n * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->prior_g, n * 69 * sizeof(float)));
+    SM_TRY(ctx, hipMalloc((void**)&s->fk, n * 432 * sizeof(float)));
     SM_TRY(ctx, hipMalloc((void**)&s->res0, n * 33 * sizeof(float)));
     SM_TRY(ctx, hipMalloc((void**)&s->res1, n * 33 * sizeof(float)));
     SM_TRY(ctx, hipHostMalloc((void**)&s->h_x, n * 75 * sizeof(float)));
@@ -112,10 +119,10 @@ SmplifyArgs make_args(SmplifyState* s, const float* x, const float* kp, const fl
     SmplifyArgs A{};
     A.aa = x; A.tran = x + T * 72;
     A.kp = kp; A.ref3d = ref3d; A.imu_aa = imu_aa;
-    A.means = s->means; A.prec = s->prec; A.lognll = s->lognll;
+    A.means = s->means; A.prec = s->prec; A.prec_sym = s->prec + kPriorMat; A.lognll = s->lognll;
     A.mj = s->mj; A.proj = s->proj;
     A.frame_loss = s->terms; A.imu_loss = s->terms + T; A.smooth_loss = s->terms + 2 * T;
-    A.argmin = s->argmin;
+    A.argmin = s->argmin; A.prior_ll = s->prior_ll; A.prior_g = s->prior_g; A.fk = s->fk;
     A.grad_aa = grad; A.grad_tran = grad + T * 72;
     for (int q = 0; q < 9; ++q) A.K[q] = K[q];
     A.ign_mask = ign_mask;
@@ -436,6 +443,7 @@ struct RowBuf {                       // device vectors of one row (carved from 
     float* terms = nullptr;           // [3 T] frame | imu | smooth, device (inside the terms arena)
     const float* terms_h = nullptr;   // the same region of the pinned copy
     int* argmin = nullptr;
+    float *prior_ll = nullptr, *prior_g = nullptr, *fk = nullptr;
     float* h_res = nullptr;           // pinned [66 T]
     float K[9];
     const float* kp = nullptr;
@@ -527,10 +535,10 @@ class RowBatch {
                 SmplifyArgs A{};
                 A.aa = xp; A.tran = xp + b.T * 72;
                 A.kp = b.kp; A.ref3d = b.ref3d; A.imu_aa = b.imu_aa;
-                A.means = prior->means; A.prec = prior->prec; A.lognll = prior->lognll;
+                A.means = prior->means; A.prec = prior->prec; A.prec_sym = prior->prec + kPriorMat; A.lognll = prior->lognll;
                 A.mj = b.mj; A.proj = b.proj;
                 A.frame_loss = b.terms; A.imu_loss = b.terms + b.T; A.smooth_loss = b.terms + 2 * b.T;
-                A.argmin = b.argmin;
+                A.argmin = b.argmin; A.prior_ll = b.prior_ll; A.prior_g = b.prior_g; A.fk = b.fk;
                 float* g = b.gslot + (size_t)q->k * b.n;
                 A.grad_aa = g; A.grad_tran = g + b.T * 72;
                 for (int e = 0; e < 9; ++e) A.K[e] = b.K[e];
@@ -835,7 +843,17 @@ int rc_smplify_set_prior(rc_ctx* ctx, const float* means, const float* prec, con
         lg[m] = logf(nllw[m]);
     }
     SM_TRY(ctx, hipMemcpy(s->means, means, 8 * 69 * sizeof(float), hipMemcpyHostToDevice));
-    SM_TRY(ctx, hipMemcpy(s->prec, prec, 8 * 69 * 69 * sizeof(float), hipMemcpyHostToDevice));
+    // rows padded to 72 floats (32-byte aligned for the prior kernel's scalar loads); the second half is P + P^T, the matrix of the
+    // gradient of d^T P d (the fp32 sum the gradient kernel used to form per element)
+    std::vector<float> pad(2 * kPriorMat, 0.0f);
+    for (int m = 0; m < 8; ++m)
+        for (int i = 0; i < 69; ++i)
+            for (int j = 0; j < 69; ++j) {
+                const float a = prec[((size_t)m * 69 + i) * 69 + j], b = prec[((size_t)m * 69 + j) * 69 + i];
+                pad[((size_t)m * 69 + i) * kPriorLd + j] = a;
+                pad[kPriorMat + ((size_t)m * 69 + i) * kPriorLd + j] = a + b;
+            }
+    SM_TRY(ctx, hipMemcpy(s->prec, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice));
     SM_TRY(ctx, hipMemcpy(s->lognll, lg, sizeof(lg), hipMemcpyHostToDevice));
     s->have_prior = true;
     return RC_OK;
@@ -1039,7 +1057,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     size_t dev_need = 0, pin_need = 0;
     auto dtake = [&](size_t bytes) { const size_t o = dev_need; dev_need += al(bytes); return o; };
     auto ptake = [&](size_t bytes) { const size_t o = pin_need; pin_need += al(bytes); return o; };
-    struct Off { size_t x, xt, dir, gs, Sv, Yv, ref, imu, mj, proj, joint, r0, r1, Kd, am, hres; };
+    struct Off { size_t x, xt, dir, gs, Sv, Yv, ref, imu, mj, proj, joint, r0, r1, Kd, am, pl, pg, fk, hres; };
     std::vector<Off> off((size_t)n_rows);
     for (int r = 0; r < n_rows; ++r) {
         const size_t n = B.row[r].n, T = (size_t)B.row[r].T;
@@ -1047,7 +1065,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
         o.x = dtake(n * 4); o.xt = dtake(n * 4); o.dir = dtake(n * 4); o.gs = dtake(kSlots * n * 4);
         o.Sv = dtake((size_t)P * n * 4); o.Yv = dtake((size_t)P * n * 4);
         o.ref = dtake(T * 99 * 4); o.imu = dtake(T * 18 * 4); o.mj = dtake(T * 99 * 4); o.proj = dtake(T * 66 * 4); o.joint = dtake(T * 72 * 4);
-        o.r0 = dtake(T * 33 * 4); o.r1 = dtake(T * 33 * 4); o.Kd = dtake(64); o.am = dtake(T * 4);
+        o.r0 = dtake(T * 33 * 4); o.r1 = dtake(T * 33 * 4); o.Kd = dtake(64); o.am = dtake(T * 4); o.pl = dtake(T * 4); o.pg = dtake(T * 69 * 4); o.fk = dtake(T * 432 * 4);
         o.hres = ptake(T * 66 * 4);
     }
     const size_t nr = (size_t)n_rows;
@@ -1083,7 +1101,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
         auto f = [&](size_t q) { return (float*)(B.dev + q); };
         b.x = f(o.x); b.xt = f(o.xt); b.dir = f(o.dir); b.gslot = f(o.gs); b.Sv = f(o.Sv); b.Yv = f(o.Yv);
         b.ref3d = f(o.ref); b.imu_aa = f(o.imu); b.mj = f(o.mj); b.proj = f(o.proj); b.joint = f(o.joint); b.res0 = f(o.r0); b.res1 = f(o.r1);
-        b.Kd = f(o.Kd); b.argmin = (int*)(B.dev + o.am);
+        b.Kd = f(o.Kd); b.argmin = (int*)(B.dev + o.am); b.prior_ll = f(o.pl); b.prior_g = f(o.pg); b.fk = f(o.fk);
         b.h_res = (float*)(B.pin + o.hres);
         b.terms = B.terms_d + (size_t)r * 3 * B.T_max;
         b.terms_h = B.terms_h + (size_t)r * 3 * B.T_max;

@@ -46,6 +46,14 @@ def main():
             if "rounds" in v0:      # one lock-step batch over all rows (rc_smplify_run_batch): host_ms / device_ms are the batch's
                 out[key]["smplify_batch"] = {"call_ms": round(v0["host_ms"], 2), "closure_kernels_ms": round(v0["device_ms"], 2), "rounds": v0["rounds"],
                                              "n_eval_min_max": [min(v["n_eval"] for v in info.values()), max(v["n_eval"] for v in info.values())]}
+                # A/B of numerics-neutral kernel changes (RC_LIB_PATH = the other build): refined outputs and per-row optimiser records
+                import hashlib
+                h = hashlib.sha256()
+                for k in sorted(res):
+                    h.update(res[k][0].cpu().numpy().tobytes()); h.update(res[k][1].cpu().numpy().tobytes())
+                out[key]["smplify_batch"]["outputs_sha256"] = h.hexdigest()[:16]
+                out[key]["smplify_batch"]["final_loss_sum"] = float(np.sum([np.float64(v["final_loss"]) for v in info.values()]))
+                out[key]["smplify_batch"]["n_eval_sum"] = int(sum(v["n_eval"] for v in info.values()))
             else:
                 out[key]["smplify_ms_per_row"] = round(float(np.mean([v["host_ms"] for v in info.values()])), 2)
     if rank == 0 and world == 1:     # where the net-only time goes: the harness's three steps timed one by one
