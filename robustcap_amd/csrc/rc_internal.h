@@ -313,6 +313,29 @@ struct VecOp { const float* a; const float* b; const float* c; float* out; float
 struct VecCombRow { VecComb c; float* out; long long n; };
 struct VecJobN { const float* a; const float* b; int op; int pad_; long long n; };
 void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t s);
+// set-up and wrap-up of a batch of rows (rc_smplify_run_batch) in one launch each: what rc_smplify_run does per row with
+// rc_launch_residual / rc_launch_R2aa / rc_launch_body_fk / rc_launch_aa2R and two device-to-device copies
+struct SmplifyRowIO {
+    const float* pose;      // [T,24,3,3] initial local rotations
+    const float* tran;      // [T,3]
+    const float* kp;        // [T,33,3]
+    const float* imu_ori;   // [T,6,3,3]
+    float* x;               // [T*75] optimiser parameters [axis-angle | translation]
+    float* imu_aa;          // [T,18]
+    float* joint;           // [T,24,3]
+    float* ref3d;           // [T,33,3]
+    float* res0;            // [T,33] residual before
+    float* res1;            // [T,33] residual after
+    float* pose_out;        // [T,24,3,3]
+    float* tran_out;        // [T,3]
+    float K[9];
+    int T;
+    int live;               // wrap-up: 0 = the pre-check rejected the row (nothing to do)
+};
+void rc_launch_smplify_begin_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
+                                  unsigned long long ign_mask, hipStream_t s);
+void rc_launch_smplify_end_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
+                                unsigned long long ign_mask, hipStream_t s);
 void rc_launch_vec_ops(const VecOp* ops_dev, int n_ops, long long n_max, hipStream_t s);
 void rc_launch_vec_comb_rows(const VecCombRow* rows_dev, int n_rows, long long n_max, hipStream_t s);
 void rc_launch_vec_dots_rows(const VecJobN* jobs_dev, int n_jobs, int nb_max, double* partial, hipStream_t s);

@@ -444,6 +444,100 @@ void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, 
     hipLaunchKernelGGL(rc_smplify_grad_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(128), 0, st, rows_dev, body);
 }
 
+// ======================================================= set-up / wrap-up of a batch of rows, one launch each (grid: frame x row)
+// The arithmetic of rc_residual_kernel, rc_R2aa_kernel, rc_body_fk_kernel and rc_aa2R_kernel (rc_frame.hip), which rc_smplify_run
+// launches one after another per row: 72 rows x 8 launches and copies were 6.7 of config 3's 32 ms.
+__device__ __forceinline__ void residual_of_frame(const WaveScratch& s, const float* K, const float* kp, long long b, float sigma,
+                                                  unsigned long long ign_mask, float* loss, int lane) {
+    if (lane < 33) {
+        const float z = s.J33[lane][2];
+        const float q[3] = {s.J33[lane][0] / z, s.J33[lane][1] / z, z / z};
+        const float u = (K[0] * q[0] + K[1] * q[1]) + K[2] * q[2];
+        const float v = (K[3] * q[0] + K[4] * q[1]) + K[5] * q[2];
+        const float* k3 = kp + (b * 33 + lane) * 3;
+        const bool ign = (ign_mask >> lane) & 1ull;
+        const float cf = ign ? 0.0f : k3[2];
+        const float s2 = sigma * sigma;
+        const float dx = u - k3[0], dy = v - k3[1];
+        const float ex = (s2 * (dx * dx)) / (s2 + dx * dx), ey = (s2 * (dy * dy)) / (s2 + dy * dy);
+        loss[b * 33 + lane] = (cf * cf) * (ex + ey);
+    }
+}
+
+// residual of the initial pose (the pre-check reads its first frame), optimiser parameters (R -> axis-angle, translation), IMU
+// orientations as axis-angle, joints and the preserved 3D landmarks of the initial pose (temporal_smplify.py:111-139)
+__global__ __launch_bounds__(64) void rc_smplify_begin_rows_kernel(const SmplifyRowIO* __restrict__ rows, const BodyConst* __restrict__ body,
+                                                                  float sigma, unsigned long long ign_mask) {
+    __shared__ WaveScratch s;
+    const SmplifyRowIO& io = rows[blockIdx.y];
+    const long long b = blockIdx.x;
+    const int T = io.T;
+    if (b >= T) return;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 216; e += 64) s.Rl[e / 9][e % 9] = io.pose[b * 216 + e];
+    const float t[3] = {io.tran[b * 3], io.tran[b * 3 + 1], io.tran[b * 3 + 2]};
+    __syncthreads();
+    if (lane < 24) rotmat_to_aa(s.Rl[lane], io.x + b * 72 + 3 * lane);
+    else if (lane < 30) rotmat_to_aa(io.imu_ori + b * 54 + 9 * (lane - 24), io.imu_aa + b * 18 + 3 * (lane - 24));
+    else if (lane < 33) io.x[(long long)T * 72 + b * 3 + (lane - 30)] = t[lane - 30];
+    wave_body_fk(body, s, t, lane);
+    residual_of_frame(s, io.K, io.kp, b, sigma, ign_mask, io.res0, lane);
+    if (lane < 24) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) io.joint[(b * 24 + lane) * 3 + c] = s.P[lane][c] + t[c];
+    }
+    if (lane < 33) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) io.ref3d[(b * 33 + lane) * 3 + c] = s.J33[lane][c];
+    }
+}
+
+// rotations of the refined parameters (art.math.axis_angle_to_rotation_matrix), translation, residual after (run.py:31-34)
+__global__ __launch_bounds__(64) void rc_smplify_end_rows_kernel(const SmplifyRowIO* __restrict__ rows, const BodyConst* __restrict__ body,
+                                                                float sigma, unsigned long long ign_mask) {
+    __shared__ WaveScratch s;
+    const SmplifyRowIO& io = rows[blockIdx.y];
+    const long long b = blockIdx.x;
+    const int T = io.T;
+    if (b >= T || !io.live) return;
+    const int lane = threadIdx.x;
+    if (lane < 24) {
+        const float* aa = io.x + b * 72 + 3 * lane;
+        const float a[3] = {aa[0], aa[1], aa[2]};
+        const float th = norm3(a);
+        float k[3] = {a[0] / th, a[1] / th, a[2] / th};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (!(fabsf(k[q]) <= 3.0e38f)) k[q] = 0.0f;          // NaN / inf -> 0
+        const float c = cosf(th), sn = sinf(th), tt = 1.0f - c;
+        const float Km[9] = {0.f, -k[2], k[1], k[2], 0.f, -k[0], -k[1], k[0], 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float v = ((r == q ? c : 0.0f) + tt * (k[r] * k[q])) + sn * Km[3 * r + q];
+                s.Rl[lane][3 * r + q] = v;
+                io.pose_out[b * 216 + lane * 9 + 3 * r + q] = v;
+            }
+    }
+    const float* xt = io.x + (long long)T * 72 + b * 3;
+    const float t[3] = {xt[0], xt[1], xt[2]};
+    if (lane < 3) io.tran_out[b * 3 + lane] = t[lane];
+    __syncthreads();
+    wave_body_fk(body, s, t, lane);
+    residual_of_frame(s, io.K, io.kp, b, sigma, ign_mask, io.res1, lane);
+}
+
+void rc_launch_smplify_begin_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
+                                  unsigned long long ign_mask, hipStream_t st) {
+    if (n_rows <= 0 || T_max <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_begin_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body, sigma, ign_mask);
+}
+void rc_launch_smplify_end_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
+                                unsigned long long ign_mask, hipStream_t st) {
+    if (n_rows <= 0 || T_max <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_end_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body, sigma, ign_mask);
+}
+
 // ================================================================= vector kernels of the device-resident L-BFGS
 // (rc_smplify_api.cpp: minimize_on_device). The optimiser's vectors -- parameters, gradients of the bracket points, the
 // curvature pairs -- never leave the device; what the host reads back per step is a handful of inner products.

@@ -447,7 +447,7 @@ struct RowBuf {                       // device vectors of one row (carved from 
     const float* terms_h = nullptr;   // the same region of the pinned copy
     int* argmin = nullptr;
     float *prior_ll = nullptr, *prior_g = nullptr, *fk = nullptr;
-    float* h_res = nullptr;           // pinned [66 T]
+    float *h_res0 = nullptr, *h_res1 = nullptr;   // pinned [33 T] each: residual before / after
     float K[9];
     const float* kp = nullptr;
 };
@@ -1088,7 +1088,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     size_t dev_need = 0, pin_need = 0;
     auto dtake = [&](size_t bytes) { const size_t o = dev_need; dev_need += al(bytes); return o; };
     auto ptake = [&](size_t bytes) { const size_t o = pin_need; pin_need += al(bytes); return o; };
-    struct Off { size_t x, xt, dir, gs, Sv, Yv, ref, imu, mj, proj, joint, r0, r1, Kd, am, pl, pg, fk, hres; };
+    struct Off { size_t x, xt, dir, gs, Sv, Yv, ref, imu, mj, proj, joint, r0, r1, am, pl, pg, fk; };
     std::vector<Off> off((size_t)n_rows);
     for (int r = 0; r < n_rows; ++r) {
         const size_t n = B.row[r].n, T = (size_t)B.row[r].T;
@@ -1096,10 +1096,16 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
         o.x = dtake(n * 4); o.xt = dtake(n * 4); o.dir = dtake(n * 4); o.gs = dtake(kSlots * n * 4);
         o.Sv = dtake((size_t)P * n * 4); o.Yv = dtake((size_t)P * n * 4);
         o.ref = dtake(T * 99 * 4); o.imu = dtake(T * 18 * 4); o.mj = dtake(T * 99 * 4); o.proj = dtake(T * 66 * 4); o.joint = dtake(T * 72 * 4);
-        o.r0 = dtake(T * 33 * 4); o.r1 = dtake(T * 33 * 4); o.Kd = dtake(64); o.am = dtake(T * 4); o.pl = dtake(T * 4); o.pg = dtake(T * 69 * 4); o.fk = dtake(T * 432 * 4);
-        o.hres = ptake(T * 66 * 4);
+        o.am = dtake(T * 4); o.pl = dtake(T * 4); o.pg = dtake(T * 69 * 4); o.fk = dtake(T * 432 * 4);
     }
+    // the residuals of all rows in one span each (one read-back per span; the pinned copies mirror the offsets)
+    const size_t r0_begin = dev_need;
+    for (int r = 0; r < n_rows; ++r) off[r].r0 = dtake((size_t)B.row[r].T * 33 * 4);
+    const size_t r_bytes = dev_need - r0_begin, r1_begin = dev_need;
+    for (int r = 0; r < n_rows; ++r) off[r].r1 = dtake((size_t)B.row[r].T * 33 * 4);
+    const size_t p_r0 = ptake(r_bytes), p_r1 = ptake(r_bytes);
     const size_t nr = (size_t)n_rows;
+    const size_t o_io = dtake(nr * sizeof(SmplifyRowIO)), p_io = ptake(nr * sizeof(SmplifyRowIO));
     const size_t o_args = dtake(nr * sizeof(SmplifyArgs)), o_ops = dtake(3 * nr * sizeof(VecOp)), o_comb = dtake(nr * sizeof(VecCombRow));
     const size_t o_jobs = dtake(nr * B.max_jobs * sizeof(VecJobN)), o_part = dtake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
     const size_t o_terms = dtake(nr * 3 * (size_t)B.T_max * 4);
@@ -1132,20 +1138,30 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
         auto f = [&](size_t q) { return (float*)(B.dev + q); };
         b.x = f(o.x); b.xt = f(o.xt); b.dir = f(o.dir); b.gslot = f(o.gs); b.Sv = f(o.Sv); b.Yv = f(o.Yv);
         b.ref3d = f(o.ref); b.imu_aa = f(o.imu); b.mj = f(o.mj); b.proj = f(o.proj); b.joint = f(o.joint); b.res0 = f(o.r0); b.res1 = f(o.r1);
-        b.Kd = f(o.Kd); b.argmin = (int*)(B.dev + o.am); b.prior_ll = f(o.pl); b.prior_g = f(o.pg); b.fk = f(o.fk);
-        b.h_res = (float*)(B.pin + o.hres);
+        b.argmin = (int*)(B.dev + o.am); b.prior_ll = f(o.pl); b.prior_g = f(o.pg); b.fk = f(o.fk);
+        b.h_res0 = (float*)(B.pin + p_r0 + (o.r0 - r0_begin));
+        b.h_res1 = (float*)(B.pin + p_r1 + (o.r1 - r1_begin));
         b.terms = B.terms_d + (size_t)r * 3 * B.T_max;
         b.terms_h = B.terms_h + (size_t)r * 3 * B.T_max;
     }
-    // ---- pre-check of every row (run.py:24-29): mean residual of its FIRST frame against the threshold
+    // ---- set-up of every row in ONE launch: residual of the initial pose (the pre-check, run.py:24-29, reads its first frame),
+    // optimiser parameters, IMU orientations as axis-angle, joints and preserved landmarks (temporal_smplify.py:111-139)
+    SmplifyRowIO* io_h = (SmplifyRowIO*)(B.pin + p_io);
+    SmplifyRowIO* io_d = (SmplifyRowIO*)(B.dev + o_io);
     for (int r = 0; r < n_rows; ++r) {
         RowBuf& b = B.row[r];
         std::memset(&infos[r], 0, sizeof(infos[r]));
         std::memset(update_host[r], 0, (size_t)b.T);
-        SM_TRY(ctx, hipMemcpyAsync(b.Kd, b.K, 9 * sizeof(float), hipMemcpyHostToDevice, st));
-        rc_launch_residual(body, pose[r], tran[r], kp[r], b.Kd, 100.0f, B.ign, b.res0, b.T, st);
-        SM_TRY(ctx, hipMemcpyAsync(b.h_res, b.res0, (size_t)b.T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
+        SmplifyRowIO& io = io_h[r];
+        io.pose = pose[r]; io.tran = tran[r]; io.kp = kp[r]; io.imu_ori = imu_ori[r];
+        io.x = b.x; io.imu_aa = b.imu_aa; io.joint = b.joint; io.ref3d = b.ref3d; io.res0 = b.res0; io.res1 = b.res1;
+        io.pose_out = pose_out[r]; io.tran_out = tran_out[r];
+        for (int e = 0; e < 9; ++e) io.K[e] = b.K[e];
+        io.T = (int)b.T; io.live = 0;
     }
+    SM_TRY(ctx, hipMemcpyAsync(io_d, io_h, nr * sizeof(SmplifyRowIO), hipMemcpyHostToDevice, st));
+    rc_launch_smplify_begin_rows(io_d, n_rows, B.T_max, body, 100.0f, B.ign, st);
+    SM_TRY(ctx, hipMemcpyAsync(B.pin + p_r0, B.dev + r0_begin, r_bytes, hipMemcpyDeviceToHost, st));
     SM_TRY(ctx, hipStreamSynchronize(st));
     auto frame_mean = [](const float* v) {
         float acc = 0.0f;
@@ -1155,17 +1171,14 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     std::vector<int> live;
     for (int r = 0; r < n_rows; ++r) {
         RowBuf& b = B.row[r];
-        if (frame_mean(b.h_res) > loss_threshold) {
+        if (frame_mean(b.h_res0) > loss_threshold) {
             if (pose_out[r] != pose[r]) SM_TRY(ctx, hipMemcpyAsync(pose_out[r], pose[r], (size_t)b.T * 216 * sizeof(float), hipMemcpyDeviceToDevice, st));
             if (tran_out[r] != tran[r]) SM_TRY(ctx, hipMemcpyAsync(tran_out[r], tran[r], (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
             infos[r].status = 0;
             continue;
         }
         live.push_back(r);
-        rc_launch_R2aa(pose[r], b.x, b.T * 24, st);                       // temporal_smplify.py:111-139
-        SM_TRY(ctx, hipMemcpyAsync(b.x + b.T * 72, tran[r], (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        rc_launch_R2aa(imu_ori[r], b.imu_aa, b.T * 6, st);
-        rc_launch_body_fk(body, pose[r], tran[r], nullptr, b.joint, b.ref3d, b.T, st);
+        io_h[r].live = 1;
     }
     SM_TRY(ctx, hipStreamSynchronize(st));
     SM_TRY(ctx, hipGetLastError());
@@ -1210,13 +1223,11 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     if (B.herr != hipSuccess) return rc_ctx_fail(ctx, RC_ERR_HIP, (std::string("smplify batch: ") + hipGetErrorString(B.herr)).c_str());
     for (int r : live) if (!ok[r]) return rc_ctx_fail(ctx, RC_ERR_HIP, "smplify batch: a row's optimiser did not finish");
     const auto t_res = std::chrono::steady_clock::now();
-    // ---- results: rotations, residual after, per-frame update mask (run.py:31-34)
-    for (int r : live) {
-        RowBuf& b = B.row[r];
-        rc_launch_aa2R(b.x, pose_out[r], b.T * 24, st);
-        SM_TRY(ctx, hipMemcpyAsync(tran_out[r], b.x + b.T * 72, (size_t)b.T * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        rc_launch_residual(body, pose_out[r], tran_out[r], kp[r], b.Kd, 100.0f, B.ign, b.res1, b.T, st);
-        SM_TRY(ctx, hipMemcpyAsync(b.h_res + b.T * 33, b.res1, (size_t)b.T * 33 * sizeof(float), hipMemcpyDeviceToHost, st));
+    // ---- results in ONE launch: rotations, translation, residual after; then the per-frame update mask (run.py:31-34)
+    if (!live.empty()) {
+        SM_TRY(ctx, hipMemcpyAsync(io_d, io_h, nr * sizeof(SmplifyRowIO), hipMemcpyHostToDevice, st));
+        rc_launch_smplify_end_rows(io_d, n_rows, B.T_max, body, 100.0f, B.ign, st);
+        SM_TRY(ctx, hipMemcpyAsync(B.pin + p_r1, B.dev + r1_begin, r_bytes, hipMemcpyDeviceToHost, st));
     }
     SM_TRY(ctx, hipStreamSynchronize(st));
     SM_TRY(ctx, hipGetLastError());
@@ -1232,7 +1243,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     }
     for (int r : live) {
         RowBuf& b = B.row[r];
-        for (int64_t t = 0; t < b.T; ++t) update_host[r][t] = frame_mean(b.h_res + (b.T + t) * 33) < frame_mean(b.h_res + t * 33) ? 1 : 0;
+        for (int64_t t = 0; t < b.T; ++t) update_host[r][t] = frame_mean(b.h_res1 + t * 33) < frame_mean(b.h_res0 + t * 33) ? 1 : 0;
         infos[r].status = 1;
         infos[r].n_iter = res[r].n_iter;
         infos[r].n_eval = res[r].n_eval;

@@ -87,9 +87,10 @@ def test_shape_variant_matches_reference_capture(g, synth_assets):
         smplify_runner(pose, t(g["ev_tran"]), t(g["ev_kp"]), t(g["ev_imu_ori"]), T, t(g["ev_K"]), use_lbfgs=False, runner=r)
 
 
-@pytest.mark.parametrize("T,seed", [(1, 5), (2, 6), (37, 7)])
+@pytest.mark.parametrize("T,seed", [(1, 5), (2, 6), (37, 7), (150, 8)])
 def test_closure_matches_oracle(T, seed, synth_assets, runner):
-    """Seeded poses away from the capture, including T=1 (no temporal terms) and a ragged length."""
+    """Seeded poses away from the capture, including T=1 (no temporal terms), a ragged length, and one that spans three 64-frame
+    blocks of the prior kernel (the last one partly filled; several mixtures chosen across the frames)."""
     body = synth_assets["body"]
     obody, prior = O.OracleBody(body), S.Prior(synth.make_gmm(3))
     rnd = lambda stream, *shape: synth.normal(seed, stream, int(np.prod(shape))).reshape(shape).astype(np.float32)
