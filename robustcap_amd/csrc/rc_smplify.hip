@@ -182,11 +182,8 @@ __global__ __launch_bounds__(512) void rc_smplify_prior_rows_kernel(const Smplif
 // ============================================================================================== forward pass
 __device__ __forceinline__ void smplify_fwd_frame(const SmplifyArgs& A, const BodyConst* __restrict__ body_g, const int t) {
     __shared__ WaveScratch s;
-    __shared__ __attribute__((aligned(16))) BodyConst s_body;
     const int lane = threadIdx.x;
-    stage_body(&s_body, body_g, lane, 64);
-    __syncthreads();
-    const BodyConst* body = &s_body;
+    const BodyConst* body = body_g;     // (read through the L1: staging the 4.9 KB in LDS per one-wave workgroup cost more than it saved, 207 vs 200 us)
     const float* aa = A.aa + (long long)t * 72;
     const float tr[3] = {A.tran[t * 3], A.tran[t * 3 + 1], A.tran[t * 3 + 2]};
     frame_primal(body, s, aa, tr, lane);
