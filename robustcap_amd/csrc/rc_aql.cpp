@@ -34,14 +34,16 @@ struct AqlChain {
 namespace {
 constexpr size_t kKargStride = 2048;
 
-struct FindAgent { uint32_t bdf; int count = 0; hsa_agent_t first{}, match{}; bool have_match = false; };
+struct FindAgent { uint32_t bdf; uint32_t domain = 0; int count = 0; hsa_agent_t first{}, match{}; bool have_match = false; };
 hsa_status_t agent_cb(hsa_agent_t a, void* d) {
     FindAgent* f = (FindAgent*)d;
     hsa_device_type_t t;
     if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
     if (f->count++ == 0) f->first = a;
-    uint32_t bdf = 0;
-    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS && bdf == f->bdf && !f->have_match) {
+    uint32_t bdf = 0, dom = 0;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) dom = f->domain;   // (older runtimes: bus / device / function only)
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS && bdf == f->bdf && dom == f->domain &&
+        !f->have_match) {
         f->match = a; f->have_match = true;
     }
     return HSA_STATUS_SUCCESS;
@@ -93,13 +95,13 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
     if (st != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_init", st);
     c->hsa_up = true;
     c->n = n;
-    // the HSA agent of the HIP device: by PCI bus / device / function
+    // the HSA agent of the HIP device: by PCI domain / bus / device / function (an 8-GPU node may repeat bus numbers across domains)
     FindAgent fa{};
     {
         char bus[64] = {0};
         unsigned dom = 0, b = 0, dv = 0, fn = 0;
         if (hipDeviceGetPCIBusId(bus, sizeof(bus), hip_device) == hipSuccess && std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &dv, &fn) == 4)
-            fa.bdf = (b << 8) | (dv << 3) | fn;
+            { fa.bdf = (b << 8) | (dv << 3) | fn; fa.domain = dom; }
         else fa.bdf = 0xffffffffu;
     }
     if ((st = hsa_iterate_agents(agent_cb, &fa)) != HSA_STATUS_SUCCESS || fa.count == 0) return bail(c, err, err_len, "no GPU agent", st);
