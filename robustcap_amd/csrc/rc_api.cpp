@@ -146,6 +146,7 @@ struct rc_ctx {
     int seq_min_frames = 8;              // calls shorter than this are neither planned nor skewed (no pre-pass, no synchronisation)
     float* x1_alt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second relu(linear1) buffer per net
     int tile6[2] = {0, 0}, tile378[2] = {0, 0}, tile2[2] = {0, 0}, tile4[2] = {0, 0};   // LSTM tile shapes of full-batch stages (0 = pick_tile)
+    bool ring2_failed = false;           // ensure_wave2_buffers failed once: not retried
     bool seq_two_streams = true;         // tuning: per-row kernels + linear2 on the second stream (else everything on the caller's)
     hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
     hipStream_t h512_stream = nullptr;   // the tick's {H = 512 nets, linear1} launch, beside the {rnn6, rnn4} launch on the caller's stream
@@ -689,8 +690,7 @@ void plan_wave(const signed char* codes, int B, int T, int t0, const int* first_
     for (int i = 0; i < n_frames; ++i) P.est_stepped_us += cost[2] + (tr_frame[i] ? cost[3] : 0.0);
 }
 
-int ensure_wave2_buffers(rc_ctx* ctx) {
-    if (ctx->ring2_ready) return RC_OK;
+static int ensure_wave2_buffers_once(rc_ctx* ctx) {
     const size_t B = (size_t)ctx->B, Bp = (size_t)ctx->Bp;
     for (int s = 0; s < kRing; ++s) {
         FrameBuffers f = ctx->fb;                      // state pointers are shared; the per-frame buffers get their own slot
@@ -729,6 +729,17 @@ int ensure_wave2_buffers(rc_ctx* ctx) {
     ctx->ring2_ready = true;
     ctx->wave2_valid = false;
     return RC_OK;
+}
+
+// Ring slots, the two extra streams and the hand-over events of the wavefront engine: allocated once. A failure half-way (out of memory)
+// is final for the context: the slots already allocated stay owned by it (rc_destroy frees them) and later calls report the error
+// instead of allocating all 16 slots and the streams a second time on top of the partial set.
+int ensure_wave2_buffers(rc_ctx* ctx) {
+    if (ctx->ring2_ready) return RC_OK;
+    if (ctx->ring2_failed) return fail(ctx, RC_ERR_STATE, "wavefront engine: its buffers could not be allocated earlier (out of memory?)");
+    const int rc = ensure_wave2_buffers_once(ctx);
+    if (rc != RC_OK) ctx->ring2_failed = true;
+    return rc;
 }
 
 // GEMM problems of every ring slot: problem q (kTick order, then the three init_net layers) working on slot sl. Rows come from
@@ -793,7 +804,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // the plan's table: frame every row starts at every tick
     const size_t need = (size_t)P.n_prep * B;
     if (need > ctx->frame_at_cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(st));                             // nothing in flight may still read the old table
+        HIP_TRY(ctx, hipDeviceSynchronize());                               // nothing in flight (on any of the engine's streams) may still read the old table
         if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
         if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
         ctx->frame_at_d = nullptr; ctx->frame_at_h = nullptr; ctx->frame_at_cap = 0;
