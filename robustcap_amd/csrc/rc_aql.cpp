@@ -25,6 +25,11 @@ struct AqlChain {
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};
     char* kargs = nullptr;                       // device memory: n blocks of kKargStride bytes
+    // completion by a word the last kernel stores itself (one row; RC_LIVE_DONE_FLAG=0 switches it off): the sequence number of the frame
+    unsigned* flag_h = nullptr;                  // pinned host word (the device sees the same address)
+    unsigned* seq_d = nullptr;                   // device counter of frames
+    unsigned seq = 0;                            // frames submitted
+    long long sig0 = 0;                          // value of `done` before any frame: every retired frame decrements it
     hsa_kernel_dispatch_packet_t pkt[RC_LIVE_KERNELS]{};
     uint16_t hdr[RC_LIVE_KERNELS]{};
     int n = 0;
@@ -123,7 +128,8 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
     }
     if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
         return bail(c, err, err_len, "hsa_queue_create", st);
-    if ((st = hsa_signal_create(0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    c->sig0 = 1ll << 40;
+    if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
     // kernel arguments: device memory, written once (a frame's inputs arrive at fixed pinned addresses)
     std::vector<char> host((size_t)n * kKargStride, 0);
     if (hipMalloc((void**)&c->kargs, host.size()) != hipSuccess) return bail(c, err, err_len, "kernarg buffer");
@@ -134,9 +140,17 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
         const int lstm[4] = {1, 2, 4, 5};
         for (int q = 0; q < 4; ++q) hot[q] = reinterpret_cast<LiveGrid*>(c->kargs + (size_t)lstm[q] * kKargStride + sizeof(LiveFrame));
     }
+    static const bool flag_env = [] { const char* e = std::getenv("RC_LIVE_DONE_FLAG"); return !e || std::atoi(e) != 0; }();
+    if (flag_env && n == RC_LIVE_KERNELS && k[0].F.B == 1) {
+        if (hipHostMalloc((void**)&c->flag_h, 64, hipHostMallocDefault) != hipSuccess) return bail(c, err, err_len, "completion word");
+        *c->flag_h = 0;
+        if (hipMalloc((void**)&c->seq_d, 64) != hipSuccess || hipMemset(c->seq_d, 0, 64) != hipSuccess) return bail(c, err, err_len, "frame counter");
+    }
     for (int i = 0; i < n; ++i) {
         LiveFrame F = k[i].F;
         for (int q = 0; q < 4; ++q) F.hot[q] = hot[q];
+        F.done_flag = (i == n - 1) ? c->flag_h : nullptr;
+        F.done_seq = (i == n - 1) ? c->seq_d : nullptr;
         std::memcpy(&host[(size_t)i * kKargStride], &F, sizeof(LiveFrame));
         if (k[i].has_grid) {
             LiveGrid G = k[i].G;
@@ -170,8 +184,8 @@ int rc_aql_run(AqlChain* c) {
     if (!c || !c->q) return -1;
     hsa_queue_t* q = c->q;
     const uint32_t mask = q->size - 1;
-    hsa_signal_store_relaxed(c->done, 1);
-    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; the queue is empty (every run waits)
+    // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; at most the retirement of the previous frame is pending
     for (int i = 0; i < c->n; ++i) {
         hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & mask);
         // body first, header (which hands the packet to the packet processor) last
@@ -180,20 +194,32 @@ int rc_aql_run(AqlChain* c) {
     }
     hsa_queue_store_write_index_release(q, base + c->n);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + c->n - 1));
+    const unsigned seq = ++c->seq;
+    const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)seq);
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
-    while (hsa_signal_load_scacquire(c->done) != 0) {
+    for (;;) {
+        if (c->flag_h ? (__atomic_load_n(c->flag_h, __ATOMIC_ACQUIRE) == seq) : (hsa_signal_load_scacquire(c->done) == retired)) break;
         if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
             // a frame is ~100 us: something is slow (profiler, contention) -- sleep on the signal, give up after 10 s
-            if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, 0, 10000000000ull, HSA_WAIT_STATE_BLOCKED) != 0) return -2;
+            if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, retired, 10000000000ull, HSA_WAIT_STATE_BLOCKED) != retired) return -2;
             break;
         }
     }
     return 0;
 }
 
+// the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
+static void aql_drain(AqlChain* c) {
+    if (!c || !c->q || c->seq == 0) return;
+    (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, (hsa_signal_value_t)(c->sig0 - (long long)c->seq), 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+}
+
 void rc_aql_destroy(AqlChain* c) {
     if (!c) return;
+    aql_drain(c);
+    if (c->flag_h) (void)hipHostFree(c->flag_h);
+    if (c->seq_d) (void)hipFree(c->seq_d);
     if (c->q) (void)hsa_queue_destroy(c->q);
     if (c->done.handle) (void)hsa_signal_destroy(c->done);
     if (c->kargs) (void)hipFree(c->kargs);

@@ -200,6 +200,8 @@ struct LiveFrame {
     const BodyConst* body;
     int* status;                    // device word, set != 0 when a frame the lean plan does not cover reached it (init_net trigger)
     LiveGrid* hot[4];               // AQL path: the LiveGrid argument blocks of K2, K3 (written by K1) and K5, K6 (by K4); else null
+    unsigned* done_flag;            // AQL path, one row: pinned host word K7 stores the frame's sequence number to, behind a system-scope
+    unsigned* done_seq;             // release, when everything of the frame is written (device counter of frames); else null
     int B;
     int nc;                         // 16-column blocks per LSTM tile (1 or 2)
 };

@@ -508,6 +508,16 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) 
     RC_LT(2, 2);
     if (tid >= 64) return;
     tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub, &tr);
+    // AQL path, one row: tell the host the frame is complete from HERE -- every write of the frame is behind this point; the host then does
+    // not wait for the packet processor to retire the dispatch, run its release fence and write the completion signal (rc_aql.cpp).
+    if (F.done_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                     // system scope: this wave's stores (the only wave left) are visible
+        if (lane == 0) {
+            const unsigned seq = *F.done_seq + 1u;
+            *F.done_seq = seq;
+            __hip_atomic_store(F.done_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // (plain names: the AQL path of rc_aql.cpp finds the kernels by symbol)

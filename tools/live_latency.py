@@ -5,7 +5,8 @@ host tensors out). Prints one JSON line:
                 configuration: steady-state frames on the lean seven-launch capture, the rest on the frame-stepped captures)
   graph         the same through Net.forward_online (Python surface)
   eager         Net.forward_online without use_graph (rc_step)
-  variants      C-ABI p50/p99 under environment switches (RC_LIVE_LEAN=0: round 3's plan, RC_LIVE_LEAN_NC=2, RC_LIVE_EAGER=1)
+  variants      C-ABI p50/p99 under environment switches (RC_LIVE_LEAN=0: round 3's plan, RC_LIVE_LEAN_NC=2, RC_LIVE_AQL=0: hipGraph replay,
+                RC_LIVE_DONE_FLAG=0: completion by the queue's signal instead of the word the last kernel stores, RC_LIVE_EAGER=1)
     python tools/live_latency.py [frames=10000] [conf=mixed] [variants=1]"""
 import json
 import os
@@ -102,7 +103,7 @@ def main():
         del net
     if variants:
         out["variants"] = {}
-        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}), ("lean_edge_agent", {"RC_AQL_EDGE_SCOPE": "agent"}),
+        for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}), ("lean_signal", {"RC_LIVE_DONE_FLAG": "0"}), ("lean_edge_agent", {"RC_AQL_EDGE_SCOPE": "agent"}),
                           ("lean_direct_launches", {"RC_LIVE_EAGER": "1"}), ("lean_again", {})):
             net = make(sd, body, m, env=env)
             out["variants"][name] = stats(run_c(net, m, min(n, 4000)))
