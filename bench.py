@@ -115,12 +115,23 @@ def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=C
     for i in range(1, 1 + frames_single):
         one.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
     dt_1 = time.perf_counter() - t0
+    # the same on ONE thread ({1 thread, all threads}); a handful of frames, the thread count restored afterwards
+    n_1t = max(1, min(8, frames_single))
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        for i in range(1, 1 + n_1t):
+            one.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+        dt_1t = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
     return {"value": round(float(np.median(rates)), 1), "unit": "body-frames/s", "cores": threads, "kind": "port",
             "samples": len(rates), "min": round(min(rates), 1), "max": round(max(rates), 1),
+            "batch1_all_threads": round(frames_single / dt_1, 1), "batch1_one_thread": round(n_1t / dt_1t, 1),
             "sample": f"oracle (torch CPU, oneDNN LSTM) batched B={B} x {frames_batched} frames, median of {len(rates)} samples "
                       f"({', '.join('%.1fs' % x for x in secs)}); "
                       f"batch-1 frame-by-frame like evaluate.py: {frames_single / dt_1:.1f} body-frames/s "
-                      f"({frames_single} frames = {dt_1:.1f}s); nproc={os.cpu_count()}"}
+                      f"({frames_single} frames = {dt_1:.1f}s), on one thread {n_1t / dt_1t:.1f} ({n_1t} frames = {dt_1t:.1f}s); nproc={os.cpu_count()}"}
 
 
 def guarded(fn, *a, **k):
