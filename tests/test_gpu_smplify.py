@@ -226,6 +226,40 @@ def test_batched_rows_equal_one_row_at_a_time(runner, synth_assets):
     assert 20 <= info[0]["rounds"] <= 60                                   # lock-step: rounds of the longest row, not their sum
 
 
+_SCHED_SCRIPT = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tools"))
+import torch
+import smplify_bench as sb
+from robustcap_amd import synth
+from robustcap_amd.smplify import TemporalSMPLify
+body = synth.make_body(1)
+runner = TemporalSMPLify(body=body, gmm=synth.make_gmm(3))
+rows = [sb.make_case(runner, body, T, seed=seed) for seed, T in ((11, 64), (23, 100), (31, 37))]
+out = runner.run_batch(rows, lr=0.001)
+h = hashlib.sha256()
+for p, tr, upd in out:
+    h.update(p.cpu().numpy().tobytes()); h.update(tr.cpu().numpy().tobytes()); h.update(upd.numpy().tobytes())
+print(json.dumps({"sha": h.hexdigest(), "info": [[i["n_iter"], i["n_eval"], i["final_loss"]] for i in runner.last_batch_info]}))
+"""
+
+
+def test_rows_as_fibers_equal_rows_as_threads():
+    """rc_smplify_run_batch drives every row's optimiser as a fiber of the caller's thread (makecontext / swapcontext); RC_SMPLIFY_THREADS=1
+    selects a host thread per row instead. Same requests in the same rounds: outputs and optimiser records bitwise equal."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    res = []
+    for threads in ("0", "1"):
+        env = dict(os.environ, RC_SMPLIFY_THREADS=threads)
+        r = subprocess.run([sys.executable, "-c", _SCHED_SCRIPT, root], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
+    assert all(i[1] >= 20 for i in res[0]["info"])
+
+
 def test_runner_gate_and_errors(g, runner, synth_assets):
     from robustcap_amd import _lib
     from robustcap_amd.smplify import TemporalSMPLify, smplify_runner
