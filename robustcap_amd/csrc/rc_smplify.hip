@@ -9,13 +9,13 @@
 // Here: parameters x = [T, 72 axis-angle + 3 translation]. Three kernels per evaluation:
 //   rc_smplify_prior_kernel GMM pose prior of 64 frames per workgroup (lane = frame, wave = mixture): value, argmin, gradient rows
 //   rc_smplify_fwd_kernel   one workgroup per frame; primal: rotations, FK, 33 landmarks, projection, per-frame loss terms
-//   rc_smplify_grad_kernel  wave 0 forms the adjoint lambda = dL/d(landmark) of its frame (incl. the smoothness terms
-//                           that couple it to frames t-1 and t+1) and contracts it with the constant skinning data
-//                           into per-joint co-factors; 72 threads then push one TANGENT each (d/d axis-angle
-//                           component) through Rodrigues and the kinematic chain (only the descendants of the joint
-//                           move) and dot it with the co-factors -- forward-mode through the tree, reverse-mode
-//                           through everything after it. ~2 MFLOP per frame per evaluation; HBM traffic is the 75
-//                           parameters in, 75 gradients out and ~1.5 KB of landmarks per frame.
+//   rc_smplify_grad_kernel  one workgroup per frame, on the forward kernel's primal (rotations, landmarks): the adjoint lambda = dL/d(landmark)
+//                           of the frame (incl. the smoothness terms that couple it to frames t-1 and t+1), contracted with the constant
+//                           skinning data into per-joint co-factors, pulled from the leaves of the kinematic tree to the root (one pass by
+//                           tree level over child lists), and dotted with dRl/d(axis-angle component) per joint -- reverse mode throughout
+// and, for a batch of rows (rc_smplify_run_batch), one launch each for set-up (residual of the initial pose, R -> axis-angle, joints and
+// preserved landmarks) and wrap-up (axis-angle -> R, residual after). HBM traffic per frame and evaluation: 75 parameters in, 75 gradients
+// out, ~4 KB of primal (rotations, landmarks, projections) written by the forward kernel and read by the gradient kernel.
 #include "rc_device.h"
 
 #define SM_SIGMA 100.0f

@@ -432,17 +432,17 @@ int minimize_on_device(rc_ctx* ctx, SmplifyState* s, const BodyConst* body, cons
 // evaluate.py:86-90 refines the (sequence, camera) rows of an evaluation one after another; they are independent optimisation
 // problems. Round 3 drove them from host threads, one context and stream each: ~300 HIP calls per row contend for the runtime,
 // 72 rows of 600 frames took 0.19-0.23 s however many threads ran. Here every row's optimiser (the algorithm of
-// minimize_on_device, unchanged, on a host thread of its own) hands its next device request -- "evaluate the closure at x + t d
+// minimize_on_device, unchanged, as a fiber of the caller's thread -- a stack of its own, see RowBatch::fibers) hands its next device request -- "evaluate the closure at x + t d
 // into gradient slot k", or "form the curvature pair and these inner products" -- to ONE executor; when every live row has asked,
 // the executor runs all requests with one launch per kind over all rows (descriptor tables in device memory, the row from
-// blockIdx.y), one read-back, one synchronisation, and wakes the rows. A round costs what its largest kernel costs; per row the
+// blockIdx.y), one read-back, one synchronisation, and resumes the rows. A round costs what its largest kernel costs; per row the
 // arithmetic is the same chain of operations as alone, so n_iter / n_eval / losses are those of the one-row-at-a-time run.
 struct RowBuf {                       // device vectors of one row (carved from the batch's arena)
     int64_t T = 0;
     size_t n = 0;                     // 75 T
     int nb = 0;                       // 4,096-element blocks of a vector
     float *x = nullptr, *xt = nullptr, *dir = nullptr, *gslot = nullptr, *Sv = nullptr, *Yv = nullptr;
-    float *ref3d = nullptr, *imu_aa = nullptr, *mj = nullptr, *proj = nullptr, *joint = nullptr, *res0 = nullptr, *res1 = nullptr, *Kd = nullptr;
+    float *ref3d = nullptr, *imu_aa = nullptr, *mj = nullptr, *proj = nullptr, *joint = nullptr, *res0 = nullptr, *res1 = nullptr;
     float* terms = nullptr;           // [3 T] frame | imu | smooth, device (inside the terms arena)
     const float* terms_h = nullptr;   // the same region of the pinned copy
     int* argmin = nullptr;
