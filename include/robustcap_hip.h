@@ -180,7 +180,10 @@ int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames);
 int rc_get_live_profile(rc_ctx* ctx, double* avg_us4);
 /* What rc_live_step uses for steady-state frames after rc_live_begin: *lean_captured = the seven-launch capture exists;
  * *aql = its dispatches are pre-built AQL packets on an HSA queue of the context's own (csrc/rc_aql.cpp: ~0.5 us of host time per
- * frame instead of hipGraphLaunch's ~7 us; RC_LIVE_AQL=0 switches it off); note: why not, when it is not (may be NULL). */
+ * frame instead of hipGraphLaunch's ~7 us; RC_LIVE_AQL=0 switches it off); note: why not, when it is not (may be NULL). With one row the
+ * last kernel of the chain stores the frame's sequence number to a pinned host word once every write of the frame is released at system
+ * scope, and rc_live_step returns on that word (RC_LIVE_DONE_FLAG=0: on the queue's completion signal) -- outputs and the context's device
+ * state are complete either way; rc_live_end / rc_destroy wait for the queue itself to drain. */
 int rc_get_live_backend(rc_ctx* ctx, int32_t* lean_captured, int32_t* aql, char* note, int32_t note_len);
 
 /* ---- per-op entry points (tests, harness; each a single kernel) ------------------------------------------ */
