@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line (metric, value, ..., roofline, cpu_baseline). The K-
 (default 5; every repetition = reset + W warm-up frames + K timed frames between barrier + synchronize) and ``value`` /
 ``ms_per_step`` are those of the MEDIAN repetition (``timing`` carries min / max). ``variants`` carries the other
 configurations of BASELINE.json on the same box: ``high`` (all-visible, same K), ``fp32_mfma``, ``mixed_long`` /
-``high_long`` (256 frames per call whatever --steps is: the wavefront engine's steady state), ``occ1024`` (config 4) and
+``high_long`` (512 frames per call whatever --steps is: configs[1]'s own T, the wavefront engine's steady state), ``occ1024`` (config 4) and
 ``live_b1`` (config 5: p50 / p99 of the captured batch-1 frame; ``graph_replay`` = the same capture through hipGraphLaunch). The roofline pass and the side legs are guarded: a
 failure there is recorded as {"error": ...} and the line is still printed.
 """
@@ -42,7 +42,7 @@ from robustcap_amd import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA (16x16x4 / 32x32x2), dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA; the split kernel issues 6 bf16 MFMAs per fp32-equivalent product
-LONG_FRAMES = 256                      # frames per call of the *_long variants
+LONG_FRAMES = 512                      # frames per call of the *_long variants: the T of BASELINE configs[1]
 PRODUCTS_SPLIT = ("fp32 operands split exactly into 3 bf16 terms each; every product = 6 partial products on "
                   "v_mfma_f32_16x16x32_bf16 (all terms >= 2^-16 of the product), fp32 accumulation, fp32 gates / state")
 PRODUCTS_FP32 = "v_mfma_f32_16x16x4_f32 (fp32 operands, an fma chain per output element)"
@@ -239,35 +239,35 @@ class Workload:
         # duration covers time in which the other one holds part of the CUs. The kernel's rate is its FLOPs over the time during
         # which it runs at all (union of the launch intervals); the per-launch figure is kept beside it (it is what a rocprofv3
         # kernel summary shows: avg_launch_us there = avg_launch_us here).
-        ach = flop_per_launch * launches / (busy_ms * 1e-3) / 1e12
-        ach_launch = flop_per_launch / avg_s / 1e12
+        ach_union = flop_per_launch * launches / (busy_ms * 1e-3) / 1e12
+        ach = flop_per_launch / avg_s / 1e12
         path = bodies_total * K * C.FLOPS_PER_BODY_FRAME / dt / 1e12 / self.world
         traffic, src = pmc_traffic(B, self.conf, K)
         issued_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if self.split else PEAK_FP32_MFMA_TFLOPS
         wave, stepped, ticks = net.sequence_stats()
-        return {"bound": "mfma", "kernel": "rc_gemm_split_kernel" if self.split else "rc_gemm_kernel", "achieved": round(ach, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "peak_issued": round(issued_peak, 1), "frac_issued": round(ach / issued_peak, 4),
+        return {"bound": "mfma", "kernel": net.gemm_kernel_name(), "achieved": round(ach, 2),
+                "peak": round(issued_peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / issued_peak, 4), "frac_per_launch": round(ach / issued_peak, 4),
+                "peak_fp32_input": PEAK_FP32_MFMA_TFLOPS, "frac_fp32_roof": round(ach_union / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic,
                 "traffic_note": (f"fabric-side L2 miss bytes per gate-GEMM launch, rocprofv3 PMC pass of this batch/schedule "
                                  f"(profiles/{src})" if src else
                                  "no PMC pass committed for this batch / schedule / frames per call (profiles/*pmc_traffic*.json are keyed by all three)"),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches, "launches_per_step": round(launches / K, 2),
                 "busy_ms": round(busy_ms, 3), "concurrency": round(ms / busy_ms, 3),
-                "per_launch": {"achieved": round(ach_launch, 2), "frac": round(ach_launch / PEAK_FP32_MFMA_TFLOPS, 4),
-                               "frac_issued": round(ach_launch / issued_peak, 4)},
+                "union": {"achieved": round(ach_union, 2), "frac": round(ach_union / issued_peak, 4)},
                 "flop_per_launch": flop_per_launch,
-                "path_achieved": round(path, 2), "path_frac": round(path / PEAK_FP32_MFMA_TFLOPS, 4),
+                "path_achieved": round(path, 2), "path_frac": round(path / issued_peak, 4),
                 "products": PRODUCTS_SPLIT if self.split else PRODUCTS_FP32,
                 "engine": {"wavefront_frames": wave, "frame_stepped_frames": stepped, "ticks": ticks},
-                "note": "frac: the wide-tile gate-GEMM kernel alone (its algorithmic fp32 FLOPs / the HIP-event time during which at "
-                        "least one of its launches runs: the engine's two launches of a tick overlap on two streams, concurrency = sum "
-                        "of the launch durations / that time; per_launch = the same FLOPs over each launch's own duration) against the "
-                        "dense fp32-input MFMA peak, the peak of the type the path computes in; frac_issued: the same rate against "
-                        "the roof of the instructions the kernel actually issues (split mode: dense bf16 MFMA peak / 6 partial "
-                        "products = 416.7 TFLOP/s fp32-equivalent) -- the figure to read as MFMA utilisation; path_frac: whole "
-                        "frame incl. the weight-streaming 16-row launches and the per-frame logic kernels"}
+                "note": "achieved: the algorithmic fp32 FLOPs of one wide-tile gate-GEMM launch / the average HIP-event duration of such a "
+                        "launch (avg_launch_us: what a rocprofv3 --kernel-trace --stats summary of the same command shows for the kernel); "
+                        "peak: the roof of the instructions the kernel issues (split mode: dense bf16 MFMA peak / 6 partial products = "
+                        "416.7 TFLOP/s fp32-equivalent; fp32 mode: the 157.3 TFLOP/s fp32-input MFMA peak); frac = achieved / peak, the "
+                        "figure to read as MFMA utilisation. union: the same FLOPs over the time during which at least one such launch "
+                        "runs (launches on two streams overlap: concurrency = sum of the launch durations / that time); frac_fp32_roof: "
+                        "the union rate against the fp32-input roof (rounds 1-4 quoted it as frac; it may exceed 1 in split mode); "
+                        "path_frac: whole frame incl. the weight-streaming 16-row launches and the per-frame logic kernels, against peak"}
 
 
 def self_launch(n):

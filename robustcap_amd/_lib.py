@@ -55,6 +55,7 @@ SIGNATURES = {
     "rc_default_gemm_mode": (_I32, [_I32]),
     "rc_set_sequence_mode": (_I32, [_P, _I32, _I32]),
     "rc_get_sequence_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
+    "rc_get_launch_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "rc_plan_sequence": (_I32, [_P, _I32, _I32, _P, _U32, _I32, _P]),
     "rc_plan_wave": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I64, C.POINTER(_I32), C.POINTER(_I32), _P, _P]),
     "rc_live_begin": (_I32, [_P]),
@@ -123,7 +124,10 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RobustcapLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    ab_build = bool(os.environ.get("RC_LIB_PATH"))     # an A/B build of another revision (tools/ab.py) may lack the newest entry points
     for name, (res, args) in SIGNATURES.items():
+        if ab_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)            # AttributeError here = header / library mismatch: fail loudly
         fn.restype, fn.argtypes = res, args
     _lib = lib

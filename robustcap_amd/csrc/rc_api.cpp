@@ -169,6 +169,15 @@ struct rc_ctx {
                                                          // per-layer tick estimate, hand-over per tick, frame-stepped frame, its transition launches
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
+    // one launch per tick (rc_gemm_tick_kernel): problem tables of a planned call and the per-tick queue counters
+    int seq_tick = 0;                    // RC_SEQ_TICK: 1 = one launch per tick on resident workgroups (built and measured in round 5: 9-13 % slower
+                                         // than the two wide launches per tick, profiles/r05_tick_notes.txt; off by default)
+    int tick_grid = 248;                 // RC_TICK_GRID: resident workgroups of a tick launch (the rest of the 256 CUs serve the per-row kernels)
+    TickTable* tick_tab_d = nullptr;     // [tick_cap]
+    TickTable* tick_tab_h = nullptr;     // pinned
+    int* tick_queue_d = nullptr;         // [tick_cap][8 queues][16 ints]
+    size_t tick_cap = 0;
+    long long stat_tick_launches = 0, stat_wide_launches = 0;
 };
 
 namespace {
@@ -428,6 +437,7 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     }
     L.n = (int)ordered.size();
     ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
+    if (!rc_gemm_is_small(L)) ctx->stat_wide_launches += 1;
     if (ctx->timing && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
         if (ctx->ev_used == ctx->ev_pool.size()) {
             hipEvent_t a, b;
@@ -794,6 +804,8 @@ inline int w2_group(int q, bool merge_h512, bool merge_big) {
     return g;
 }
 
+int reserve_tick_tables(rc_ctx* ctx, size_t n_ticks);
+
 int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0, int t_last, hipStream_t st) {
     if (int rc = ensure_wave2_buffers(ctx)) return rc;
     if (!ctx->wave2_valid) if (int rc = build_wave2_problems(ctx)) return rc;
@@ -832,13 +844,20 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // calls 862k -> 917k, fp32 MFMA 662k -> 725k, batch 1024 970k -> 1,012k, 128: 613k -> 631k, 64: 398k -> 418k; batch 32: 329k ->
     // 299k, 16: 214k -> 178k (a tick there is launch latency, and a third stream adds two hand-overs to it): from 48 rows.
     static const int split_main_env = tune_env("RC_SEQ_SPLIT_MAIN", -1);      // 0 / 1 force, default: by batch
-    const bool split_main = (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 && merge_big &&
-                            !merge_fill && ext_events;
+    // Round 5, one launch per tick: every wide problem of a tick (all of them 64 x 128 split-product tiles in the steady state) in ONE
+    // launch of resident workgroups that pull tiles from per-XCD queues and request the next tile's operands behind the current
+    // tile's last MFMA (rc_gemm.hip: rc_gemm_tick_kernel). The launch reads its problem table from device memory: the tables of all
+    // ticks of the call are built here, before the first tick, and uploaded in one copy. Ticks with another tile shape in them (few
+    // rows: transition / init_net problems, lagging rows only) or with fewer tiles than CUs take the launches below.
+    const bool tick_mode = ctx->seq_tick && ctx->gemm_split && two && merge_h512 && merge_big && !merge_fill && ext_events &&
+                           B <= 256 * RC_TICK_CH;
+    const bool split_main = !tick_mode && (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 &&
+                            merge_big && !merge_fill && ext_events;
     hipStream_t s2 = ctx->h512_stream;
     // 64-row tile shapes of the wide launches. With both launches of a tick on one stream rnn4 ran best on 64 x 80 tiles (256 tiles
     // per layer = whole rounds of the 256 CUs); on two streams the other launch fills what a round leaves idle and the 64 x 128 tile's
     // 13 % fewer operand bytes per MFMA win: mixed 512 frames 1,030k -> 1,120k, all-visible 1,208k -> 1,258k, batch 1024 999k -> 1,088k
-    int t4[2] = {4, split_main ? 8 : 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
+    int t4[2] = {4, (split_main || tick_mode) ? 8 : 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
@@ -846,7 +865,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // 64 -> 33 rows: batch 80 486k -> 519k -> 541k body-frames/s, batch 128 638k -> 773k -> 787k (the rnn4 / rnn6 problems of a mixed
     // batch have 60-127 rows), batch 256 and 1024 unchanged: a half-filled 64-row tile still halves the weight bytes of two 32-row tiles
     static const int tile64_rows = tune_env("RC_SEQ_TILE64_ROWS", 33);
-    auto collect = [&](int k, int g) -> std::vector<GemmProblem> {            // problems of group g with rows at tick k
+    auto collect = [&](int k, int g, bool allow_narrow = true) -> std::vector<GemmProblem> {   // problems of group g with rows at tick k
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
             const int q = (merge_big && qi < 4) ? (qi ^ 2) : qi;               // rnn6 (kTick 2, 3) in front of rnn4 (0, 1): longest tiles first
@@ -893,7 +912,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         }
         // Filling and draining ticks (and ticks of lagging rows) carry fewer problems per launch: when the launch would leave
         // half of the CUs without a tile, the 64 x 128 tiles are cut to 64 x 64 (twice the tiles, half as long each).
-        if (g < 4 && narrow_fill) {
+        if (g < 4 && narrow_fill && allow_narrow) {
             int total = 0;
             for (const GemmProblem& p : ps) total += p.n_tiles * p.m_tiles;
             if (total > 0 && total <= 128)
@@ -905,6 +924,58 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {
         return launch_problems(ctx, collect(k, g), nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
     };
+    std::vector<unsigned char> tick_ok((size_t)P.n_ticks, 0);
+    if (tick_mode) {
+        static const int min_tiles = tune_env("RC_TICK_MIN_TILES", 129);          // fewer: a tile per CU at most, nothing to hand over
+        static const int max_tiles = tune_env("RC_TICK_MAX_TILES", 1 << 30);      // (A/B: one launch only for the filling / draining ticks)
+        if ((size_t)P.n_ticks > ctx->tick_cap) {
+            HIP_TRY(ctx, hipDeviceSynchronize());                                  // nothing in flight may still read the old tables
+            if (int rc = reserve_tick_tables(ctx, (size_t)P.n_ticks)) return rc;
+        }
+        bool any = false;
+        for (int k = 0; k < P.n_ticks; ++k) {
+            std::vector<GemmProblem> all;
+            for (int g = 0; g <= last_group; ++g) {
+                std::vector<GemmProblem> v = collect(k, g, false);
+                all.insert(all.end(), v.begin(), v.end());
+            }
+            bool ok = !all.empty() && (int)all.size() <= RC_TICK_MAXP;
+            long long tiles = 0;
+            for (const GemmProblem& p : all) {
+                const bool relu4 = p.epi == RC_EPI_RELU && p.out_packed && p.out_bit == 0 && ((p.out_col0 | p.N) & 3) == 0;
+                ok = ok && p.mr == 4 && p.nc == 8 && (p.epi == RC_EPI_LSTM || relu4) && p.open_step == 0 && p.Kp % 128 == 0;
+                tiles += (long long)p.n_tiles * p.m_tiles;
+            }
+            if (!ok || tiles < min_tiles || tiles > max_tiles) continue;
+            // longest tiles first (K' = 2560 rnn4, 2048 rnn6, 1024 the H = 512 nets, 128 / 256 linear1): the queues end on short tiles
+            std::stable_sort(all.begin(), all.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.Kp > b.Kp; });
+            TickTable& T = ctx->tick_tab_h[k];
+            T.n_prob = (int)all.size();
+            T.trace_base = ctx->trace_next;
+            T.pad_ = 0;
+            int base = 0;
+            for (int q = 0; q < RC_TICK_MAXP + 4; ++q) T.item_base[q] = 0x7fffffff;
+            for (size_t q = 0; q < all.size(); ++q) {
+                GemmProblem p = all[q];
+                p.wg_base = base;
+                // (the kernel requests flag / select / step words of every problem, used or not: a valid array behind each)
+                if (!p.flags) { p.flags = ctx->ring2[0].flags2; p.flag_bit = 0; }
+                if (!p.sel_flags) { p.sel_flags = ctx->ring2[0].flags2; p.sel_bit = 0; }
+                if (!p.steps) p.steps = ctx->net[0].steps;
+                T.item_base[q] = base;
+                T.p[q] = p;
+                base += round_up(p.n_tiles * p.m_tiles, 8);
+            }
+            T.n_items = base;
+            ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
+            tick_ok[k] = 1;
+            any = true;
+        }
+        if (any) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->tick_tab_d, ctx->tick_tab_h, (size_t)P.n_ticks * sizeof(TickTable), hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->tick_queue_d, 0, (size_t)P.n_ticks * 128 * sizeof(int), st));
+        }
+    }
     WavePrep wp{};
     for (int i = 0; i < 6; ++i) wp.steps[i] = ctx->net[i].steps;
     wp.cx4l = ctx->fb.x4l; wp.cx6l = ctx->fb.x6l;
@@ -946,14 +1017,36 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         std::vector<GemmProblem> gp[4];
         size_t n_prob = 0;
         long long n_tiles = 0;
-        for (int g = 0; g <= last_group; ++g) {
+        for (int g = 0; g <= last_group && !tick_ok[k]; ++g) {
             gp[g] = collect(k, g);
             n_prob += gp[g].size();
             for (const GemmProblem& p : gp[g]) n_tiles += (long long)p.n_tiles * p.m_tiles;
         }
         bool main_signalled = false;
         hipEvent_t stop_ev = (two && ext_events) ? ctx->ev_main[e] : nullptr;
-        if (split_main) {
+        if (tick_ok[k]) {
+            // ONE launch: linear1 (and nothing else of it) reads what the second stream wrote in tick k - 1
+            if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            const TickTable* tab = ctx->tick_tab_d + k;
+            int* queue = ctx->tick_queue_d + (size_t)k * 128;
+            if (ctx->timing) {
+                if (ctx->ev_used == ctx->ev_pool.size()) {
+                    hipEvent_t a, b;
+                    HIP_TRY(ctx, hipEventCreate(&a));
+                    HIP_TRY(ctx, hipEventCreate(&b));
+                    ctx->ev_pool.emplace_back(a, b);
+                }
+                auto& ev = ctx->ev_pool[ctx->ev_used++];
+                HIP_TRY(ctx, hipEventRecord(ev.first, st));
+                rc_launch_gemm_tick(tab, queue, B, ctx->tick_grid, st);
+                HIP_TRY(ctx, hipEventRecord(ev.second, st));
+            } else {
+                rc_launch_gemm_tick(tab, queue, B, ctx->tick_grid, st, stop_ev);
+                main_signalled = stop_ev != nullptr;
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->stat_tick_launches += 1;
+        } else if (split_main) {
             // {H = 512 nets, linear1} (reads what the second stream wrote in tick k - 1) on its own stream ...
             bool sig2 = false, sig0 = false;
             if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_aux[ep], 0));
@@ -1054,6 +1147,22 @@ int reserve_plan_tables(rc_ctx* ctx, int T) {
         HIP_TRY(ctx, hipHostMalloc((void**)&ctx->frame_at_h, fneed * sizeof(int), hipHostMallocDefault));
         ctx->frame_at_cap = fneed;
     }
+    if (ctx->seq_tick) if (int rc = reserve_tick_tables(ctx, (size_t)T + 64)) return rc;
+    return RC_OK;
+}
+
+// tables of the one-launch-per-tick path for a call of n_ticks ticks (grow-only; the caller makes sure nothing in flight reads them)
+int reserve_tick_tables(rc_ctx* ctx, size_t n_ticks) {
+    if (n_ticks <= ctx->tick_cap) return RC_OK;
+    if (ctx->tick_tab_d) (void)hipFree(ctx->tick_tab_d);
+    if (ctx->tick_tab_h) (void)hipHostFree(ctx->tick_tab_h);
+    if (ctx->tick_queue_d) (void)hipFree(ctx->tick_queue_d);
+    ctx->tick_tab_d = nullptr; ctx->tick_tab_h = nullptr; ctx->tick_queue_d = nullptr; ctx->tick_cap = 0;
+    const size_t cap = n_ticks + n_ticks / 4 + 64;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->tick_tab_d, cap * sizeof(TickTable)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->tick_tab_h, cap * sizeof(TickTable), hipHostMallocDefault));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->tick_queue_d, cap * 128 * sizeof(int)));
+    ctx->tick_cap = cap;
     return RC_OK;
 }
 
@@ -1107,6 +1216,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_lean = tune_env("RC_LIVE_LEAN", 1);
     ctx->live_lean_nc = tune_env("RC_LIVE_LEAN_NC", 1) == 2 ? 2 : 1;
     ctx->live_aql_on = tune_env("RC_LIVE_AQL", 1);
+    ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
+    ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
@@ -1182,6 +1293,9 @@ int rc_destroy(rc_ctx* ctx) {
     if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
     if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
     if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
+    if (ctx->tick_tab_d) (void)hipFree(ctx->tick_tab_d);
+    if (ctx->tick_tab_h) (void)hipHostFree(ctx->tick_tab_h);
+    if (ctx->tick_queue_d) (void)hipFree(ctx->tick_queue_d);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
@@ -1493,6 +1607,13 @@ int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_fr
     if (wave_frames) *wave_frames = ctx->stat_wave_frames;
     if (stepped_frames) *stepped_frames = ctx->stat_stepped_frames;
     if (ticks) *ticks = ctx->stat_ticks;
+    return RC_OK;
+}
+
+int rc_get_launch_stats(rc_ctx* ctx, int64_t* tick_launches, int64_t* other_wide_launches) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (tick_launches) *tick_launches = ctx->stat_tick_launches;
+    if (other_wide_launches) *other_wide_launches = ctx->stat_wide_launches;
     return RC_OK;
 }
 

@@ -96,6 +96,20 @@ struct GemmLaunch {
 
 #define RC_TICK_PROB 24   // GEMM problems of one sequence-mode tick (6 sub-nets x {linear1, LSTM l0, LSTM l1, linear2})
 
+// ---- one launch per tick (rc_gemm_tick_kernel, rc_gemm.hip): the tick's wide problems as a table in DEVICE memory, read through the
+// scalar cache; resident workgroups pull 64 x 128 split-product tiles ("items") from per-XCD queues
+#define RC_TICK_MAXP 24   // wide problems of a tick: 12 LSTM layer steps + 6 linear1 (+ head room)
+#define RC_TICK_CH 4      // chunks of 256 candidate rows whose flag / step words a tile requests ahead: contexts of up to 1024 rows
+struct TickTable {
+    int n_prob;             // problems
+    int n_items;            // items = tiles incl. the padding that keeps every problem's first item a multiple of 8
+    int trace_base;         // first record slot of this launch (-DRC_TRACE_TILES builds)
+    int pad_;
+    int item_base[RC_TICK_MAXP + 4];   // first item of problem q (multiples of 8), ascending
+    GemmProblem p[RC_TICK_MAXP];       // every problem: split products, 64 x 128 tiles (mr 4, nc 8), epilogue LSTM or packed relu
+};
+void rc_launch_gemm_tick(const TickTable* tab_dev, int* queue_dev, int B, int grid, hipStream_t s, hipEvent_t stop = nullptr);
+
 // ---- per-frame small kernels -------------------------------------------------------------------------------
 struct BodyConst {          // device copy of the body constants the path needs
     int parent[24];
