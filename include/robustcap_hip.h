@@ -322,7 +322,8 @@ int rc_smplify_run(rc_ctx* ctx, const float* pose, const float* tran, const floa
                    float* tran_out, uint8_t* update_host, rc_smplify_info* info, void* stream);
 
 /* The same for n_rows independent (sequence, camera) rows at once (evaluate.py:86-90 loops them): every row runs the optimiser
- * of rc_smplify_run on a host thread of its own, the device work of all rows goes out in lock-step rounds -- one launch per kind
+ * of rc_smplify_run as a fiber of the CALLING thread (a stack of its own behind a guard page; RC_SMPLIFY_THREADS=1: a host thread per
+ * row instead), the device work of all rows goes out in lock-step rounds -- one launch per kind
  * of operation over all rows, one read-back and one synchronisation per round -- so 72 rows cost about what the longest row's ~46
  * rounds cost. Per row the arithmetic is that of rc_smplify_run (same n_iter / n_eval / losses). Arrays of n_rows: T, DEVICE
  * pointers pose / tran / kp / imu_ori / pose_out / tran_out, HOST pointers update (uint8[T_r] each), HOST K[n_rows,9], infos

@@ -1685,6 +1685,7 @@ int rc_live_begin(rc_ctx* ctx) {
     }
     hipStream_t st = ctx->live_stream;
     const bool timing = ctx->timing;
+    struct TimingGuard { rc_ctx* c; bool v; ~TimingGuard() { c->timing = v; } } timing_guard{ctx, timing};   // restored on every exit path
     ctx->timing = false;
     // Two captures of the frame: with and without the three transition launches. rc_live_step replays the short one
     // when the host can rule out that any row carries a deferred updater step into a frame it steps on camera data.
@@ -1707,46 +1708,61 @@ int rc_live_begin(rc_ctx* ctx) {
     // The lean plan of the steady-state frame (rc_live.hip): seven launches. rc_live_step replays it when the frame needs neither a
     // transition step nor init_net and is not a sequence start; every other frame takes the captures above.
     // (fp32-MFMA contexts only: the lean kernels stream the fp32 weights, a context switched to split products keeps one arithmetic)
+    // The lean plan is an OPTION on top of the two captures above: whatever fails in here (an allocation, its capture, the AQL chain) leaves
+    // the context on those captures with a note (rc_get_live_backend), and never fails rc_live_begin (round-4 advice).
     if (!rc && ctx->live_lean && B <= RC_LIVE_MAXB && !ctx->gemm_split) {
-        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->live_status_h, sizeof(int), hipHostMallocMapped));
-        *ctx->live_status_h = 0;
-        LiveFrame& F = ctx->live_frame;
-        F = LiveFrame{};
-        for (int i = 0; i < 6; ++i) {
-            const NetDev& n = ctx->net[i];
-            LiveNet& l = F.net[i];
-            l.W1 = n.lin1.W; l.b1 = n.lin1.b;
-            for (int q = 0; q < 2; ++q) { l.Wl[q] = n.Wl[q]; l.bl[q] = n.bl[q]; }
-            l.W2 = n.lin2.Wrm; l.b2 = n.lin2.b;
-            l.x1 = n.x1; l.h = n.h; l.c = n.c; l.part = n.part; l.steps = n.steps;
-            l.H = n.H; l.out = n.out; l.outp = round_up(n.out, 4); l.Kp1 = n.lin1.Kp;
-            l.BpH = (long long)ctx->Bp * n.H;
-        }
-        F.fb = ctx->fb; F.io = io; F.prm = dev_params(ctx->prm); F.body = ctx->body; F.B = (int)B; F.nc = ctx->live_lean_nc;
-        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&F.status, ctx->live_status_h, 0));
-        std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
-        const int nk = rc_live_plan(F, plan.data());
-      if (nk == RC_LIVE_KERNELS) {                                          // (0: sub-net sizes these kernels are not compiled for)
-        HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
-        rc_launch_live_frame(F, st);
-        if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
-        const hipError_t e = hipStreamEndCapture(st, &ctx->live_graph_lean);
-        if (e != hipSuccess) rc = fail(ctx, RC_ERR_HIP, std::string("hipStreamEndCapture (lean frame): ") + hipGetErrorString(e));
-        if (!rc && hipGraphInstantiate(&ctx->live_exec_lean, ctx->live_graph_lean, nullptr, nullptr, 0) != hipSuccess)
-            rc = fail(ctx, RC_ERR_HIP, "hipGraphInstantiate (lean frame)");
-        // ... and the same seven dispatches as pre-built AQL packets (rc_aql.cpp); without them the graph above is replayed
         ctx->live_aql_note.clear();
-        // (not under a profiling tool: rocprofv3's HSA queue interception crashes on packets written straight into the ring --
-        // ROCm 7.2; traces then show the graph replay of the same kernels. RC_LIVE_AQL=2 insists.)
-        const char* preload = std::getenv("LD_PRELOAD");
-        const bool tool = std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("HSA_TOOLS_LIB") || (preload && std::strstr(preload, "rocprofiler"));
-        if (!rc && tool && ctx->live_aql_on == 1) ctx->live_aql_note = "a profiling tool intercepts the HSA queues";
-        else if (!rc && ctx->live_aql_on && ctx->live_zero_copy && !ctx->live_eager) {
-            char msg[256] = {0};
-            if (rc_aql_create(ctx->dev, plan.data(), nk, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
-        } else if (!rc) ctx->live_aql_note = "switched off";
-      }
+        auto lean_setup = [&]() -> std::string {
+            if (hipHostMalloc((void**)&ctx->live_status_h, sizeof(int), hipHostMallocMapped) != hipSuccess) return "lean frame: status word allocation failed";
+            *ctx->live_status_h = 0;
+            LiveFrame& F = ctx->live_frame;
+            F = LiveFrame{};
+            for (int i = 0; i < 6; ++i) {
+                const NetDev& n = ctx->net[i];
+                LiveNet& l = F.net[i];
+                l.W1 = n.lin1.W; l.b1 = n.lin1.b;
+                for (int q = 0; q < 2; ++q) { l.Wl[q] = n.Wl[q]; l.bl[q] = n.bl[q]; }
+                l.W2 = n.lin2.Wrm; l.b2 = n.lin2.b;
+                l.x1 = n.x1; l.h = n.h; l.c = n.c; l.part = n.part; l.steps = n.steps;
+                l.H = n.H; l.out = n.out; l.outp = round_up(n.out, 4); l.Kp1 = n.lin1.Kp;
+                l.BpH = (long long)ctx->Bp * n.H;
+            }
+            F.fb = ctx->fb; F.io = io; F.prm = dev_params(ctx->prm); F.body = ctx->body; F.B = (int)B; F.nc = ctx->live_lean_nc;
+            if (hipHostGetDevicePointer((void**)&F.status, ctx->live_status_h, 0) != hipSuccess) return "lean frame: status word not mapped";
+            std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
+            const int nk = rc_live_plan(F, plan.data());
+            if (nk != RC_LIVE_KERNELS) return "lean frame: sub-net sizes these kernels are not compiled for";
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return "lean frame: hipStreamBeginCapture failed";
+            if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st);
+            rc_launch_live_frame(F, st);
+            if (!ctx->live_zero_copy) (void)hipMemcpyAsync(ctx->live_out_h, ctx->live_out_d, B * 219 * sizeof(float), hipMemcpyDeviceToHost, st);
+            const hipError_t e = hipStreamEndCapture(st, &ctx->live_graph_lean);      // (always ended: the stream must not stay in capture mode)
+            if (e != hipSuccess) return std::string("lean frame: hipStreamEndCapture: ") + hipGetErrorString(e);
+            if (hipGraphInstantiate(&ctx->live_exec_lean, ctx->live_graph_lean, nullptr, nullptr, 0) != hipSuccess) return "lean frame: hipGraphInstantiate failed";
+            // ... and the same seven dispatches as pre-built AQL packets (rc_aql.cpp); without them the graph above is replayed.
+            // Not under a tool that intercepts the HSA queues (rocprofv3's interception crashes on packets written straight into the ring --
+            // ROCm 7.2; traces then show the graph replay of the same kernels; a debugger's or tracer's runtime hooks are treated alike).
+            // RC_LIVE_AQL=2 insists.
+            const char* preload = std::getenv("LD_PRELOAD");
+            bool tool = std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("HSA_TOOLS_LIB") || std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+                        std::getenv("ROCR_DEBUG_AGENT") || std::getenv("HSA_ENABLE_DEBUG");
+            for (const char* sub : {"rocprof", "roctracer", "rocm-debug", "rocgdb", "omnitrace", "rocprofiler"}) tool = tool || (preload && std::strstr(preload, sub));
+            if (tool && ctx->live_aql_on == 1) ctx->live_aql_note = "a profiling / debugging tool intercepts the HSA queues";
+            else if (ctx->live_aql_on && ctx->live_zero_copy && !ctx->live_eager) {
+                char msg[256] = {0};
+                if (rc_aql_create(ctx->dev, plan.data(), nk, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
+            } else ctx->live_aql_note = "switched off";
+            return std::string();
+        };
+        const std::string why = lean_setup();
+        if (!why.empty()) {                                                // back to the two full captures
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); }
+            (void)hipGetLastError();
+            if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
+            if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
+            ctx->live_aql_note = why;
+        }
     }
     ctx->timing = timing;
     ctx->live_maybe_pend.assign(B, 1);
@@ -1807,7 +1823,16 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     } else if (lean) {
         if (ctx->live_aql) {
             if (waited_eager) HIP_TRY(ctx, hipStreamSynchronize(st));        // the AQL queue is not ordered behind the stream: wait here
-            if (rc_aql_run(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete");
+            if (rc_aql_run(ctx->live_aql) != 0) {
+                // The frame did not retire in time (a tool on the queue, a wedged device): the chain is dropped -- its destructor waits
+                // for whatever is still in flight before the ring and the argument blocks go -- and the following frames replay the
+                // captured graph of the same seven kernels. THIS frame's state is unknown: the caller gets the error.
+                rc_aql_destroy(ctx->live_aql);
+                ctx->live_aql = nullptr;
+                ctx->live_aql_note = "an AQL frame did not complete: back on hipGraphLaunch";
+                ctx->live_prev_known = false;
+                return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete (later frames use the graph replay)");
+            }
             aql_done = true;
         } else if (ctx->live_eager) rc_launch_live_frame(ctx->live_frame, st);
         else HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec_lean, st));

@@ -28,7 +28,9 @@ struct AqlChain {
     // completion by a word the last kernel stores itself (one row; RC_LIVE_DONE_FLAG=0 switches it off): the sequence number of the frame
     unsigned* flag_h = nullptr;                  // pinned host word (the device sees the same address)
     unsigned* seq_d = nullptr;                   // device counter of frames
-    unsigned seq = 0;                            // frames submitted
+    unsigned long long seq = 0;                  // frames submitted (64 bits: the completion signal counts down once per frame for the life of
+                                                 // the chain; the flag word K7 stores is its low 32 bits)
+    bool dead = false;                           // a frame did not complete in time: the chain takes no further frame (rc_live_step falls back)
     long long sig0 = 0;                          // value of `done` before any frame: every retired frame decrements it
     hsa_kernel_dispatch_packet_t pkt[RC_LIVE_KERNELS]{};
     uint16_t hdr[RC_LIVE_KERNELS]{};
@@ -126,9 +128,23 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
         // explicit arguments only: a kernel that grew hidden arguments (printf, dynamic LDS, blockDim) does not fit this path
         if (fs.karg[i] != need || fs.karg[i] > kKargStride) return bail(c, err, err_len, (std::string("unexpected kernarg segment of ") + k[i].name).c_str());
     }
+    // This path hands the packet processor kernel arguments in DEVICE memory that K1 / K4 rewrite while later packets of the frame are
+    // already in the ring (LiveGrid.hot): that is only sound for kernels that read every argument word from memory when they run. A code
+    // object built with kernarg preload (arguments copied into SGPRs when the packet is processed) would see stale words -- checked in the
+    // kernel descriptors (bytes 58-59: preload length in the low 7 bits), not assumed.
+    for (int i = 0; i < n; ++i) {
+        unsigned char kd[64] = {0};
+        if (hipMemcpy(kd, reinterpret_cast<const void*>(fs.kobj[i]), sizeof(kd), hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(c, err, err_len, (std::string("cannot read the kernel descriptor of ") + k[i].name).c_str());
+        const unsigned preload = (unsigned)kd[58] | ((unsigned)kd[59] << 8);
+        uint32_t kd_karg = 0;
+        std::memcpy(&kd_karg, kd + 8, 4);
+        if ((preload & 0x7f) != 0) return bail(c, err, err_len, (std::string("kernarg preload in ") + k[i].name + ": its arguments cannot be rewritten in place").c_str());
+        if (kd_karg != fs.karg[i]) return bail(c, err, err_len, (std::string("kernel descriptor / symbol mismatch of ") + k[i].name).c_str());
+    }
     if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
         return bail(c, err, err_len, "hsa_queue_create", st);
-    c->sig0 = 1ll << 40;
+    c->sig0 = 1ll << 62;                                                     // counts down once per frame: ~10^14 years of frames
     if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
     // kernel arguments: device memory, written once (a frame's inputs arrive at fixed pinned addresses)
     std::vector<char> host((size_t)n * kKargStride, 0);
@@ -182,6 +198,7 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
 
 int rc_aql_run(AqlChain* c) {
     if (!c || !c->q) return -1;
+    if (c->dead) return -3;
     hsa_queue_t* q = c->q;
     const uint32_t mask = q->size - 1;
     // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
@@ -194,15 +211,20 @@ int rc_aql_run(AqlChain* c) {
     }
     hsa_queue_store_write_index_release(q, base + c->n);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + c->n - 1));
-    const unsigned seq = ++c->seq;
+    const unsigned long long seq = ++c->seq;
+    const unsigned seq32 = (unsigned)seq;                                   // what K7 stores: its device counter wraps the same way
     const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)seq);
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     for (;;) {
-        if (c->flag_h ? (__atomic_load_n(c->flag_h, __ATOMIC_ACQUIRE) == seq) : (hsa_signal_load_scacquire(c->done) == retired)) break;
+        if (c->flag_h ? (__atomic_load_n(c->flag_h, __ATOMIC_ACQUIRE) == seq32) : (hsa_signal_load_scacquire(c->done) == retired)) break;
         if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
             // a frame is ~100 us: something is slow (profiler, contention) -- sleep on the signal, give up after 10 s
-            if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, retired, 10000000000ull, HSA_WAIT_STATE_BLOCKED) != retired) return -2;
+            // ("< retired + 1", not "== retired": the signal only counts down, and a wait that starts late must not miss the value)
+            if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, retired + 1, 10000000000ull, HSA_WAIT_STATE_BLOCKED) > retired) {
+                c->dead = true;                                             // the frame may still be running: nobody may reuse its buffers or the ring
+                return -2;
+            }
             break;
         }
     }
@@ -212,7 +234,7 @@ int rc_aql_run(AqlChain* c) {
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
     if (!c || !c->q || c->seq == 0) return;
-    (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_EQ, (hsa_signal_value_t)(c->sig0 - (long long)c->seq), 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+    (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
 }
 
 void rc_aql_destroy(AqlChain* c) {

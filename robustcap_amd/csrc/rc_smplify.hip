@@ -17,6 +17,7 @@
 // preserved landmarks) and wrap-up (axis-angle -> R, residual after). HBM traffic per frame and evaluation: 75 parameters in, 75 gradients
 // out, ~4 KB of primal (rotations, landmarks, projections) written by the forward kernel and read by the gradient kernel.
 #include "rc_device.h"
+#include <algorithm>
 
 #define SM_SIGMA 100.0f
 #define SM_NG 8
@@ -434,11 +435,18 @@ void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t 
     hipLaunchKernelGGL(rc_smplify_fwd_kernel, dim3(A.T), dim3(64), 0, st, A, body);
     hipLaunchKernelGGL(rc_smplify_grad_kernel, dim3(A.T), dim3(128), 0, st, A, body);
 }
+// The row (or job) of these launches comes from blockIdx.y, and a grid's y extent ends at 65,535: longer tables go out in slices of the
+// table (round-4 advice: a lock-step round of the batched optimiser can ask for 6 (max_iter + 1) inner products per row -- 606 jobs a
+// row at max_iter = 100 -- and failed as a whole from ~108 rows on).
+#define RC_GRID_Y_MAX 65535
 void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t st) {
     if (n_rows <= 0 || T_max <= 0) return;
-    hipLaunchKernelGGL(rc_smplify_prior_rows_kernel, dim3((unsigned)(T_max + 63) / 64, (unsigned)n_rows), dim3(512), 0, st, rows_dev);
-    hipLaunchKernelGGL(rc_smplify_fwd_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body);
-    hipLaunchKernelGGL(rc_smplify_grad_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(128), 0, st, rows_dev, body);
+    for (int y0 = 0; y0 < n_rows; y0 += RC_GRID_Y_MAX) {
+        const unsigned ny = (unsigned)std::min(RC_GRID_Y_MAX, n_rows - y0);
+        hipLaunchKernelGGL(rc_smplify_prior_rows_kernel, dim3((unsigned)(T_max + 63) / 64, ny), dim3(512), 0, st, rows_dev + y0);
+        hipLaunchKernelGGL(rc_smplify_fwd_rows_kernel, dim3((unsigned)T_max, ny), dim3(64), 0, st, rows_dev + y0, body);
+        hipLaunchKernelGGL(rc_smplify_grad_rows_kernel, dim3((unsigned)T_max, ny), dim3(128), 0, st, rows_dev + y0, body);
+    }
 }
 
 // ======================================================= set-up / wrap-up of a batch of rows, one launch each (grid: frame x row)
@@ -527,12 +535,16 @@ __global__ __launch_bounds__(64) void rc_smplify_end_rows_kernel(const SmplifyRo
 void rc_launch_smplify_begin_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
                                   unsigned long long ign_mask, hipStream_t st) {
     if (n_rows <= 0 || T_max <= 0) return;
-    hipLaunchKernelGGL(rc_smplify_begin_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body, sigma, ign_mask);
+    for (int y0 = 0; y0 < n_rows; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_smplify_begin_rows_kernel, dim3((unsigned)T_max, (unsigned)std::min(RC_GRID_Y_MAX, n_rows - y0)), dim3(64), 0, st,
+                           rows_dev + y0, body, sigma, ign_mask);
 }
 void rc_launch_smplify_end_rows(const SmplifyRowIO* rows_dev, int n_rows, int T_max, const BodyConst* body, float sigma,
                                 unsigned long long ign_mask, hipStream_t st) {
     if (n_rows <= 0 || T_max <= 0) return;
-    hipLaunchKernelGGL(rc_smplify_end_rows_kernel, dim3((unsigned)T_max, (unsigned)n_rows), dim3(64), 0, st, rows_dev, body, sigma, ign_mask);
+    for (int y0 = 0; y0 < n_rows; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_smplify_end_rows_kernel, dim3((unsigned)T_max, (unsigned)std::min(RC_GRID_Y_MAX, n_rows - y0)), dim3(64), 0, st,
+                           rows_dev + y0, body, sigma, ign_mask);
 }
 
 // ================================================================= vector kernels of the device-resident L-BFGS
@@ -635,15 +647,20 @@ __global__ __launch_bounds__(256) void rc_vec_dots_rows_kernel(const VecJobN* __
 }
 void rc_launch_vec_ops(const VecOp* ops_dev, int n_ops, long long n_max, hipStream_t st) {
     if (n_ops <= 0 || n_max <= 0) return;
-    hipLaunchKernelGGL(rc_vec_ops_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)n_ops), dim3(256), 0, st, ops_dev);
+    for (int y0 = 0; y0 < n_ops; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_vec_ops_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)std::min(RC_GRID_Y_MAX, n_ops - y0)), dim3(256), 0, st, ops_dev + y0);
 }
 void rc_launch_vec_comb_rows(const VecCombRow* rows_dev, int n_rows, long long n_max, hipStream_t st) {
     if (n_rows <= 0 || n_max <= 0) return;
-    hipLaunchKernelGGL(rc_vec_comb_rows_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)n_rows), dim3(256), 0, st, rows_dev);
+    for (int y0 = 0; y0 < n_rows; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_vec_comb_rows_kernel, dim3((unsigned)((n_max + 255) / 256), (unsigned)std::min(RC_GRID_Y_MAX, n_rows - y0)), dim3(256), 0, st,
+                           rows_dev + y0);
 }
 void rc_launch_vec_dots_rows(const VecJobN* jobs_dev, int n_jobs, int nb_max, double* partial, hipStream_t st) {
     if (n_jobs <= 0 || nb_max <= 0) return;
-    hipLaunchKernelGGL(rc_vec_dots_rows_kernel, dim3((unsigned)nb_max, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, nb_max, partial);
+    for (int y0 = 0; y0 < n_jobs; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_vec_dots_rows_kernel, dim3((unsigned)nb_max, (unsigned)std::min(RC_GRID_Y_MAX, n_jobs - y0)), dim3(256), 0, st, jobs_dev + y0,
+                           nb_max, partial + (long long)y0 * nb_max);
 }
 
 void rc_launch_vec_axpy(const float* x, const float* d, float t, float* out, long long n, hipStream_t st) {
@@ -658,5 +675,7 @@ void rc_launch_vec_comb(const VecComb& c, float* out, long long n, hipStream_t s
 void rc_launch_vec_dots(const VecJob* jobs_dev, int n_jobs, long long n, double* partial, hipStream_t st) {
     if (n_jobs <= 0) return;
     const int nb = (int)((n + 4095) / 4096);
-    hipLaunchKernelGGL(rc_vec_dots_kernel, dim3((unsigned)nb, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, n, nb, partial);
+    for (int y0 = 0; y0 < n_jobs; y0 += RC_GRID_Y_MAX)
+        hipLaunchKernelGGL(rc_vec_dots_kernel, dim3((unsigned)nb, (unsigned)std::min(RC_GRID_Y_MAX, n_jobs - y0)), dim3(256), 0, st, jobs_dev + y0, n, nb,
+                           partial + (long long)y0 * nb);
 }

@@ -16,7 +16,9 @@
 #include <thread>
 #include <cstdio>
 #include <memory>
+#include <sys/mman.h>
 #include <ucontext.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -1194,14 +1196,24 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     } else if (!live.empty() && !smplify_threads_env()) {
         B.fibers = true;
         B.fctx.resize((size_t)n_rows);
+        // a stack per row with an inaccessible page below it (round-4 advice: in one plain array an overflow ran silently into the
+        // neighbouring row's stack; now it faults at the guard page)
         constexpr size_t kStack = 256u << 10;
-        std::unique_ptr<char[]> stacks(new char[kStack * live.size()]);
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE), slot = kStack + page;
+        struct Stacks {
+            void* p = MAP_FAILED; size_t n = 0;
+            ~Stacks() { if (p != MAP_FAILED) munmap(p, n); }
+        } stacks;
+        stacks.n = slot * live.size();
+        stacks.p = mmap(nullptr, stacks.n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (stacks.p == MAP_FAILED) return rc_ctx_fail(ctx, RC_ERR_HIP, "smplify batch: cannot map the rows' stacks");
+        for (size_t i = 0; i < live.size(); ++i) (void)mprotect((char*)stacks.p + i * slot, page, PROT_NONE);
         std::vector<FiberArg> fa(live.size());
         for (size_t i = 0; i < live.size(); ++i) {
             const int r = live[i];
             fa[i] = FiberArg{&B, r, lr, (int)max_iter, &res[r], &ok[r]};
             getcontext(&B.fctx[r]);
-            B.fctx[r].uc_stack.ss_sp = stacks.get() + i * kStack;
+            B.fctx[r].uc_stack.ss_sp = (char*)stacks.p + i * slot + page;
             B.fctx[r].uc_stack.ss_size = kStack;
             B.fctx[r].uc_link = &B.sched;
             const uintptr_t p = (uintptr_t)&fa[i];

@@ -194,8 +194,9 @@ def shard_rows(all_rows, Tmax, compute, device="cuda"):
 
 def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device, smplify_info, workers):
     """smplify over the rows of this rank (evaluate.py:86-90 loops them one after another): ONE batched call -- every row's
-    optimiser advances in lock-step rounds on the device (TemporalSMPLify.run_batch / rc_smplify_run_batch). ``workers`` = 0
-    selects round 3's scheme instead (that many host threads, a context and a stream each; RC_SMPLIFY_WORKERS overrides)."""
+    optimiser advances in lock-step rounds on the device (TemporalSMPLify.run_batch / rc_smplify_run_batch). ``workers``
+    (run_dataset's ``smplify_workers``) is only read by round 3's scheme -- that many host threads, a context and a stream each --
+    which the environment switch RC_SMPLIFY_WORKERS=n (n > 0, A/B runs) selects; the batched call has no worker count."""
     from .smplify import TemporalSMPLify
     torch.cuda.synchronize()
     scale = torch.tensor([float(image_size[0]), float(image_size[1]), 1.0])
@@ -218,7 +219,7 @@ def _refine_rows(dataset, mine, body, gmm, out_p, out_t, ori, image_size, device
         torch.cuda.synchronize()
         return
     import threading
-    workers = max(1, min(threads, len(mine)))
+    workers = max(1, min(threads if threads > 0 else int(workers or 1), len(mine)))
     runners = [TemporalSMPLify(body=body, gmm=gmm, device=device) for _ in range(workers)]
     if not runners[0].has_prior:
         raise ValueError("run_smplify=True needs the GMM pose prior (gmm=)")

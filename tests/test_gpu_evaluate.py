@@ -210,3 +210,79 @@ def test_dataset_metrics_in_one_call_equal_the_row_by_row_loop(synth_assets):
         one = model.mesh_metrics(pose, pt)[1]
         assert max(abs(a - b) for a, b in zip(one, per_row[(i, j)])) < 1e-6
     assert all(v > 1e-3 for v in mean)
+
+
+def test_config3_at_its_own_size(synth_assets):
+    """BASELINE config 3 (the AIST++ evaluation: every (sequence, camera) row through the harness, evaluate.py:20-117) at the
+    size tools/config3_eval.py quotes -- 8 sequences x 9 cameras x 600 frames = 72 rows -- with smplify on:
+      * size-independent properties of the net's outputs (finite, orthonormal rotations, the IMU root in place),
+      * a row of the batch == that row run alone (bitwise, same product arithmetic),
+      * an oracle spot check (2 rows x 64 frames, 1e-4 m / 0.1 deg),
+      * the row blocks of 8 ranks (dist.shard_range) computed one after another == the unsharded run, bitwise,
+      * every row refined by the batched optimiser, the metric call over all rows."""
+    from oracle import sig_mp_oracle as O
+    from robustcap_amd import dist as rdist
+    from robustcap_amd import evaluate as ev
+    from robustcap_amd import synth
+    from robustcap_amd.body import ParametricModel
+    from robustcap_amd.net.sig_mp import Net
+    body, sd, gmm = synth_assets["body"], synth_assets["state_dict"], synth.make_gmm(3)
+    n_seq, n_cam, T = 8, 9, 600
+    ds = synth.make_dataset(21, n_seq, T, body, n_cam=n_cam, conf="mixed")
+    rows = ev.rows_of(ds)
+    assert len(rows) == 72
+    nets = {}
+    plain = ev.run_dataset(ds, sd, body, nets=nets)
+    assert sorted(plain) == sorted(rows)
+    split = Net.default_gemm_mode(len(rows))
+    assert split                                                                   # 72 rows: split-bf16 products
+    # ---- properties at full size
+    P = torch.stack([plain[k][0] for k in rows])                                   # [72, 600, 24, 3, 3]
+    Tr = torch.stack([plain[k][1] for k in rows])
+    assert P.shape == (72, T, 24, 3, 3) and torch.isfinite(P).all() and torch.isfinite(Tr).all()
+    eye = torch.eye(3)
+    assert float((P.transpose(-1, -2) @ P - eye).abs().max()) < 1e-4
+    assert float((torch.linalg.det(P) - 1).abs().max()) < 1e-4
+    for (i, j) in ((0, 0), (5, 7)):                                                # pose[0] = the pelvis IMU in the camera frame (sig_mp.py:175)
+        o = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])[2]
+        assert torch.equal(plain[(i, j)][0][:, 0], o[:, 5].cpu())
+    # ---- a row of the batch == that row alone (same arithmetic), and the oracle on its first 64 frames
+    for (i, j) in ((2, 3), (7, 8)):
+        k, a, o, g = ev.camera_inputs(ds["joint2d_mp"][i][j], ds["imu_acc"][i], ds["imu_ori"][i], ds["cam_K"][i][j], ds["cam_T"][i][j])
+        net = Net(body=body, batch=1)
+        net.load_state_dict(sd)
+        net.set_gemm_mode(split)
+        net.gravityc = g
+        ft = ev.labels(ds, i, j)[1][0]
+        p, tr = net.forward_sequence(k[None], a[None], o[None], first_tran=ft[None])
+        assert torch.equal(p[0].cpu(), plain[(i, j)][0]) and torch.equal(tr[0].cpu(), plain[(i, j)][1])
+        ref = O.OracleNet(body, batch=1)
+        ref.load_numpy_state_dict(sd)
+        ref.gravityc = g
+        kc, ac, oc = k.cpu(), a.cpu(), o.cpu()
+        for f in range(64):
+            rp, rt = ref.forward_online(kc[f], ac[f], oc[f], ft if f == 0 else None)
+            assert float((rt - plain[(i, j)][1][f]).abs().max()) < 1e-4, (i, j, f)
+            cosang = ((rp.transpose(-1, -2) @ plain[(i, j)][0][f]).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+            assert float(torch.rad2deg(torch.acos(cosang.clamp(-1, 1))).max()) < 0.1, (i, j, f)
+    # ---- the partition of 8 ranks, block by block on this one device == unsharded (what shard_rows + one gather give on 8 GPUs)
+    for rank in range(8):
+        a_, b_ = rdist.shard_range(len(rows), rank, 8)
+        assert b_ - a_ == 9
+        part = ev.run_dataset(ds, sd, body, rows=rows[a_:b_], nets=nets, gemm_mode=split)
+        for key in rows[a_:b_]:
+            assert torch.equal(part[key][0], plain[key][0]) and torch.equal(part[key][1], plain[key][1]), (rank, key)
+    # ---- smplify over all rows (one lock-step batch) and the metrics of the refined result
+    info = {}
+    refined = ev.run_dataset(ds, sd, body, run_smplify=True, gmm=gmm, smplify_info=info, nets=nets)
+    assert len(info) == 72 and all(v["n_eval"] >= 1 for v in info.values())
+    done = [k for k in rows if info[k]["status"] == 1]
+    assert len(done) >= 36                                                          # (rows the pre-check rejects stay as they are)
+    assert all(torch.isfinite(refined[k][0]).all() and torch.isfinite(refined[k][1]).all() for k in rows)
+    assert max(float((refined[k][1] - plain[k][1]).abs().max()) for k in done) > 0.0
+    R = torch.stack([refined[k][0] for k in done])
+    assert float((R.transpose(-1, -2) @ R - eye).abs().max()) < 1e-4
+    model = ParametricModel(body=body)
+    model.set_regressor(synth.make_j_regressor(4), 14)
+    per_row, mean = ev.dataset_metrics(model, ds, refined)
+    assert len(per_row) == 72 and np.isfinite(np.asarray(mean)).all()
