@@ -46,6 +46,7 @@ LONG_FRAMES = 512                      # frames per call of the *_long variants:
 PRODUCTS_SPLIT = ("fp32 operands split exactly into 3 bf16 terms each; every product = 6 partial products on "
                   "v_mfma_f32_16x16x32_bf16 (all terms >= 2^-16 of the product), fp32 accumulation, fp32 gates / state")
 PRODUCTS_FP32 = "v_mfma_f32_16x16x4_f32 (fp32 operands, an fma chain per output element)"
+PACED_FRAMES = 1000                    # live_b1.paced_60fps: frames at 60 fps (16.7 s of the default run)
 CPU_FRAMES_BATCHED = 8                 # cpu_baseline: 3 samples of B x 8 frames batched (median) + 48 frames batch-1 (~10-30 s)
 CPU_FRAMES_SINGLE = 48
 CPU_SAMPLES = 3
@@ -307,7 +308,7 @@ def live_b1(sd, body, frames=2000):
     T = m["j2dc"].shape[1]
     ins = [(t(m["j2dc"][0, k]).contiguous(), t(m["accc"][0, k]).contiguous(), t(m["oric"][0, k]).contiguous()) for k in range(T)]
 
-    def run(n_frames, env):
+    def run(n_frames, env, period_s=0.0):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -327,9 +328,19 @@ def live_b1(sd, body, frames=2000):
         pp, pt = C_.c_void_p(pose.data_ptr()), C_.c_void_p(tran.data_ptr())
         ptrs = [(C_.c_void_p(a.data_ptr()), C_.c_void_p(b.data_ptr()), C_.c_void_p(c.data_ptr())) for a, b, c in ins]
         lat = np.empty(n_frames + 50)
+        t_next = time.perf_counter() + period_s
         for i in range(n_frames + 50):
             a, b, c = ptrs[1 + i % (T - 1)]
-            t0 = time.perf_counter()
+            if period_s > 0:                                                # the frame ARRIVES at t_next: sleep, spin to it, clock from the arrival
+                slack = t_next - time.perf_counter() - 1e-3
+                if slack > 0:
+                    time.sleep(slack)
+                while time.perf_counter() < t_next:
+                    pass
+                t0 = t_next
+                t_next += period_s
+            else:
+                t0 = time.perf_counter()
             rc = fn(ctx, a, b, c, None, 0, pp, pt)
             lat[i] = time.perf_counter() - t0
             if rc != 0:
@@ -347,6 +358,12 @@ def live_b1(sd, body, frames=2000):
            "lean_frames": lean, "full_frames": full, "launches_per_lean_frame": 7 if cap else None,
            "dispatch": "AQL packet chain on the context's own HSA queue" if aql else ("hipGraphLaunch" + (f" ({note})" if note else "")),
            "workload": "BASELINE config 5: batch 1, captured frame (steady state: seven kernels), host tensors in / out through rc_live_step"}
+    # config 5 as BASELINE states it: 60 fps -- a frame every 16.67 ms, the device idle in between; latency from the frame's arrival
+    paced = run(PACED_FRAMES, {}, 1.0 / 60.0)[0]
+    out["paced_60fps"] = {"p50_us": round(float(np.percentile(paced, 50)), 1), "p99_us": round(float(np.percentile(paced, 99)), 1),
+                          "mean_us": round(float(paced.mean()), 1), "frames": len(paced), "period_ms": round(1e3 / 60.0, 3),
+                          "note": "inputs arrive every 16.67 ms (sleep + spin to the arrival time), latency = arrival -> outputs on the host; "
+                                  "p50_us / p99_us above are the same frames back to back"}
     if aql:
         lat2 = run(max(200, frames // 4), {"RC_LIVE_AQL": "0"})[0]
         out["graph_replay"] = {"p50_us": round(float(np.percentile(lat2, 50)), 1), "p99_us": round(float(np.percentile(lat2, 99)), 1),

@@ -181,6 +181,13 @@ int rc_live_end(rc_ctx* ctx);
  * fixed order instead of one MFMA chain, so a lean frame equals an rc_step frame to rounding (<= 1e-6), not bit for bit.
  * RC_LIVE_LEAN=0 in the environment of rc_create switches it off. Counters: frames replayed from the lean / the full captures. */
 int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames);
+/* Round 5, the idle-time pre-step of a paced live stream (BASELINE config 5: "60 fps"; live_server.py:40-48 receives one camera frame
+ * every 16.6 ms): when the caller left the device idle in front of a frame (>= RC_LIVE_PRESTEP_IDLE_US, default 500 us), rc_live_step
+ * enqueues, behind that frame, the recurrent halves W_hh h(t-1) of the NEXT frame's twelve LSTM layer steps (half of the 243 MB of weights,
+ * one launch, while the device would idle); the next lean frame then starts from them and streams only the input halves. Bitwise the same
+ * layer steps. Any eager call in between (reset, rc_step, ...) discards them. presteps: enqueued since rc_create; available: the AQL chain
+ * carries the pre-step programs (either may be NULL). */
+int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available);
 /* Host time of rc_live_step averaged over the lean frames so far, microseconds: {staging the inputs + choosing the capture, enqueue
  * (hipGraphLaunch), waiting for the frame, copying the outputs}. The frame's GPU time is inside the third. */
 int rc_get_live_profile(rc_ctx* ctx, double* avg_us4);

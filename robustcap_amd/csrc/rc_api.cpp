@@ -125,6 +125,16 @@ struct rc_ctx {
     int live_aql_on = 1;                                    // RC_LIVE_AQL: 0 = lean frames by hipGraphLaunch only
     AqlChain* live_aql = nullptr;                           // the lean frame as pre-built AQL packets on a queue of its own (rc_aql.cpp)
     std::string live_aql_note;                              // why the AQL path is not in use (empty when it is)
+    // the idle-time pre-step (rc_live.hip: rc_live_pre): the recurrent halves of the next frame's layer steps, computed behind a frame
+    // when the caller leaves the device idle between frames (a 60 fps stream: 16.6 ms)
+    int live_prestep = 1;                                   // RC_LIVE_PRESTEP: 0 = never
+    double live_prestep_idle_us = 500.0;                    // RC_LIVE_PRESTEP_IDLE_US: idle time in front of a frame from which the next pre-step is enqueued
+    float* live_pre_buf = nullptr;                          // [tiles of the twelve layer steps][2 waves][64 lanes][4]
+    int aql_prog_lean = -1, aql_prog_lean_pre = -1, aql_prog_pre = -1;     // programs of the AQL chain
+    bool live_pre_valid = false;                            // a pre-step of the CURRENT state is in the queue (or done)
+    bool live_have_return = false;
+    std::chrono::steady_clock::time_point live_last_return{};
+    long long stat_live_pre = 0;
     int* live_status_h = nullptr;                           // pinned + mapped: set by a lean frame that met an init_net trigger
     std::vector<unsigned char> live_may_reach;              // host-side, conservative: the row may still trigger init_net (L178-183)
     long long stat_live_lean = 0, stat_live_full = 0;
@@ -206,6 +216,7 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
 // Eager work was enqueued on the caller's stream `st`: the next live-graph replay (private stream) must wait for it.
 // (The other direction needs nothing: rc_live_step synchronises its stream before it returns.)
 int mark_eager(rc_ctx* ctx, hipStream_t st) {
+    ctx->live_pre_valid = false;         // the state the pre-step read is no longer the state the next live frame starts from
     if (!ctx->eager_ev) return RC_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->eager_ev, st));
     ctx->eager_dirty = true;
@@ -535,6 +546,7 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
 
 // run every pending (deferred) updater step now: state then equals the reference's at the end of its frame
 int flush_pending(rc_ctx* ctx, hipStream_t st) {
+    ctx->live_pre_valid = false;
     if (!ctx->have_weights || !ctx->prm.use_vision_updater) return RC_OK;
     const FrameBuffers& fb = ctx->fb;
     rc_launch_flush_flags(fb, ctx->B, st);
@@ -1216,6 +1228,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_lean = tune_env("RC_LIVE_LEAN", 1);
     ctx->live_lean_nc = tune_env("RC_LIVE_LEAN_NC", 1) == 2 ? 2 : 1;
     ctx->live_aql_on = tune_env("RC_LIVE_AQL", 1);
+    ctx->live_prestep = tune_env("RC_LIVE_PRESTEP", 1);
+    ctx->live_prestep_idle_us = (double)tune_env("RC_LIVE_PRESTEP_IDLE_US", 500);
     ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
     ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
@@ -1649,7 +1663,10 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
     if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
-    if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }
+    if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }     // (waits for a pre-step still in flight)
+    if (ctx->live_pre_buf) { (void)hipFree(ctx->live_pre_buf); ctx->live_pre_buf = nullptr; }
+    ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
+    ctx->live_pre_valid = false; ctx->live_have_return = false;
     if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
     if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
     if (ctx->live_status_h) { (void)hipHostFree(ctx->live_status_h); ctx->live_status_h = nullptr; }
@@ -1750,7 +1767,22 @@ int rc_live_begin(rc_ctx* ctx) {
             if (tool && ctx->live_aql_on == 1) ctx->live_aql_note = "a profiling / debugging tool intercepts the HSA queues";
             else if (ctx->live_aql_on && ctx->live_zero_copy && !ctx->live_eager) {
                 char msg[256] = {0};
-                if (rc_aql_create(ctx->dev, plan.data(), nk, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
+                if (rc_aql_create(ctx->dev, &ctx->live_aql, msg, (int)sizeof(msg)) != 0) { ctx->live_aql = nullptr; ctx->live_aql_note = msg; }
+                else if ((ctx->aql_prog_lean = rc_aql_add(ctx->live_aql, plan.data(), nk, 1, msg, (int)sizeof(msg))) < 0) {
+                    rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; ctx->live_aql_note = msg;
+                } else if (ctx->live_prestep && F.nc == 1) {
+                    // the pre-step and the frame that starts from its partial sums: two more programs on the same queue; without them
+                    // (an allocation or a symbol failed) the chain simply keeps the one frame program
+                    const size_t nf = (size_t)rc_live_pre_floats(F);
+                    if (hipMalloc((void**)&ctx->live_pre_buf, nf * sizeof(float)) == hipSuccess && hipMemset(ctx->live_pre_buf, 0, nf * sizeof(float)) == hipSuccess) {
+                        std::vector<LiveKernel> plan2(RC_LIVE_KERNELS), plan3(1);
+                        if (rc_live_plan(F, plan2.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS && rc_live_pre_plan(F, ctx->live_pre_buf, plan3.data()) == 1) {
+                            ctx->aql_prog_lean_pre = rc_aql_add(ctx->live_aql, plan2.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
+                            if (ctx->aql_prog_lean_pre >= 0) ctx->aql_prog_pre = rc_aql_add(ctx->live_aql, plan3.data(), 1, 0, msg, (int)sizeof(msg));
+                        }
+                    } else { ctx->live_pre_buf = nullptr; (void)hipGetLastError(); }
+                    if (ctx->aql_prog_pre < 0) ctx->aql_prog_lean_pre = -1;
+                }
             } else ctx->live_aql_note = "switched off";
             return std::string();
         };
@@ -1778,6 +1810,8 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     const size_t B = ctx->B;
     hipStream_t st = ctx->live_stream;
     const auto t_in = std::chrono::steady_clock::now();
+    // how long the caller left the device alone since the previous frame returned: a 60 fps stream idles 16.6 ms, a benchmark loop none
+    const double idle_us = ctx->live_have_return ? std::chrono::duration<double, std::micro>(t_in - ctx->live_last_return).count() : 0.0;
     bool waited_eager = false;
     if (ctx->eager_dirty) {          // e.g. reset_states() on the caller's stream just before this frame
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->eager_ev, 0));
@@ -1813,6 +1847,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     const bool lean = ctx->live_exec_lean && !need_tr && !maybe_reach && !first_tran && !(flags & RC_FLAG_FIRST_FRAME);
     const auto t_staged = std::chrono::steady_clock::now();
     bool aql_done = false;
+    const bool use_pre = lean && ctx->live_aql && ctx->live_pre_valid && ctx->aql_prog_lean_pre >= 0;
+    ctx->live_pre_valid = false;                                  // (whatever this frame is, it moves the state on)
+    if (!(lean && ctx->live_aql) && ctx->live_aql) {
+        // this frame runs on the HIP stream: a pre-step still in the HSA queue must not read the state while the frame rewrites it
+        if (rc_aql_wait_background(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the pre-step did not complete");
+    }
     if (first_tran || (flags & RC_FLAG_FIRST_FRAME)) {           // sequence start: ordinary enqueue path
         if (!ctx->live_zero_copy) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_in_d, ctx->live_in_h, B * 171 * sizeof(float), hipMemcpyHostToDevice, st));
         if (first_tran) HIP_TRY(ctx, hipMemcpyAsync(ctx->live_ft_d, first_tran, B * 3 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -1823,13 +1863,14 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     } else if (lean) {
         if (ctx->live_aql) {
             if (waited_eager) HIP_TRY(ctx, hipStreamSynchronize(st));        // the AQL queue is not ordered behind the stream: wait here
-            if (rc_aql_run(ctx->live_aql) != 0) {
+            if (rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean) != 0) {
                 // The frame did not retire in time (a tool on the queue, a wedged device): the chain is dropped -- its destructor waits
                 // for whatever is still in flight before the ring and the argument blocks go -- and the following frames replay the
                 // captured graph of the same seven kernels. THIS frame's state is unknown: the caller gets the error.
                 rc_aql_destroy(ctx->live_aql);
                 ctx->live_aql = nullptr;
                 ctx->live_aql_note = "an AQL frame did not complete: back on hipGraphLaunch";
+                ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
                 ctx->live_prev_known = false;
                 return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete (later frames use the graph replay)");
             }
@@ -1867,6 +1908,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     const auto t_done = std::chrono::steady_clock::now();
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));
     std::memcpy(tran, ctx->live_out_h + B * 216, B * 3 * sizeof(float));
+    // The pre-step of the NEXT frame, behind this one in the queue, when the caller paces its frames (the idle time in front of this call
+    // says so): it streams half of the weights while the device would otherwise idle, and a caller that comes back at once -- a
+    // throughput loop -- would only wait for it.
+    if (ctx->live_aql && ctx->aql_prog_pre >= 0 && idle_us >= ctx->live_prestep_idle_us) {
+        if (rc_aql_submit(ctx->live_aql, ctx->aql_prog_pre) == 0) { ctx->live_pre_valid = true; ctx->stat_live_pre += 1; }
+    }
     if (lean) {
         const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::micro>(b - a).count();
@@ -1875,6 +1922,8 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         ctx->live_prof_us[3] += us(t_done, std::chrono::steady_clock::now());
         ctx->live_prof_n += 1;
     }
+    ctx->live_last_return = std::chrono::steady_clock::now();
+    ctx->live_have_return = true;
     return RC_OK;
 }
 
@@ -1883,6 +1932,13 @@ int rc_get_live_backend(rc_ctx* ctx, int32_t* lean_captured, int32_t* aql, char*
     if (lean_captured) *lean_captured = ctx->live_exec_lean ? 1 : 0;
     if (aql) *aql = ctx->live_aql ? 1 : 0;
     if (note && note_len > 0) std::snprintf(note, (size_t)note_len, "%s", ctx->live_aql_note.c_str());
+    return RC_OK;
+}
+
+int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (presteps) *presteps = ctx->stat_live_pre;
+    if (available) *available = (ctx->live_aql && ctx->aql_prog_pre >= 0) ? 1 : 0;
     return RC_OK;
 }
 

@@ -20,21 +20,29 @@
 #include <string>
 #include <vector>
 
+struct AqlProgram {
+    hsa_kernel_dispatch_packet_t pkt[RC_LIVE_KERNELS]{};
+    uint16_t hdr[RC_LIVE_KERNELS]{};
+    int n = 0;
+    bool frame = false;                          // a live frame (completion word / frame signal) or a background program (pre-step)
+    char* kargs = nullptr;                       // device memory: n blocks of kKargStride bytes
+};
+
 struct AqlChain {
     hsa_agent_t gpu{};
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};
-    char* kargs = nullptr;                       // device memory: n blocks of kKargStride bytes
+    hsa_signal_t bg_done{};                      // background programs: decremented by the last packet of each
+    unsigned long long bg_seq = 0;
     // completion by a word the last kernel stores itself (one row; RC_LIVE_DONE_FLAG=0 switches it off): the sequence number of the frame
     unsigned* flag_h = nullptr;                  // pinned host word (the device sees the same address)
     unsigned* seq_d = nullptr;                   // device counter of frames
     unsigned long long seq = 0;                  // frames submitted (64 bits: the completion signal counts down once per frame for the life of
                                                  // the chain; the flag word K7 stores is its low 32 bits)
     bool dead = false;                           // a frame did not complete in time: the chain takes no further frame (rc_live_step falls back)
-    long long sig0 = 0;                          // value of `done` before any frame: every retired frame decrements it
-    hsa_kernel_dispatch_packet_t pkt[RC_LIVE_KERNELS]{};
-    uint16_t hdr[RC_LIVE_KERNELS]{};
-    int n = 0;
+    long long sig0 = 0;                          // value of `done` / `bg_done` before any program: every retired one decrements it
+    std::vector<AqlProgram> prog;
+    void* loader_fs = nullptr;
     bool hsa_up = false;
 };
 
@@ -94,14 +102,13 @@ int bail(AqlChain* c, char* err, int err_len, const char* what, hsa_status_t st 
 }
 }  // namespace
 
-int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, char* err, int err_len) {
-    if (!k || !out || n < 1 || n > RC_LIVE_KERNELS) return -1;
+int rc_aql_create(int hip_device, AqlChain** out, char* err, int err_len) {
+    if (!out) return -1;
     *out = nullptr;
     AqlChain* c = new AqlChain();
     hsa_status_t st = hsa_init();                                    // reference-counted: HIP runs on the same runtime
     if (st != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_init", st);
     c->hsa_up = true;
-    c->n = n;
     // the HSA agent of the HIP device: by PCI domain / bus / device / function (an 8-GPU node may repeat bus numbers across domains)
     FindAgent fa{};
     {
@@ -114,19 +121,40 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
     if ((st = hsa_iterate_agents(agent_cb, &fa)) != HSA_STATUS_SUCCESS || fa.count == 0) return bail(c, err, err_len, "no GPU agent", st);
     if (!fa.have_match && fa.count != 1) return bail(c, err, err_len, "cannot match the HIP device to an HSA agent");
     c->gpu = fa.have_match ? fa.match : fa.first;
+    if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
+        return bail(c, err, err_len, "hsa_queue_create", st);
+    c->sig0 = 1ll << 62;                                                     // counts down once per frame: ~10^14 years of frames
+    if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->bg_done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    *out = c;
+    return 0;
+}
+
+int rc_aql_add(AqlChain* c, const LiveKernel* k, int n, int frame, char* err, int err_len) {
+    auto fail_add = [&](const char* what, hsa_status_t st = HSA_STATUS_SUCCESS) {
+        if (err && err_len > 0) {
+            const char* m = nullptr;
+            if (st != HSA_STATUS_SUCCESS) hsa_status_string(st, &m);
+            std::snprintf(err, (size_t)err_len, "%s%s%s", what, m ? ": " : "", m ? m : "");
+        }
+        return -1;
+    };
+    if (!c || !c->q || !k || n < 1 || n > RC_LIVE_KERNELS) return fail_add("bad program");
+    hsa_status_t st;
     // kernel objects of the (already loaded) kernels
     hsa_ven_amd_loader_1_03_pfn_t ld{};
     if ((st = hsa_system_get_major_extension_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof(ld), &ld)) != HSA_STATUS_SUCCESS ||
         !ld.hsa_ven_amd_loader_iterate_executables)
-        return bail(c, err, err_len, "AMD loader extension 1.03", st);
+        return fail_add("AMD loader extension 1.03", st);
     FindSyms fs{};
     fs.gpu = c->gpu; fs.k = k; fs.n = n;
-    if ((st = ld.hsa_ven_amd_loader_iterate_executables(exec_cb, &fs)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "iterate executables", st);
+    if ((st = ld.hsa_ven_amd_loader_iterate_executables(exec_cb, &fs)) != HSA_STATUS_SUCCESS) return fail_add("iterate executables", st);
     for (int i = 0; i < n; ++i) {
-        const uint32_t need = (uint32_t)(sizeof(LiveFrame) + (k[i].has_grid ? sizeof(LiveGrid) : 0));
-        if (!fs.kobj[i]) return bail(c, err, err_len, (std::string("kernel symbol not loaded: ") + k[i].name).c_str());
+        // arguments: (LiveFrame) | (LiveFrame, LiveGrid) | has_grid == 2: (LiveFrame, one pointer: LiveGrid.prebuf)
+        const uint32_t need = (uint32_t)(sizeof(LiveFrame) + (k[i].has_grid == 1 ? sizeof(LiveGrid) : (k[i].has_grid == 2 ? sizeof(void*) : 0)));
+        if (!fs.kobj[i]) return fail_add((std::string("kernel symbol not loaded: ") + k[i].name).c_str());
         // explicit arguments only: a kernel that grew hidden arguments (printf, dynamic LDS, blockDim) does not fit this path
-        if (fs.karg[i] != need || fs.karg[i] > kKargStride) return bail(c, err, err_len, (std::string("unexpected kernarg segment of ") + k[i].name).c_str());
+        if (fs.karg[i] != need || fs.karg[i] > kKargStride) return fail_add((std::string("unexpected kernarg segment of ") + k[i].name).c_str());
     }
     // This path hands the packet processor kernel arguments in DEVICE memory that K1 / K4 rewrite while later packets of the frame are
     // already in the ring (LiveGrid.hot): that is only sound for kernels that read every argument word from memory when they run. A code
@@ -135,82 +163,106 @@ int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, ch
     for (int i = 0; i < n; ++i) {
         unsigned char kd[64] = {0};
         if (hipMemcpy(kd, reinterpret_cast<const void*>(fs.kobj[i]), sizeof(kd), hipMemcpyDeviceToHost) != hipSuccess)
-            return bail(c, err, err_len, (std::string("cannot read the kernel descriptor of ") + k[i].name).c_str());
+            return fail_add((std::string("cannot read the kernel descriptor of ") + k[i].name).c_str());
         const unsigned preload = (unsigned)kd[58] | ((unsigned)kd[59] << 8);
         uint32_t kd_karg = 0;
         std::memcpy(&kd_karg, kd + 8, 4);
-        if ((preload & 0x7f) != 0) return bail(c, err, err_len, (std::string("kernarg preload in ") + k[i].name + ": its arguments cannot be rewritten in place").c_str());
-        if (kd_karg != fs.karg[i]) return bail(c, err, err_len, (std::string("kernel descriptor / symbol mismatch of ") + k[i].name).c_str());
+        if ((preload & 0x7f) != 0) return fail_add((std::string("kernarg preload in ") + k[i].name + ": its arguments cannot be rewritten in place").c_str());
+        if (kd_karg != fs.karg[i]) return fail_add((std::string("kernel descriptor / symbol mismatch of ") + k[i].name).c_str());
     }
-    if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
-        return bail(c, err, err_len, "hsa_queue_create", st);
-    c->sig0 = 1ll << 62;                                                     // counts down once per frame: ~10^14 years of frames
-    if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    c->prog.emplace_back();
+    AqlProgram& P = c->prog.back();
+    auto drop = [&](const char* what) { if (P.kargs) (void)hipFree(P.kargs); c->prog.pop_back(); return fail_add(what); };
+    P.n = n; P.frame = frame != 0;
     // kernel arguments: device memory, written once (a frame's inputs arrive at fixed pinned addresses)
     std::vector<char> host((size_t)n * kKargStride, 0);
-    if (hipMalloc((void**)&c->kargs, host.size()) != hipSuccess) return bail(c, err, err_len, "kernarg buffer");
+    if (hipMalloc((void**)&P.kargs, host.size()) != hipSuccess) { P.kargs = nullptr; return drop("kernarg buffer"); }
     // The LSTM launches find their per-row words in their own argument block (LiveGrid.hot): the linear1 kernel in front of them
     // writes them there. Launch i's LiveGrid sits behind its LiveFrame; the plan is K1 | l0 l1 | K4 | l0 l1 | K7.
     LiveGrid* hot[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (n == RC_LIVE_KERNELS) {
+    if (P.frame && n == RC_LIVE_KERNELS) {
         const int lstm[4] = {1, 2, 4, 5};
-        for (int q = 0; q < 4; ++q) hot[q] = reinterpret_cast<LiveGrid*>(c->kargs + (size_t)lstm[q] * kKargStride + sizeof(LiveFrame));
+        for (int q = 0; q < 4; ++q) hot[q] = reinterpret_cast<LiveGrid*>(P.kargs + (size_t)lstm[q] * kKargStride + sizeof(LiveFrame));
     }
     static const bool flag_env = [] { const char* e = std::getenv("RC_LIVE_DONE_FLAG"); return !e || std::atoi(e) != 0; }();
-    if (flag_env && n == RC_LIVE_KERNELS && k[0].F.B == 1) {
-        if (hipHostMalloc((void**)&c->flag_h, 64, hipHostMallocDefault) != hipSuccess) return bail(c, err, err_len, "completion word");
+    if (P.frame && flag_env && n == RC_LIVE_KERNELS && k[0].F.B == 1 && !c->flag_h) {
+        if (hipHostMalloc((void**)&c->flag_h, 64, hipHostMallocDefault) != hipSuccess) { c->flag_h = nullptr; return drop("completion word"); }
         *c->flag_h = 0;
-        if (hipMalloc((void**)&c->seq_d, 64) != hipSuccess || hipMemset(c->seq_d, 0, 64) != hipSuccess) return bail(c, err, err_len, "frame counter");
+        if (hipMalloc((void**)&c->seq_d, 64) != hipSuccess || hipMemset(c->seq_d, 0, 64) != hipSuccess) return drop("frame counter");
     }
     for (int i = 0; i < n; ++i) {
         LiveFrame F = k[i].F;
         for (int q = 0; q < 4; ++q) F.hot[q] = hot[q];
-        F.done_flag = (i == n - 1) ? c->flag_h : nullptr;
-        F.done_seq = (i == n - 1) ? c->seq_d : nullptr;
+        F.done_flag = (P.frame && i == n - 1) ? c->flag_h : nullptr;
+        F.done_seq = (P.frame && i == n - 1) ? c->seq_d : nullptr;
         std::memcpy(&host[(size_t)i * kKargStride], &F, sizeof(LiveFrame));
-        if (k[i].has_grid) {
+        if (k[i].has_grid == 1) {
             LiveGrid G = k[i].G;
             G.hot = hot[0] ? 1 : 0;
             std::memcpy(&host[(size_t)i * kKargStride + sizeof(LiveFrame)], &G, sizeof(LiveGrid));
+        } else if (k[i].has_grid == 2) {
+            const void* pbuf = k[i].G.prebuf;
+            std::memcpy(&host[(size_t)i * kKargStride + sizeof(LiveFrame)], &pbuf, sizeof(void*));
         }
     }
-    if (hipMemcpy(c->kargs, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return bail(c, err, err_len, "kernarg upload");
+    if (hipMemcpy(P.kargs, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return drop("kernarg upload");
     for (int i = 0; i < n; ++i) {
-        hsa_kernel_dispatch_packet_t& p = c->pkt[i];
+        hsa_kernel_dispatch_packet_t& p = P.pkt[i];
         std::memset(&p, 0, sizeof(p));
+        const unsigned wg = k[i].wg ? k[i].wg : 256u;
         p.setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
-        p.workgroup_size_x = 256; p.workgroup_size_y = 1; p.workgroup_size_z = 1;
-        p.grid_size_x = k[i].grid * 256u; p.grid_size_y = 1; p.grid_size_z = 1;
+        p.workgroup_size_x = (uint16_t)wg; p.workgroup_size_y = 1; p.workgroup_size_z = 1;
+        p.grid_size_x = k[i].grid * wg; p.grid_size_y = 1; p.grid_size_z = 1;
         p.private_segment_size = fs.priv[i]; p.group_segment_size = fs.group[i];
         p.kernel_object = fs.kobj[i];
-        p.kernarg_address = c->kargs + (size_t)i * kKargStride;
-        p.completion_signal = i == n - 1 ? c->done : hsa_signal_t{0};
+        p.kernarg_address = P.kargs + (size_t)i * kKargStride;
+        p.completion_signal = i == n - 1 ? (P.frame ? c->done : c->bg_done) : hsa_signal_t{0};
         // (RC_AQL_EDGE_SCOPE=agent: probe of what the two system-scope fences cost; the frame's host-side I/O is fine-grained memory)
         static const bool edge_agent = [] { const char* e = std::getenv("RC_AQL_EDGE_SCOPE"); return e && !std::strcmp(e, "agent"); }();
-        const int acq = (i == 0 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-        const int rel = (i == n - 1 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-        c->hdr[i] = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                               (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+        // a background program neither reads nor writes host memory: agent scope at both ends
+        const int acq = (P.frame && i == 0 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        const int rel = (P.frame && i == n - 1 && !edge_agent) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        P.hdr[i] = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
     }
-    *out = c;
+    return (int)c->prog.size() - 1;
+}
+
+// body first, header (which hands the packet to the packet processor) last; the barrier bit of every packet orders it behind everything
+// in front of it in the ring -- a frame behind the pre-step that ran in the idle time, the pre-step behind the frame whose state it reads
+static void aql_push(AqlChain* c, const AqlProgram& P) {
+    hsa_queue_t* q = c->q;
+    const uint32_t mask = q->size - 1;
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; at most one frame + one background program are in the ring
+    for (int i = 0; i < P.n; ++i) {
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & mask);
+        std::memcpy((char*)p + 4, (const char*)&P.pkt[i] + 4, sizeof(*p) - 4);
+        __atomic_store_n((uint32_t*)p, (uint32_t)P.hdr[i] | ((uint32_t)P.pkt[i].setup << 16), __ATOMIC_RELEASE);
+    }
+    hsa_queue_store_write_index_release(q, base + P.n);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + P.n - 1));
+}
+
+int rc_aql_submit(AqlChain* c, int prog) {
+    if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || c->prog[prog].frame) return -1;
+    if (c->dead) return -3;
+    aql_push(c, c->prog[prog]);
+    c->bg_seq += 1;
     return 0;
 }
 
-int rc_aql_run(AqlChain* c) {
-    if (!c || !c->q) return -1;
+int rc_aql_wait_background(AqlChain* c) {
+    if (!c || !c->q || c->bg_seq == 0) return 0;
+    const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)c->bg_seq);
+    if (hsa_signal_load_scacquire(c->bg_done) <= retired) return 0;
+    return hsa_signal_wait_scacquire(c->bg_done, HSA_SIGNAL_CONDITION_LT, retired + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) <= retired ? 0 : -2;
+}
+
+int rc_aql_run(AqlChain* c, int prog) {
+    if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || !c->prog[prog].frame) return -1;
     if (c->dead) return -3;
-    hsa_queue_t* q = c->q;
-    const uint32_t mask = q->size - 1;
     // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
-    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; at most the retirement of the previous frame is pending
-    for (int i = 0; i < c->n; ++i) {
-        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & mask);
-        // body first, header (which hands the packet to the packet processor) last
-        std::memcpy((char*)p + 4, (const char*)&c->pkt[i] + 4, sizeof(*p) - 4);
-        __atomic_store_n((uint32_t*)p, (uint32_t)c->hdr[i] | ((uint32_t)c->pkt[i].setup << 16), __ATOMIC_RELEASE);
-    }
-    hsa_queue_store_write_index_release(q, base + c->n);
-    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + c->n - 1));
+    aql_push(c, c->prog[prog]);
     const unsigned long long seq = ++c->seq;
     const unsigned seq32 = (unsigned)seq;                                   // what K7 stores: its device counter wraps the same way
     const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)seq);
@@ -233,8 +285,9 @@ int rc_aql_run(AqlChain* c) {
 
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
-    if (!c || !c->q || c->seq == 0) return;
-    (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+    if (!c || !c->q) return;
+    if (c->seq) (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
+    (void)rc_aql_wait_background(c);
 }
 
 void rc_aql_destroy(AqlChain* c) {
@@ -244,7 +297,8 @@ void rc_aql_destroy(AqlChain* c) {
     if (c->seq_d) (void)hipFree(c->seq_d);
     if (c->q) (void)hsa_queue_destroy(c->q);
     if (c->done.handle) (void)hsa_signal_destroy(c->done);
-    if (c->kargs) (void)hipFree(c->kargs);
+    if (c->bg_done.handle) (void)hsa_signal_destroy(c->bg_done);
+    for (AqlProgram& P : c->prog) if (P.kargs) (void)hipFree(P.kargs);
     if (c->hsa_up) (void)hsa_shut_down();
     delete c;
 }

@@ -196,7 +196,10 @@ struct rc_params_dev {
 // rnn7, rnn8) -- are IN the kernel arguments: on the AQL path (rc_aql.cpp) the arguments live in device memory of the context's own,
 // and the linear1 kernel that opens the steps (K1 / K4) writes them there, so the LSTM kernels have no dependent global read in
 // front of the weight stream. hot = 0 (graph replay, direct launches): read from the state.
-struct LiveGrid { int hot; int st[4][RC_LIVE_MAXB]; int act[4][RC_LIVE_MAXB]; };
+// `pre` (round 5, the idle-time pre-step): 1 = the recurrent half of this launch's layer steps -- the partial sums of waves 2 and 3 of every
+// tile, W_hh . h(t - 1) over their K ranges -- was computed after the PREVIOUS frame (rc_live_pre) and sits in `prebuf`; those waves load
+// it instead of streaming their half of the weights. Same MFMA chain per accumulator, same reduction order: bitwise the unhoisted step.
+struct LiveGrid { int hot; int st[4][RC_LIVE_MAXB]; int act[4][RC_LIVE_MAXB]; int pre; int pre_base; const float* prebuf; };
 struct LiveNet {
     const float *W1, *b1;           // linear1: pack_weights order [N/16][Kp1/16][64][4], bias
     const float *Wl[2], *bl[2];     // LSTM layers: pack_weights order, gate-interleaved columns; b_ih + b_hh
@@ -220,22 +223,33 @@ struct LiveFrame {
     int nc;                         // 16-column blocks per LSTM tile (1 or 2)
 };
 #define RC_LIVE_KERNELS 7
-struct LiveKernel {             // one launch of the lean frame: host function + symbol name, grid (workgroups of 256), arguments
+struct LiveKernel {             // one launch of the lean frame: host function + symbol name, grid (workgroups of `wg` threads), arguments
     const void* fn;
     const char* name;
     unsigned grid;
     int has_grid;               // arguments: (LiveFrame) or (LiveFrame, LiveGrid)
+    unsigned wg;                // threads per workgroup (0 = 256)
     LiveFrame F;
     LiveGrid G;
 };
-int rc_live_plan(const LiveFrame& F, LiveKernel* out);                // fills RC_LIVE_KERNELS entries, returns their number
-void rc_launch_live_frame(const LiveFrame& F, hipStream_t s);
+int rc_live_plan(const LiveFrame& F, LiveKernel* out, const float* prebuf = nullptr);   // fills RC_LIVE_KERNELS entries, returns their number;
+                                                                      // prebuf: the LSTM launches take their recurrent halves from it (LiveGrid.pre)
+int rc_live_pre_plan(const LiveFrame& F, float* prebuf, LiveKernel* out);   // the idle-time pre-step: ONE launch (rc_live_pre); returns 1, or 0
+long long rc_live_pre_floats(const LiveFrame& F);                     // size of prebuf
+void rc_launch_live_frame(const LiveFrame& F, hipStream_t s, const float* prebuf = nullptr);
+void rc_launch_live_pre(const LiveFrame& F, float* prebuf, hipStream_t s);
 
-// The same chain as AQL packets on an HSA queue of the context's own (rc_aql.cpp): rc_live_step then pays ~0.5 us of host time to
-// enqueue the frame instead of hipGraphLaunch's ~7 us, and polls the completion signal itself.
+// The same chains as AQL packets on an HSA queue of the context's own (rc_aql.cpp): rc_live_step then pays ~0.5 us of host time to
+// enqueue the frame instead of hipGraphLaunch's ~7 us, and polls the completion itself. A chain holds several PROGRAMS (packet lists
+// with their own argument blocks) on one queue: the lean frame, the lean frame on pre-computed recurrent halves, and the pre-step.
 struct AqlChain;
-int rc_aql_create(int hip_device, const LiveKernel* k, int n, AqlChain** out, char* err, int err_len);
-int rc_aql_run(AqlChain* c);                                          // submit, then spin until the last packet's signal; 0 = done
+int rc_aql_create(int hip_device, AqlChain** out, char* err, int err_len);
+// a program of n <= RC_LIVE_KERNELS launches; frame != 0: a live frame (its last kernel stores the completion word, its last packet carries
+// the frame signal), else a background program (pre-step) with a signal of its own. Returns the program id (>= 0) or -1.
+int rc_aql_add(AqlChain* c, const LiveKernel* k, int n, int frame, char* err, int err_len);
+int rc_aql_run(AqlChain* c, int prog);                                // frame program: submit, then spin until it retired; 0 = done
+int rc_aql_submit(AqlChain* c, int prog);                             // background program: submit and return
+int rc_aql_wait_background(AqlChain* c);                              // until every submitted background program has retired
 void rc_aql_destroy(AqlChain* c);
 
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);

@@ -321,7 +321,8 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     constexpr int D = NC == 1 ? 8 : 4, UT = 4 * NC, NT = 16 * NC, LD = NT + 16;
     __shared__ __attribute__((aligned(16))) float s_part[4 * 16 * LD];
     __shared__ __attribute__((aligned(16))) float s_h[RC_LIVE_MAXB][UT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // problem (order: stage 1 rnn4, rnn2; stage 2 rnn6, rnn3, rnn7, rnn8 -- longest K first) and tile from the block id alone
     const int b = (int)blockIdx.x;
     constexpr int TB = (STAGE == 1 ? LIVE_H4 : LIVE_H6) / UT, TS = LIVE_H5 / UT;   // tiles of the big net / of an H = 512 net
@@ -346,19 +347,32 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     const int* const steps = n.steps;
     const long long BpH = n.BpH;
     const int out = n.out, outp = n.outp, hot = G.hot;
+    // the recurrent half from the pre-step (LiveGrid.pre): waves 2 and 3 own exactly the K range of [.. | h] that reads the layer's own h
+    const int g_pre = G.pre, g_pre_base = G.pre_base;
+    const float* const g_prebuf = G.prebuf;
     const int hs0 = G.st[pi][0], hs1 = G.st[pi][1], hs2 = G.st[pi][2], hs3 = G.st[pi][3];
     const int ha0 = G.act[pi][0], ha1 = G.act[pi][1], ha2 = G.act[pi][2], ha3 = G.act[pi][3];
     const unsigned char* const flags2 = F.fb.flags2;
     asm volatile("; kernel arguments in" ::"s"(B), "s"(Wl), "s"(bl), "s"(cbase), "s"(hbase), "s"(x1), "s"(W2), "s"(part), "s"(steps), "s"(BpH),
-                 "s"(out), "s"(outp), "s"(hot), "s"(hs0), "s"(hs1), "s"(hs2), "s"(hs3), "s"(ha0), "s"(ha1), "s"(ha2), "s"(ha3), "s"(flags2));
+                 "s"(out), "s"(outp), "s"(hot), "s"(hs0), "s"(hs1), "s"(hs2), "s"(hs3), "s"(ha0), "s"(ha1), "s"(ha2), "s"(ha3), "s"(flags2),
+                 "s"(g_pre), "s"(g_pre_base), "s"(g_prebuf));
+    const bool from_pre = g_pre != 0 && wave >= 2;
+    const f32x4* const prebuf = reinterpret_cast<const f32x4*>(g_prebuf) + ((long long)(g_pre_base + b) * 2 + (wave - 2)) * 64 + lane;
     // ---- the weight stream first: it depends on nothing but the block id
     const int Q = 2 * H / 16, Qw = Q / 4;                                  // chunks per wave: 16 / 32 / 40 (multiples of D)
     const long long bstride = (long long)Q * 256;
     const float* pb = Wl + ((long long)(n_tile * NC) * Q + (long long)wave * Qw) * 256 + lane * 4;
     f32x4 fa[D], fw[D][NC];
 #define LB(d, qi) do { _Pragma("unroll") for (int j_ = 0; j_ < NC; ++j_) fw[d][j_] = ldg_nt(pb + (long long)(qi) * 256 + j_ * bstride); } while (0)
+    f32x4 acc[NC];
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) LB(d, d);
+    for (int j = 0; j < NC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (from_pre) {
+        if constexpr (NC == 1) acc[0] = *prebuf;                           // (the pre-step is built for 16 x 16 tiles only: rc_live_pre_plan)
+    } else {
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) LB(d, d);
+    }
     // ---- every per-row word of this workgroup, one batch behind the first weight requests
     const int ri = i < B ? i : B - 1;
     const int er = tid / UT, eu = tid - er * UT;                           // epilogue item: row er, unit eu of the tile
@@ -397,13 +411,12 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     const int kbase = wave * Qw * 16;
 #define LA(d, qi) do { const int k_ = kbase + (qi) * 16; fa[d] = k_ < H ? *reinterpret_cast<const f32x4*>(pa0 + (long long)k_ * 16) \
                                                                         : *reinterpret_cast<const f32x4*>(pa1 + (long long)(k_ - H) * 16); } while (0)
+    if (!from_pre) {
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) LA(d, d);
-    f32x4 acc[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < D - 1; ++d) LA(d, d);
+    }
     RC_LT(3, 1 + 5 * LAYER);
-    for (int q = 0; q + D <= Qw; q += D) {
+    for (int q = 0; q + D <= Qw && !from_pre; q += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int qi = min(q + d + D - 1, Qw - 1);                    // past the end: a redundant, valid load, no branch
@@ -527,6 +540,69 @@ LIVE_LSTM(rc_live_s1_l0, 1, 0, 1) LIVE_LSTM(rc_live_s1_l1, 1, 1, 1) LIVE_LSTM(rc
 LIVE_LSTM(rc_live_s1_l0w, 1, 0, 2) LIVE_LSTM(rc_live_s1_l1w, 1, 1, 2) LIVE_LSTM(rc_live_s2_l0w, 2, 0, 2) LIVE_LSTM(rc_live_s2_l1w, 2, 1, 2)
 #undef LIVE_LSTM
 
+// ================================================================================== the idle-time pre-step (round 5, BASELINE config 5)
+// Between two frames of a 60 fps stream the device idles for 16.6 ms, and half of every LSTM layer step of the NEXT frame is already
+// determined: gates = W_ih x(t) + W_hh h(t - 1), and h(t - 1) is final when frame t - 1 returns (live_server.py:40-48 hands over one
+// frame per call). In the K split of a 16 x 16 tile waves 2 and 3 own exactly the K range of [x | h] that reads the layer's own h, so
+// their accumulators ARE W_hh h(t - 1): this kernel computes them for every tile of all twelve layer steps (122 of the 243 MB of
+// weights, one launch, 2,176 two-wave workgroups) and stores them; the frame's LSTM launches then stream only the x halves and load
+// these 2 KB per tile (LiveGrid.pre). The MFMA chain per accumulator -- chunk order, four products per chunk, fp32 accumulation from
+// zero -- is live_lstm_body's, so the layer steps stay bitwise what they are without the pre-step (tests/test_gpu_live.py).
+// Which copy of h: the step the next frame takes is number steps[row] + 1 and reads copy (steps[row] + 1 + 2) % 3 = steps[row] % 3. A
+// row whose sub-net does NOT step in that frame (rnn4 / rnn6 of an occluded row without a deferred step) reads another copy there; its
+// result is discarded either way.
+#define LIVE_T1 ((LIVE_H4 + LIVE_H5) / 4)      // tiles of a stage-1 layer launch (16 x 16 tiles: 4 units each)
+#define LIVE_T2 ((LIVE_H6 + 3 * LIVE_H5) / 4)  // ... of a stage-2 layer launch
+extern "C" __global__ __launch_bounds__(128) void rc_live_pre(const LiveFrame F, float* const prebuf) {
+    constexpr int D = 8;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
+    const int wave = 2 + __builtin_amdgcn_readfirstlane(tid >> 6);          // the wave of live_lstm_body whose K range this is
+    int b = (int)blockIdx.x;
+    const int tile_global = b;
+    const int stage = b < 2 * LIVE_T1 ? 1 : 2;
+    if (stage == 2) b -= 2 * LIVE_T1;
+    const int per = stage == 1 ? LIVE_T1 : LIVE_T2;
+    const int layer = b / per;
+    b -= layer * per;
+    const int TB = (stage == 1 ? LIVE_H4 : LIVE_H6) / 4, TS = LIVE_H5 / 4;
+    const int pi = b < TB ? 0 : 1 + (b - TB) / TS;
+    const int ni = stage == 1 ? (pi == 0 ? LN4 : LN2) : (pi == 0 ? LN6 : (pi == 1 ? LN3 : (pi == 2 ? LN7 : LN8)));
+    const int H = pi == 0 ? (stage == 1 ? LIVE_H4 : LIVE_H6) : LIVE_H5;
+    const int n_tile = pi == 0 ? b : (b - TB) - (pi - 1) * TS;
+    const LiveNet& n = F.net[ni];
+    const int B = F.B;
+    const float* const Wl = n.Wl[layer];
+    const float* const hbase = n.h;
+    const int* const steps = n.steps;
+    const long long BpH = n.BpH;
+    asm volatile("; kernel arguments in" ::"s"(B), "s"(Wl), "s"(hbase), "s"(steps), "s"(BpH));
+    const int Q = 2 * H / 16, Qw = Q / 4;
+    const float* pb = Wl + ((long long)n_tile * Q + (long long)wave * Qw) * 256 + lane * 4;
+    f32x4 fa[D], fw[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) fw[d] = ldg_nt(pb + (long long)d * 256);
+    const int ri = i < B ? i : B - 1;
+    const int st = steps[ri];
+    const float* pa1 = hbase + (long long)(layer * RC_HBUF + st % RC_HBUF) * BpH + rc_pk(ri, 4 * kq, H);
+    const int kbase = wave * Qw * 16 - H;                                   // (k - H of this wave's first chunk: >= 0)
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) fa[d] = *reinterpret_cast<const f32x4*>(pa1 + (long long)(kbase + d * 16) * 16);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q + D <= Qw; q += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int qi = min(q + d + D - 1, Qw - 1);
+            fa[(d + D - 1) % D] = *reinterpret_cast<const f32x4*>(pa1 + (long long)(kbase + qi * 16) * 16);
+            fw[(d + D - 1) % D] = ldg_nt(pb + (long long)qi * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[d][s_], fw[d][s_], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    reinterpret_cast<f32x4*>(prebuf)[((long long)tile_global * 2 + (wave - 2)) * 64 + lane] = acc;
+}
+
 #ifdef RC_LIVE_TRACE
 extern "C" int rc_live_trace_read(unsigned long long* out) {      // [4][16] stamps of the last frame (probe builds only)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_live_tt), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
@@ -534,32 +610,50 @@ extern "C" int rc_live_trace_read(unsigned long long* out) {      // [4][16] sta
 #endif
 
 // ============================================================================================================= the frame's launches
-int rc_live_plan(const LiveFrame& F, LiveKernel* k) {
+int rc_live_plan(const LiveFrame& F, LiveKernel* k, const float* prebuf) {
     for (int i = 0; i < 6; ++i)
         if (F.net[i].H != live_H(i)) return 0;                             // not the architecture these kernels are compiled for
     if (F.net[LN2].Kp1 != 128) return 0;
     for (int i : {LN3, LN4, LN6, LN7, LN8}) if (F.net[i].Kp1 != 256) return 0;
+    if (prebuf && F.nc != 1) return 0;
     const unsigned ut = 4u * (unsigned)F.nc;
     const unsigned wg1 = (LIVE_H4 + LIVE_H5) / ut, wg2 = (LIVE_H6 + 3 * LIVE_H5) / ut;
     const bool w = F.nc == 2;
-    auto set = [&](int i, const void* fn, const char* name, unsigned grid, int has_grid) {
-        k[i].fn = fn; k[i].name = name; k[i].grid = grid; k[i].F = F; k[i].G = LiveGrid{}; k[i].has_grid = has_grid;
+    auto set = [&](int i, const void* fn, const char* name, unsigned grid, int has_grid, int pre_base = 0) {
+        k[i].fn = fn; k[i].name = name; k[i].grid = grid; k[i].F = F; k[i].G = LiveGrid{}; k[i].has_grid = has_grid; k[i].wg = 256;
+        if (has_grid && prebuf) { k[i].G.pre = 1; k[i].G.pre_base = pre_base; k[i].G.prebuf = prebuf; }
     };
     set(0, (const void*)rc_live_k1, "rc_live_k1", (LIVE_H4 + LIVE_H5) / 16, 0);
-    set(1, w ? (const void*)rc_live_s1_l0w : (const void*)rc_live_s1_l0, w ? "rc_live_s1_l0w" : "rc_live_s1_l0", wg1, 1);
-    set(2, w ? (const void*)rc_live_s1_l1w : (const void*)rc_live_s1_l1, w ? "rc_live_s1_l1w" : "rc_live_s1_l1", wg1, 1);
+    set(1, w ? (const void*)rc_live_s1_l0w : (const void*)rc_live_s1_l0, w ? "rc_live_s1_l0w" : "rc_live_s1_l0", wg1, 1, 0);
+    set(2, w ? (const void*)rc_live_s1_l1w : (const void*)rc_live_s1_l1, w ? "rc_live_s1_l1w" : "rc_live_s1_l1", wg1, 1, LIVE_T1);
     set(3, (const void*)rc_live_k4, "rc_live_k4", (LIVE_H6 + 3 * LIVE_H5) / 16, 0);
-    set(4, w ? (const void*)rc_live_s2_l0w : (const void*)rc_live_s2_l0, w ? "rc_live_s2_l0w" : "rc_live_s2_l0", wg2, 1);
-    set(5, w ? (const void*)rc_live_s2_l1w : (const void*)rc_live_s2_l1, w ? "rc_live_s2_l1w" : "rc_live_s2_l1", wg2, 1);
+    set(4, w ? (const void*)rc_live_s2_l0w : (const void*)rc_live_s2_l0, w ? "rc_live_s2_l0w" : "rc_live_s2_l0", wg2, 1, 2 * LIVE_T1);
+    set(5, w ? (const void*)rc_live_s2_l1w : (const void*)rc_live_s2_l1, w ? "rc_live_s2_l1w" : "rc_live_s2_l1", wg2, 1, 2 * LIVE_T1 + LIVE_T2);
     set(6, (const void*)rc_live_k7, "rc_live_k7", (unsigned)F.B, 0);
     return RC_LIVE_KERNELS;
 }
 
-void rc_launch_live_frame(const LiveFrame& F, hipStream_t st) {
+long long rc_live_pre_floats(const LiveFrame&) { return (long long)(2 * LIVE_T1 + 2 * LIVE_T2) * 2 * 64 * 4; }
+
+// the pre-step as a "program" of one launch; its second argument (the buffer) travels in LiveGrid's place: see rc_aql.cpp (has_grid = 2)
+int rc_live_pre_plan(const LiveFrame& F, float* prebuf, LiveKernel* k) {
+    for (int i = 0; i < 6; ++i)
+        if (F.net[i].H != live_H(i)) return 0;
+    if (F.nc != 1 || !prebuf) return 0;
+    k[0].fn = (const void*)rc_live_pre; k[0].name = "rc_live_pre"; k[0].grid = 2 * LIVE_T1 + 2 * LIVE_T2; k[0].wg = 128;
+    k[0].F = F; k[0].G = LiveGrid{}; k[0].G.prebuf = prebuf; k[0].has_grid = 2;
+    return 1;
+}
+
+void rc_launch_live_frame(const LiveFrame& F, hipStream_t st, const float* prebuf) {
     static thread_local LiveKernel k[RC_LIVE_KERNELS];
-    const int n = rc_live_plan(F, k);
+    const int n = rc_live_plan(F, k, prebuf);
     for (int i = 0; i < n; ++i) {
         void* args[2] = {(void*)&k[i].F, (void*)&k[i].G};
         (void)hipLaunchKernel(k[i].fn, dim3(k[i].grid), dim3(256), args, 0, st);
     }
+}
+
+void rc_launch_live_pre(const LiveFrame& F, float* prebuf, hipStream_t st) {
+    hipLaunchKernelGGL(rc_live_pre, dim3(2 * LIVE_T1 + 2 * LIVE_T2), dim3(128), 0, st, F, prebuf);
 }

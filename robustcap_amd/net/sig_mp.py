@@ -267,6 +267,13 @@ class Net:
         _lib.check(self._ctx, self._lib.rc_get_live_stats(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_stats")
         return a.value, b.value
 
+    def live_prestep_stats(self):
+        """(pre-steps enqueued so far, whether the live session carries the pre-step programs): rc_get_live_prestep -- the recurrent
+        halves of the next frame's layer steps, computed while a paced (60 fps) caller leaves the device idle between two frames."""
+        a, b = C.c_int64(0), C.c_int32(0)
+        _lib.check(self._ctx, self._lib.rc_get_live_prestep(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_prestep")
+        return a.value, bool(b.value)
+
     @torch.no_grad()
     def forward_sequence(self, j2dc, accc, oric, first_tran=None, first_frame=False):
         """The evaluate.py frame loop (evaluate.py:75-83) for B sequences of T frames in one call.

@@ -83,6 +83,8 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     lv = var["live_b1"]
     assert "error" not in lv and 0 < lv["p50_us"] <= lv["p99_us"]
     assert lv["lean_frames"] > 0.9 * lv["frames"] and lv["launches_per_lean_frame"] == 7 and lv["dispatch"]
+    pc = lv["paced_60fps"]                                            # config 5 as stated: a frame every 16.67 ms, latency from its arrival
+    assert pc["frames"] >= 900 and 0 < pc["p50_us"] <= pc["p99_us"] and abs(pc["period_ms"] - 16.667) < 0.01
     if "graph_replay" in lv:
         assert 0 < lv["graph_replay"]["p50_us"] <= lv["graph_replay"]["p99_us"]
     if not extra:

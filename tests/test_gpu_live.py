@@ -201,3 +201,50 @@ def test_lean_capture_follows_reset_and_parameter_pokes(synth_assets):
     a.load_state_dict(synth_assets["state_dict"]); b.load_state_dict(synth_assets["state_dict"])
     assert run(0, 20, False) <= 1e-5
     assert b.live_stats()[0] > 40
+
+
+@pytest.mark.parametrize("path", SEQS, ids=[os.path.basename(p)[4:-4] for p in SEQS])
+def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch):
+    """The idle-time pre-step (rc_live_pre: the recurrent halves of the NEXT frame's layer steps, computed behind a frame when the caller
+    paces its frames) forced behind EVERY frame (RC_LIVE_PRESTEP_IDLE_US=0): outputs, branch traces and final states bitwise those of the
+    same frames without it -- the K order of every accumulator is kept -- on all reference sequences (regime changes, occlusions,
+    init_net, resets of the translation: frames off the lean plan run from the full captures and discard the pre-step)."""
+    s = np.load(path)
+    live = str(s["live"])
+    outs = []
+    for env in ({"RC_LIVE_PRESTEP": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = make_net(synth_assets, 1, live_ctor=(live == "pre"))
+        from robustcap_amd.net.sig_mp import Net
+        Net.live = False
+        if live == "post":
+            net.live = True
+        net.use_flat_floor = bool(s["use_flat_floor"])
+        net.use_reproj_opt = bool(s["use_reproj_opt"]) if "use_reproj_opt" in s else False
+        net.use_vision_updater = bool(s["use_vision_updater"]) if "use_vision_updater" in s else True
+        net.use_imu_updater = bool(s["use_imu_updater"]) if "use_imu_updater" in s else True
+        net.gravityc = t(s["gravityc"])
+        net.use_graph = True
+        ft = t(s["first_tran"]) if s["first_tran"].size else None
+        T = s["pose"].shape[0]
+        poses, trans, traces = [], [], []
+        for i in range(T):
+            p, tr = net.forward_online(t(s["j2dc"][i]), t(s["accc"][i]), t(s["oric"][i]), ft if i == 0 else None,
+                                       bool(s["first_frame"]) and i == 0)
+            poses.append(p.clone()), trans.append(tr.clone())
+            if i % 7 == 0:
+                traces.append(net.get_trace()[0].tolist())
+        n_pre, avail = net.live_prestep_stats()
+        states = {n: net.get_state(n) for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8")}
+        outs.append((torch.stack(poses), torch.stack(trans), traces, states, n_pre, avail, net.live_stats()))
+        del net
+    a, b = outs
+    assert a[4] == 0
+    if b[5]:                                                              # (a profiler on the queue, RC_LIVE_AQL=0: no AQL chain, no pre-step)
+        assert b[4] >= b[6][0] - 1 and b[4] > 0                           # behind every frame
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[6] == b[6]
+    for n in a[3]:
+        assert torch.equal(a[3][n][0], b[3][n][0]) and torch.equal(a[3][n][1], b[3][n][1]), n

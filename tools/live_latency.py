@@ -34,8 +34,10 @@ def run(net, m, n):
     return lat[50:] * 1e6
 
 
-def run_c(net, m, n):
-    """The library call alone (rc_live_step through ctypes on preallocated host tensors): what a C caller of the ABI sees."""
+def run_c(net, m, n, period_s=0.0):
+    """The library call alone (rc_live_step through ctypes on preallocated host tensors): what a C caller of the ABI sees.
+    period_s > 0: the frames ARRIVE every period_s (60 fps: 1 / 60) -- the caller sleeps until shortly before the arrival, spins to it,
+    and the latency is measured from the arrival to the outputs on the host, like live_server.py:40-48 receiving a camera frame."""
     import ctypes as C
     t = torch.from_numpy
     T = m["j2dc"].shape[1]
@@ -46,9 +48,19 @@ def run_c(net, m, n):
     pp, pt = C.c_void_p(pose.data_ptr()), C.c_void_p(tran.data_ptr())
     ptrs = [(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr())) for a, b, c in ins]
     lat = np.empty(n)
+    t_next = time.perf_counter() + period_s
     for i in range(n):
         a, b, c = ptrs[1 + i % (T - 1)]
-        t0 = time.perf_counter()
+        if period_s > 0:
+            slack = t_next - time.perf_counter() - 1e-3
+            if slack > 0:
+                time.sleep(slack)
+            while time.perf_counter() < t_next:
+                pass
+            t0 = t_next
+            t_next += period_s
+        else:
+            t0 = time.perf_counter()
         rc = fn(ctx, a, b, c, None, 0, pp, pt)
         lat[i] = time.perf_counter() - t0
         assert rc == 0
@@ -101,6 +113,14 @@ def main():
             net._lib.rc_get_live_backend(net._ctx, C.byref(a), C.byref(b), note, 256)
             out[mode]["backend"] = {"lean_captured": a.value, "aql": b.value, "note": note.value.decode()}
         del net
+    # BASELINE config 5 as stated: 60 fps. The frames arrive every 16.67 ms; between two frames the device idles (clocks, caches).
+    n_paced = int(os.environ.get("RC_PACED_FRAMES", "1200"))
+    if n_paced > 0:
+        for name, env in (("paced_60fps", {}), ("paced_60fps_graph_replay", {"RC_LIVE_AQL": "0"}), ("paced_60fps_no_prestep", {"RC_LIVE_PRESTEP": "0"})):
+            net = make(sd, body, m, env=env)
+            out[name] = stats(run_c(net, m, n_paced, 1.0 / 60.0))
+            out[name]["frames"] = n_paced - 50
+            del net
     if variants:
         out["variants"] = {}
         for name, env in (("lean_off", {"RC_LIVE_LEAN": "0"}), ("lean_nc2", {"RC_LIVE_LEAN_NC": "2"}), ("lean_graph", {"RC_LIVE_AQL": "0"}), ("lean_signal", {"RC_LIVE_DONE_FLAG": "0"}), ("lean_edge_agent", {"RC_AQL_EDGE_SCOPE": "agent"}),
