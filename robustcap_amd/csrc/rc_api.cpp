@@ -1775,10 +1775,11 @@ int rc_live_begin(rc_ctx* ctx) {
                     // (an allocation or a symbol failed) the chain simply keeps the one frame program
                     const size_t nf = (size_t)rc_live_pre_floats(F);
                     if (hipMalloc((void**)&ctx->live_pre_buf, nf * sizeof(float)) == hipSuccess && hipMemset(ctx->live_pre_buf, 0, nf * sizeof(float)) == hipSuccess) {
-                        std::vector<LiveKernel> plan2(RC_LIVE_KERNELS), plan3(1);
-                        if (rc_live_plan(F, plan2.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS && rc_live_pre_plan(F, ctx->live_pre_buf, plan3.data()) == 1) {
+                        std::vector<LiveKernel> plan2(RC_LIVE_KERNELS), plan3(2);
+                        const int n3 = rc_live_pre_plan(F, ctx->live_pre_buf, plan3.data());
+                        if (rc_live_plan(F, plan2.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS && n3 >= 1) {
                             ctx->aql_prog_lean_pre = rc_aql_add(ctx->live_aql, plan2.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
-                            if (ctx->aql_prog_lean_pre >= 0) ctx->aql_prog_pre = rc_aql_add(ctx->live_aql, plan3.data(), 1, 0, msg, (int)sizeof(msg));
+                            if (ctx->aql_prog_lean_pre >= 0) ctx->aql_prog_pre = rc_aql_add(ctx->live_aql, plan3.data(), n3, 0, msg, (int)sizeof(msg));
                         }
                     } else { ctx->live_pre_buf = nullptr; (void)hipGetLastError(); }
                     if (ctx->aql_prog_pre < 0) ctx->aql_prog_lean_pre = -1;

@@ -234,7 +234,7 @@ struct LiveKernel {             // one launch of the lean frame: host function +
 };
 int rc_live_plan(const LiveFrame& F, LiveKernel* out, const float* prebuf = nullptr);   // fills RC_LIVE_KERNELS entries, returns their number;
                                                                       // prebuf: the LSTM launches take their recurrent halves from it (LiveGrid.pre)
-int rc_live_pre_plan(const LiveFrame& F, float* prebuf, LiveKernel* out);   // the idle-time pre-step: ONE launch (rc_live_pre); returns 1, or 0
+int rc_live_pre_plan(const LiveFrame& F, float* prebuf, LiveKernel* out);   // the idle-time pre-step: rc_live_pre (+ rc_live_warm); returns 1 or 2 launches, or 0
 long long rc_live_pre_floats(const LiveFrame& F);                     // size of prebuf
 void rc_launch_live_frame(const LiveFrame& F, hipStream_t s, const float* prebuf = nullptr);
 void rc_launch_live_pre(const LiveFrame& F, float* prebuf, hipStream_t s);

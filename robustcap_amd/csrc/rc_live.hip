@@ -22,6 +22,7 @@
 #include "rc_device.h"
 #include "rc_frame_dev.h"
 #include "rc_gates.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { LN2 = 0, LN3 = 1, LN4 = 2, LN6 = 3, LN7 = 4, LN8 = 5 };     // rc_api.cpp: kNets order
@@ -633,6 +634,7 @@ int rc_live_plan(const LiveFrame& F, LiveKernel* k, const float* prebuf) {
     return RC_LIVE_KERNELS;
 }
 
+extern "C" __global__ void rc_live_warm(const LiveFrame F, float* const sink);
 long long rc_live_pre_floats(const LiveFrame&) { return (long long)(2 * LIVE_T1 + 2 * LIVE_T2) * 2 * 64 * 4; }
 
 // the pre-step as a "program" of one launch; its second argument (the buffer) travels in LiveGrid's place: see rc_aql.cpp (has_grid = 2)
@@ -642,7 +644,12 @@ int rc_live_pre_plan(const LiveFrame& F, float* prebuf, LiveKernel* k) {
     if (F.nc != 1 || !prebuf) return 0;
     k[0].fn = (const void*)rc_live_pre; k[0].name = "rc_live_pre"; k[0].grid = 2 * LIVE_T1 + 2 * LIVE_T2; k[0].wg = 128;
     k[0].F = F; k[0].G = LiveGrid{}; k[0].G.prebuf = prebuf; k[0].has_grid = 2;
-    return 1;
+    // (measured, paced 60 fps, p50: 82.6 us with the warm pass, 83.7 without, 99.4 without the pre-step -- within the box-to-box noise: off)
+    static const bool warm = [] { const char* e = std::getenv("RC_LIVE_PREWARM"); return e && std::atoi(e) != 0; }();
+    if (!warm) return 1;
+    k[1] = k[0];
+    k[1].fn = (const void*)rc_live_warm; k[1].name = "rc_live_warm";
+    return 2;
 }
 
 void rc_launch_live_frame(const LiveFrame& F, hipStream_t st, const float* prebuf) {
@@ -652,6 +659,34 @@ void rc_launch_live_frame(const LiveFrame& F, hipStream_t st, const float* prebu
         void* args[2] = {(void*)&k[i].F, (void*)&k[i].G};
         (void)hipLaunchKernel(k[i].fn, dim3(k[i].grid), dim3(256), args, 0, st);
     }
+}
+
+// ---- ... and the OTHER half of the weights left in the Infinity Cache (round 5). The input halves W_ih (waves 0 and 1 of every tile: 122 MB)
+// are what the next frame still has to stream; nothing else runs on the device until it arrives, so reading them once -- ordinary loads,
+// which allocate in the 256 MB memory-side cache, behind the pre-step's non-temporal pass over the recurrent halves -- leaves them there,
+// and the frame's launches stream from the cache instead of from HBM. Nothing is computed: the loaded words are summed into a value the
+// kernel never stores (the comparison keeps hipcc from dropping the loads).
+extern "C" __global__ __launch_bounds__(128) void rc_live_warm(const LiveFrame F, float* const sink) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // the wave of live_lstm_body whose K range this is (0, 1)
+    int b = (int)blockIdx.x;
+    const int stage = b < 2 * LIVE_T1 ? 1 : 2;
+    if (stage == 2) b -= 2 * LIVE_T1;
+    const int per = stage == 1 ? LIVE_T1 : LIVE_T2;
+    const int layer = b / per;
+    b -= layer * per;
+    const int TB = (stage == 1 ? LIVE_H4 : LIVE_H6) / 4, TS = LIVE_H5 / 4;
+    const int pi = b < TB ? 0 : 1 + (b - TB) / TS;
+    const int ni = stage == 1 ? (pi == 0 ? LN4 : LN2) : (pi == 0 ? LN6 : (pi == 1 ? LN3 : (pi == 2 ? LN7 : LN8)));
+    const int H = pi == 0 ? (stage == 1 ? LIVE_H4 : LIVE_H6) : LIVE_H5;
+    const int n_tile = pi == 0 ? b : (b - TB) - (pi - 1) * TS;
+    const float* const Wl = F.net[ni].Wl[layer];
+    const int Q = 2 * H / 16, Qw = Q / 4;
+    const float* pb = Wl + ((long long)n_tile * Q + (long long)wave * Qw) * 256 + lane * 4;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int q = 0; q < Qw; ++q) a += *reinterpret_cast<const f32x4*>(pb + (long long)q * 256);
+    if (a[0] + a[1] + a[2] + a[3] == 1.2345678e38f) sink[0] = a[0];
 }
 
 void rc_launch_live_pre(const LiveFrame& F, float* prebuf, hipStream_t st) {

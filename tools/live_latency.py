@@ -116,7 +116,7 @@ def main():
     # BASELINE config 5 as stated: 60 fps. The frames arrive every 16.67 ms; between two frames the device idles (clocks, caches).
     n_paced = int(os.environ.get("RC_PACED_FRAMES", "1200"))
     if n_paced > 0:
-        for name, env in (("paced_60fps", {}), ("paced_60fps_graph_replay", {"RC_LIVE_AQL": "0"}), ("paced_60fps_no_prestep", {"RC_LIVE_PRESTEP": "0"})):
+        for name, env in (("paced_60fps", {}), ("paced_60fps_graph_replay", {"RC_LIVE_AQL": "0"}), ("paced_60fps_no_prestep", {"RC_LIVE_PRESTEP": "0"}), ("paced_60fps_prestep_warm", {"RC_LIVE_PREWARM": "1"})):
             net = make(sd, body, m, env=env)
             out[name] = stats(run_c(net, m, n_paced, 1.0 / 60.0))
             out[name]["frames"] = n_paced - 50
