@@ -343,6 +343,7 @@ struct VecOp { const float* a; const float* b; const float* c; float* out; float
 struct VecCombRow { VecComb c; float* out; long long n; };
 struct VecJobN { const float* a; const float* b; int op; int pad_; long long n; };
 void rc_launch_smplify_rows(const SmplifyArgs* rows_dev, int n_rows, int T_max, const BodyConst* body, hipStream_t s);
+void rc_launch_smplify_totals(const SmplifyArgs* rows_dev, int n_rows, double* out_dev, hipStream_t s);   // total loss per table entry, the host's summation order
 // set-up and wrap-up of a batch of rows (rc_smplify_run_batch) in one launch each: what rc_smplify_run does per row with
 // rc_launch_residual / rc_launch_R2aa / rc_launch_body_fk / rc_launch_aa2R and two device-to-device copies
 struct SmplifyRowIO {

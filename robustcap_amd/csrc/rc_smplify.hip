@@ -435,6 +435,33 @@ void rc_launch_smplify(const SmplifyArgs& A, const BodyConst* body, hipStream_t 
     hipLaunchKernelGGL(rc_smplify_fwd_kernel, dim3(A.T), dim3(64), 0, st, A, body);
     hipLaunchKernelGGL(rc_smplify_grad_kernel, dim3(A.T), dim3(128), 0, st, A, body);
 }
+// ---- total loss of every row of a round, on the device (round 5). The host used to read the per-frame terms of ALL rows back every round
+// (518 KB for 72 rows x 600 frames) and add them in double: 0.2 of a round's 0.77 ms. One wave per row reads its 3 T terms 64 at a time
+// and adds them in the HOST's order -- frame by frame, three running sums, the lane's value broadcast to the whole wave so that every lane
+// carries the same chain; no fused multiply-add in the last line -- so the sum is bit for bit total_loss() of rc_smplify_api.cpp
+// (losses.py:57-87: the IMU term counts T times), and a row's line search takes the decisions it takes alone.
+__global__ __launch_bounds__(64) void rc_smplify_total_rows_kernel(const SmplifyArgs* __restrict__ rows, double* __restrict__ out) {
+    const SmplifyArgs* A = rows + blockIdx.x;
+    const int T = A->T, lane = threadIdx.x;
+    const float* fl = A->frame_loss; const float* il = A->imu_loss; const float* sl = A->smooth_loss;
+    double f = 0.0, imu = 0.0, sm = 0.0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const float vf = t < T ? fl[t] : 0.f, vi = t < T ? il[t] : 0.f, vs = t < T ? sl[t] : 0.f;
+        const int n = min(64, T - t0);
+        for (int k = 0; k < n; ++k) {
+            f = __dadd_rn(f, (double)__shfl(vf, k));
+            imu = __dadd_rn(imu, (double)__shfl(vi, k));
+            sm = __dadd_rn(sm, (double)__shfl(vs, k));
+        }
+    }
+    if (lane == 0) out[blockIdx.x] = __dadd_rn(__dadd_rn(f, __dmul_rn((double)T, imu)), sm);
+}
+void rc_launch_smplify_totals(const SmplifyArgs* rows_dev, int n_rows, double* out_dev, hipStream_t st) {
+    if (n_rows <= 0) return;
+    hipLaunchKernelGGL(rc_smplify_total_rows_kernel, dim3((unsigned)n_rows), dim3(64), 0, st, rows_dev, out_dev);
+}
+
 // The row (or job) of these launches comes from blockIdx.y, and a grid's y extent ends at 65,535: longer tables go out in slices of the
 // table (round-4 advice: a lock-step round of the batched optimiser can ask for 6 (max_iter + 1) inner products per row -- 606 jobs a
 // row at max_iter = 100 -- and failed as a whole from ~108 rows on).

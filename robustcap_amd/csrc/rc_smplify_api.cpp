@@ -467,6 +467,7 @@ struct RowReq {
     float pair_t = 0.0f;
     std::vector<VecJobN> jobs;        // inner products wanted (kind 1: the slot's five, kind 2: the Gram entries)
     int job0 = 0;                     // filled by the executor: first job of this row in the round's table
+    int arg0 = -1;                    // ... and, kind 1, the row's entry of the round's closure table (its total loss comes back there)
 };
 
 class RowBatch {
@@ -488,6 +489,8 @@ class RowBatch {
     VecJobN *jobs_d = nullptr, *jobs_h = nullptr;
     double *part_d = nullptr, *part_h = nullptr;
     float *terms_d = nullptr, *terms_h = nullptr;
+    double *total_d = nullptr, *total_h = nullptr;                       // total loss per closure-table entry of the round
+    bool device_totals = true;                                           // RC_SMPLIFY_DEVICE_TOTALS=0: read the per-frame terms back and add them on the host (A/B)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double device_ms = 0.0, round_ms = 0.0;                              // closure kernels (events) / wall time inside run_round
     int rounds = 0;
@@ -561,6 +564,7 @@ class RowBatch {
                 A.grad_aa = g; A.grad_tran = g + b.T * 72;
                 for (int e = 0; e < 9; ++e) A.K[e] = b.K[e];
                 A.ign_mask = ign; A.T = (int)b.T;
+                q->arg0 = n_args;
                 args_h[n_args++] = A;
             } else if (q->kind == 2) {
                 ops_h[n_ops++] = VecOp{q->g_new, q->g_old, b.dir, q->yv, q->sv, q->pair_t, 1, (long long)b.n};
@@ -596,12 +600,14 @@ class RowBatch {
             if (herr == hipSuccess) herr = hipEventRecord(ev0, st);
             rc_launch_smplify_rows(args_d, n_args, T_max, body, st);
             if (herr == hipSuccess) herr = hipEventRecord(ev1, st);
+            if (device_totals) rc_launch_smplify_totals(args_d, n_args, total_d, st);
         }
         rc_launch_vec_dots_rows(jobs_d, n_jobs, nb_max, part_d, st);
         if (n_jobs > 0 && herr == hipSuccess)
             herr = hipMemcpyAsync(part_h, part_d, (size_t)n_jobs * nb_max * sizeof(double), hipMemcpyDeviceToHost, st);
         if (n_args > 0 && herr == hipSuccess)
-            herr = hipMemcpyAsync(terms_h, terms_d, row.size() * (size_t)3 * T_max * sizeof(float), hipMemcpyDeviceToHost, st);
+            herr = device_totals ? hipMemcpyAsync(total_h, total_d, (size_t)n_args * sizeof(double), hipMemcpyDeviceToHost, st)
+                                 : hipMemcpyAsync(terms_h, terms_d, row.size() * (size_t)3 * T_max * sizeof(float), hipMemcpyDeviceToHost, st);
         if (herr == hipSuccess) herr = hipStreamSynchronize(st);
         if (herr == hipSuccess) herr = hipGetLastError();
         if (n_args > 0 && herr == hipSuccess) {
@@ -650,7 +656,7 @@ void lbfgs_row(RowBatch& B, const int r, const float lr, const int max_iter, Dev
         q.jobs.push_back(VecJobN{b.dir, nullptr, 1, 0, (long long)n});
         q.jobs.push_back(VecJobN{slot(k), slot(k), 0, 0, (long long)n});
         if (!B.submit(r, &q)) return false;
-        e.f = (float)total_loss(b.terms_h, b.T);
+        e.f = (float)(B.device_totals ? B.total_h[q.arg0] : total_loss(b.terms_h, b.T));
         e.gtd = (float)B.job_sum(q, 0, nb, false);
         e.gmax = (float)B.job_sum(q, 1, nb, true);
         e.gsum = (float)B.job_sum(q, 2, nb, false);
@@ -1111,6 +1117,7 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     const size_t o_args = dtake(nr * sizeof(SmplifyArgs)), o_ops = dtake(3 * nr * sizeof(VecOp)), o_comb = dtake(nr * sizeof(VecCombRow));
     const size_t o_jobs = dtake(nr * B.max_jobs * sizeof(VecJobN)), o_part = dtake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
     const size_t o_terms = dtake(nr * 3 * (size_t)B.T_max * 4);
+    const size_t o_total = dtake(nr * sizeof(double)), p_total = ptake(nr * sizeof(double));
     const size_t p_args = ptake(nr * sizeof(SmplifyArgs)), p_ops = ptake(3 * nr * sizeof(VecOp)), p_comb = ptake(nr * sizeof(VecCombRow));
     const size_t p_jobs = ptake(nr * B.max_jobs * sizeof(VecJobN)), p_part = ptake(nr * B.max_jobs * (size_t)B.nb_max * sizeof(double));
     const size_t p_terms = ptake(nr * 3 * (size_t)B.T_max * 4);
@@ -1134,6 +1141,8 @@ int rc_smplify_run_batch(rc_ctx* ctx, int32_t n_rows, const int64_t* T_rows, con
     B.jobs_d = (VecJobN*)(B.dev + o_jobs); B.part_d = (double*)(B.dev + o_part); B.terms_d = (float*)(B.dev + o_terms);
     B.args_h = (SmplifyArgs*)(B.pin + p_args); B.ops_h = (VecOp*)(B.pin + p_ops); B.comb_h = (VecCombRow*)(B.pin + p_comb);
     B.jobs_h = (VecJobN*)(B.pin + p_jobs); B.part_h = (double*)(B.pin + p_part); B.terms_h = (float*)(B.pin + p_terms);
+    B.total_d = (double*)(B.dev + o_total); B.total_h = (double*)(B.pin + p_total);
+    if (const char* e = std::getenv("RC_SMPLIFY_DEVICE_TOTALS"); e && *e == '0') B.device_totals = false;
     for (int r = 0; r < n_rows; ++r) {
         RowBuf& b = B.row[r];
         const Off& o = off[r];
