@@ -1848,10 +1848,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     const bool lean = ctx->live_exec_lean && !need_tr && !maybe_reach && !first_tran && !(flags & RC_FLAG_FIRST_FRAME);
     const auto t_staged = std::chrono::steady_clock::now();
     bool aql_done = false;
-    // (RC_LIVE_FAKE_PRE=1, timing probe only: every lean frame starts from whatever the pre-step buffer holds -- WRONG results, the
-    // lower bound of a frame whose recurrent halves were streamed off its critical path)
-    static const bool fake_pre = tune_env("RC_LIVE_FAKE_PRE", 0) != 0;
-    const bool use_pre = lean && ctx->live_aql && (ctx->live_pre_valid || fake_pre) && ctx->aql_prog_lean_pre >= 0;
+    const bool use_pre = lean && ctx->live_aql && ctx->live_pre_valid && ctx->aql_prog_lean_pre >= 0;
     ctx->live_pre_valid = false;                                  // (whatever this frame is, it moves the state on)
     if (!(lean && ctx->live_aql) && ctx->live_aql) {
         // this frame runs on the HIP stream: a pre-step still in the HSA queue must not read the state while the frame rewrites it
