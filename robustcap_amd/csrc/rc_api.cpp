@@ -937,6 +937,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         return launch_problems(ctx, collect(k, g), nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
     };
     std::vector<unsigned char> tick_ok((size_t)P.n_ticks, 0);
+    std::vector<std::vector<GemmProblem>> tick_rest((size_t)(tick_mode ? P.n_ticks : 0));
     if (tick_mode) {
         static const int min_tiles = tune_env("RC_TICK_MIN_TILES", 129);          // fewer: a tile per CU at most, nothing to hand over
         static const int max_tiles = tune_env("RC_TICK_MAX_TILES", 1 << 30);      // (A/B: one launch only for the filling / draining ticks)
@@ -951,14 +952,24 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
                 std::vector<GemmProblem> v = collect(k, g, false);
                 all.insert(all.end(), v.begin(), v.end());
             }
-            bool ok = !all.empty() && (int)all.size() <= RC_TICK_MAXP;
+            // problems of another shape (few rows: init_net layers, a slot that only carries lagging rows) go out in front of the tick
+            // launch on the kernels they always ran on; everything in a tick is independent of everything else in it
+            std::vector<GemmProblem> rest;
             long long tiles = 0;
-            for (const GemmProblem& p : all) {
-                const bool relu4 = p.epi == RC_EPI_RELU && p.out_packed && p.out_bit == 0 && ((p.out_col0 | p.N) & 3) == 0;
-                ok = ok && p.mr == 4 && p.nc == 8 && (p.epi == RC_EPI_LSTM || relu4) && p.open_step == 0 && p.Kp % 128 == 0;
-                tiles += (long long)p.n_tiles * p.m_tiles;
+            {
+                std::vector<GemmProblem> keep;
+                for (const GemmProblem& p : all) {
+                    const bool relu4 = p.epi == RC_EPI_RELU && p.out_packed && p.out_bit == 0 && ((p.out_col0 | p.N) & 3) == 0;
+                    if (p.mr == 4 && p.nc == 8 && (p.epi == RC_EPI_LSTM || relu4) && p.open_step == 0 && p.Kp % 128 == 0) {
+                        keep.push_back(p);
+                        tiles += (long long)p.n_tiles * p.m_tiles;
+                    } else rest.push_back(p);
+                }
+                all.swap(keep);
             }
+            const bool ok = !all.empty() && (int)all.size() <= RC_TICK_MAXP && (int)rest.size() <= RC_MAX_PROB;
             if (!ok || tiles < min_tiles || tiles > max_tiles) continue;
+            tick_rest[(size_t)k] = std::move(rest);
             // longest tiles first (K' = 2560 rnn4, 2048 rnn6, 1024 the H = 512 nets, 128 / 256 linear1): the queues end on short tiles
             std::stable_sort(all.begin(), all.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.Kp > b.Kp; });
             TickTable& T = ctx->tick_tab_h[k];
@@ -1039,6 +1050,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         if (tick_ok[k]) {
             // ONE launch: linear1 (and nothing else of it) reads what the second stream wrote in tick k - 1
             if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            if (!tick_rest[(size_t)k].empty()) if (int rc = launch_problems(ctx, tick_rest[(size_t)k], nullptr, st, false)) return rc;
             const TickTable* tab = ctx->tick_tab_d + k;
             int* queue = ctx->tick_queue_d + (size_t)k * 128;
             if (ctx->timing) {

@@ -80,6 +80,9 @@ def test_bench_runs_with_the_drivers_arguments(extra):
     for k in ("high", "fp32_mfma", "mixed_long", "high_long", "occ1024"):
         assert "error" not in var[k] and var[k]["value"] > 0, (k, var[k])
     assert var["mixed_long"]["frames"] == 512 and var["high_long"]["frames"] == 512      # BASELINE configs[1]: 512 frames
+    tk = var["one_launch_per_tick"]                                   # built, bitwise equal, slower: reported beside the product, not as it
+    assert "error" not in tk and tk["kernel"] == "rc_gemm_tick_kernel" and tk["tick_launches"] > tk["other_wide_launches"]
+    assert tk["value"] > 0 and 0 < tk["frac"] < 1
     lv = var["live_b1"]
     assert "error" not in lv and 0 < lv["p50_us"] <= lv["p99_us"]
     assert lv["lean_frames"] > 0.9 * lv["frames"] and lv["launches_per_lean_frame"] == 7 and lv["dispatch"]
