@@ -248,3 +248,51 @@ def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[6] == b[6]
     for n in a[3]:
         assert torch.equal(a[3][n][0], b[3][n][0]) and torch.equal(a[3][n][1], b[3][n][1]), n
+
+
+def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkeypatch):
+    """A live session with a pre-step behind every frame (RC_LIVE_PRESTEP_IDLE_US=0), interleaved with everything that moves the state
+    off the frame the pre-step read -- reset_states, an eager batch step, get_state (runs a pending updater step), an attribute poke (ends
+    and re-begins the live session), a partial reload of the weights -- against the same script with the pre-step off: bitwise."""
+    from robustcap_amd import synth
+    from robustcap_amd.net.sig_mp import Net
+    body, sd = synth_assets["body"], synth_assets["state_dict"]
+    m = synth.make_motion(31, 1, 260, body, conf="mixed")
+    script = {40: "reset", 77: "eager", 101: "state", 130: "poke", 171: "reload", 200: "reset", 201: "eager", 202: "state"}
+    outs = []
+    for env in ({"RC_LIVE_PRESTEP": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = Net(body=body, batch=1)
+        net.load_state_dict(sd)
+        net.gravityc = t(m["gravityc"])
+        net.use_graph = True
+        res = []
+        for i in range(260):
+            op = script.get(i)
+            if op == "reset":
+                net.reset_states()
+            elif op == "eager":                                          # a frame through rc_step on the caller's stream
+                net.use_graph = False
+                p, tr = net.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+                net.use_graph = True
+                res.append((p.clone(), tr.clone()))
+                continue
+            elif op == "state":
+                res.append(tuple(x.clone() for x in net.get_state("rnn6")))
+            elif op == "poke":
+                net.use_flat_floor = False                               # (ends the live session: the frame's arguments are baked in)
+            elif op == "reload":
+                net.load_state_dict({k: v for k, v in sd.items() if k.startswith("rnn3.")}, strict=False)
+            p, tr = net.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]), None, i == 0 or op == "reset")
+            res.append((p.clone(), tr.clone()))
+        n_pre, avail = net.live_prestep_stats()
+        outs.append((res, n_pre, avail, net.live_stats()))
+        del net
+    a, b = outs
+    assert a[1] == 0 and (not b[2] or b[1] > 150)
+    assert a[3] == b[3] and len(a[0]) == len(b[0])
+    for x, y in zip(a[0], b[0]):
+        assert all(torch.equal(u, v) for u, v in zip(x, y))
