@@ -2,7 +2,9 @@
 """Where the latency-bound kernels of the lean live frame spend their time: in-kernel wall-clock stamps (100 MHz) of block 0 /
 thread 0, from a -DRC_LIVE_TRACE build of the library (tools/probe_livetrace.so; RC_LIB_PATH selects it):
     hipcc ... -DRC_LIVE_TRACE -shared -o tools/probe_livetrace.so <csrc sources> -lhsa-runtime64
-    RC_LIB_PATH=tools/probe_livetrace.so python tools/live_trace.py [conf=high]"""
+    RC_LIB_PATH=tools/probe_livetrace.so python tools/live_trace.py [conf=high] [period_ms=0]
+period_ms > 0: the frames arrive every period_ms (16.667 = 60 fps: the device idles in between and rc_live_step runs the pre-step)."""
+import time
 import ctypes as C
 import os
 import sys
@@ -26,6 +28,7 @@ KNAME = {0: "K1 rc_live_k1 (prep + linear1)", 1: "K4 rc_live_k4 (sums + fuse + l
 
 def main():
     conf = sys.argv[1] if len(sys.argv) > 1 else "high"
+    period = float(sys.argv[2]) * 1e-3 if len(sys.argv) > 2 else 0.0
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     m = synth.make_motion(7, 1, 200, body, conf=conf)
     net = Net(body=body, batch=1)
@@ -36,6 +39,8 @@ def main():
     acc = np.zeros((4, 16))
     n = 0
     for i in range(200):
+        if period > 0:
+            time.sleep(period)
         net.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]), first_frame=(i == 0))
         if i < 60:
             continue
@@ -48,7 +53,8 @@ def main():
             nn = len(NAMES[k])
             acc[k, :nn] += (a[k, :nn] - a[k, 0]) * 0.01          # us from the kernel's first stamp
         n += 1
-    print(f"lean live frame, conf={conf}, {n} frames, us from each kernel's entry stamp (block 0, thread 0):")
+    print(f"lean live frame, conf={conf}, {n} frames{', one every %.2f ms' % (period * 1e3) if period > 0 else ' back to back'}, pre-steps {net.live_prestep_stats()[0]}, "
+          f"us from each kernel's entry stamp (block 0, thread 0):")
     for k in range(4):
         print(KNAME[k])
         prev = 0.0
