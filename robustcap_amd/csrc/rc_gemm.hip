@@ -100,14 +100,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define RC_SPLIT_W32 0        // 1: the weights stream as fp32 too (the fp32 packing, 4 B instead of 6 B per weight) and are split in the K
 #endif                        // loop like the activations: fewer operand bytes per MFMA for 36 more VALU per column block and k-block
 #define RC_WPL (RC_SPLIT_W32 ? 2 : 3)          // 1-KiB pieces per column block and k-block: two fp32 chunks, or three bf16 planes
-template <int MR, int NC>
+// W32 (round 5: a template parameter as well as the build macro): the launches whose weight slices have ONE reader -- every problem a single
+// 64-row tile per slice, i.e. contexts of 48-64 rows -- are pure weight streams, and 4 B per weight beat 6 B + no split (measured in round 4 with
+// the macro: batch 48 +13 %, 64 +7 %; at 256 rows, four readers per slice through the L2, -7 %). Bitwise the same products either way.
+template <int MR, int NC, bool W32 = (RC_SPLIT_W32 != 0)>
 struct FragS {                // one k-block (32 k): fp32 activations (two float4 per row block), three weight planes per column block
+    static constexpr int WPL = W32 ? 2 : 3;
     f32x4 a0[MR], a1[MR];
-    u32x4 b[NC][RC_WPL];
+    u32x4 b[NC][WPL];
 };
 
-template <int MR, int NC>
-__device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff, const u32x4* pb,
+template <int MR, int NC, bool W32>
+__device__ __forceinline__ void load_kblock(FragS<MR, NC, W32>& f, const float* const (&pa)[MR], long long aoff, const u32x4* pb,
                                             long long bstride) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ void load_kblock(FragS<MR, NC>& f, const float* const
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int p = 0; p < RC_WPL; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+        for (int p = 0; p < (W32 ? 2 : 3); ++p) f.b[j][p] = pb[j * bstride + p * 64];
 }
 
 // a = hi + mid + lo exactly; each output packs 8 bf16 (element e in the low / high half of dword e / 2).
@@ -141,15 +145,15 @@ __device__ __forceinline__ void split3(const f32x4& x0, const f32x4& x1, u32x4& 
     }
 }
 
-template <int MR, int NC>
-__device__ __forceinline__ void load_kblock_b(FragS<MR, NC>& f, const u32x4* pb, long long bstride) {
+template <int MR, int NC, bool W32>
+__device__ __forceinline__ void load_kblock_b(FragS<MR, NC, W32>& f, const u32x4* pb, long long bstride) {
 #pragma unroll
     for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int p = 0; p < RC_WPL; ++p) f.b[j][p] = pb[j * bstride + p * 64];
+        for (int p = 0; p < (W32 ? 2 : 3); ++p) f.b[j][p] = pb[j * bstride + p * 64];
 }
-template <int MR, int NC>
-__device__ __forceinline__ void load_kblock_a(FragS<MR, NC>& f, const float* const (&pa)[MR], long long aoff) {
+template <int MR, int NC, bool W32>
+__device__ __forceinline__ void load_kblock_a(FragS<MR, NC, W32>& f, const float* const (&pa)[MR], long long aoff) {
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         f.a0[r] = *reinterpret_cast<const f32x4*>(pa[r] + aoff);
@@ -157,16 +161,13 @@ __device__ __forceinline__ void load_kblock_a(FragS<MR, NC>& f, const float* con
     }
 }
 
-template <int MR, int NC>
-__device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[MR][NC]) {
+template <int MR, int NC, bool W32>
+__device__ __forceinline__ void mma_kblock(const FragS<MR, NC, W32>& f, f32x4 (&acc)[MR][NC]) {
     u32x4 wp[3][NC];              // the column blocks' planes: hi, mid, lo
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-#if RC_SPLIT_W32
-        split3(__builtin_bit_cast(f32x4, f.b[j][0]), __builtin_bit_cast(f32x4, f.b[j][1]), wp[0][j], wp[1][j], wp[2][j]);
-#else
-        wp[0][j] = f.b[j][0]; wp[1][j] = f.b[j][1]; wp[2][j] = f.b[j][2];
-#endif
+        if constexpr (W32) split3(__builtin_bit_cast(f32x4, f.b[j][0]), __builtin_bit_cast(f32x4, f.b[j][1]), wp[0][j], wp[1][j], wp[2][j]);
+        else { wp[0][j] = f.b[j][0]; wp[1][j] = f.b[j][1]; wp[2][j] = f.b[j][2]; }
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -200,7 +201,7 @@ __device__ __forceinline__ void mma_kblock(const FragS<MR, NC>& f, f32x4 (&acc)[
 // v_mfma_f32_16x16x4_f32 instead of 32x32x2: same rate, half the accumulator traffic, measured -14 % time.
 // PIPE pins a software pipeline (loads of chunk q+1 issued before the MFMAs of chunk q) with sched_barrier;
 // without it hipcc issues both chunks' loads at the top of an iteration and drains them inside it.
-template <int MR, int NC, int D, bool PIPE, bool SPLIT = false, bool DEEPOK = true, bool NTW = false>
+template <int MR, int NC, int D, bool PIPE, bool SPLIT = false, bool DEEPOK = true, bool NTW = false, bool W32 = (RC_SPLIT_W32 != 0)>
 __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, const int m_tile0, const int n_tile, float* s_mem) {
     constexpr int MT = 16 * MR, NT = 16 * NC, UT = 4 * NC, LD = NT + (MR >= 8 ? 4 : LDS_PAD);   // 128-row tiles: 140 KB with pad 4
 #ifdef RC_TRACE_TILES
@@ -268,15 +269,16 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
     // split products: the first k-blocks' weight planes depend on nothing the prologue computes -- requested here, behind the
     // step-counter reads (vmcnt completes in order) and in front of everything that waits for those, they travel while the
     // activation pointers are formed (a tile waits ~3 us for its first weights: profiles/r02_kloop_ablation.txt)
-    FragS<MR, NC> fa = {}, fb = {};
+    FragS<MR, NC, W32> fa = {}, fb = {};
     const int Qs = P.Kp / 32, Qws = Qs / RC_NW;                     // k-blocks per wave (K' % 128 == 0 -> >= 1)
-    constexpr int KBU = RC_WPL * 64;                                // uint4 per column block and k-block (planes, or fp32 chunks, x 64 lanes)
+    constexpr int WPL = W32 ? 2 : 3;
+    constexpr int KBU = WPL * 64;                                   // uint4 per column block and k-block (planes, or fp32 chunks, x 64 lanes)
     const long long bs = (long long)Qs * KBU;                       // uint4 between consecutive 16-column blocks
-    const u32x4* pbs = reinterpret_cast<const u32x4*>(RC_SPLIT_W32 ? (const void*)P.W : P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
-    constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 4 * RC_WPL) * 3 + (RC_SPLIT_W32 ? NC * 12 : 0) + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
+    const u32x4* pbs = reinterpret_cast<const u32x4*>(W32 ? (const void*)P.W : P.Ws) + ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
+    constexpr bool DEEP = SPLIT && DEEPOK && MR >= 2 && (MR * 8 + NC * 4 * WPL) * 3 + (W32 ? NC * 12 : 0) + MR * NC * 4 <= 380;   // 2x4, 4x4, 4x5 (16-row tiles: 128-VGPR budget)
     if constexpr (SPLIT) {
-        load_kblock_b<MR, NC>(fa, pbs, bs);
-        if constexpr (DEEP) load_kblock_b<MR, NC>(fb, pbs + (long long)min(1, Qws - 1) * KBU, bs);
+        load_kblock_b(fa, pbs, bs);
+        if constexpr (DEEP) load_kblock_b(fb, pbs + (long long)min(1, Qws - 1) * KBU, bs);
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
@@ -325,14 +327,14 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
 #define LOADS_A(F, QI)                                                                                              \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock_a<MR, NC>(F, pa0, (long long)k_ * 16);                                        \
-        else load_kblock_a<MR, NC>(F, pa1, (long long)(k_ - K0) * 16);                                              \
+        if (k_ < K0) load_kblock_a(F, pa0, (long long)k_ * 16);                                        \
+        else load_kblock_a(F, pa1, (long long)(k_ - K0) * 16);                                              \
     } while (0)
 #define LOADS(F, QI)                                                                                                \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock<MR, NC>(F, pa0, (long long)k_ * 16, pbs + (long long)(QI) * KBU, bs);              \
-        else load_kblock<MR, NC>(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)(QI) * KBU, bs);               \
+        if (k_ < K0) load_kblock(F, pa0, (long long)k_ * 16, pbs + (long long)(QI) * KBU, bs);              \
+        else load_kblock(F, pa1, (long long)(k_ - K0) * 16, pbs + (long long)(QI) * KBU, bs);               \
     } while (0)
         // With the MFMA time cut 2.7x the K loop is bound by what a wave keeps in flight (one k-block = 23 KiB for a 64 x 80
         // tile; 4 waves x 23 KiB / ~2 us of L2 / fabric latency = the 47 GB/s per CU the two-buffer loop was measured at):
@@ -340,9 +342,9 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
         int q = 0;
         // (Spreading the loads between the MFMAs -- sched_group_barrier patterns, or slices of the next block's loads in front of
         // every row block's MFMAs -- was measured at -2 % / +-1 %: profiles/r02_kloop_ablation.txt.)
-#define STEP(FL, QL, FM) do { LOADS(FL, QL); SB(); mma_kblock<MR, NC>(FM, acc); SB(); } while (0)
+#define STEP(FL, QL, FM) do { LOADS(FL, QL); SB(); mma_kblock(FM, acc); SB(); } while (0)
         if constexpr (DEEP) {
-            FragS<MR, NC> fc = {};
+            FragS<MR, NC, W32> fc = {};
             LOADS_A(fa, 0);
             LOADS_A(fb, min(1, Qws - 1));
             for (; q + 3 <= Qws; q += 3) {  // prefetch indices past the end are clamped: a redundant, valid load, no branch
@@ -350,15 +352,15 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
                 STEP(fa, min(q + 3, Qws - 1), fb);
                 STEP(fb, min(q + 4, Qws - 1), fc);
             }
-            if (q < Qws) mma_kblock<MR, NC>(fa, acc);
-            if (q + 1 < Qws) mma_kblock<MR, NC>(fb, acc);
+            if (q < Qws) mma_kblock(fa, acc);
+            if (q + 1 < Qws) mma_kblock(fb, acc);
         } else {
             LOADS_A(fa, 0);
             for (; q + 2 <= Qws; q += 2) {
                 STEP(fb, min(q + 1, Qws - 1), fa);
                 STEP(fa, min(q + 2, Qws - 1), fb);
             }
-            if (q < Qws) mma_kblock<MR, NC>(fa, acc);
+            if (q < Qws) mma_kblock(fa, acc);
         }
 #undef STEP
 #undef LOADS_A
@@ -572,6 +574,15 @@ __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_kernel(const GemmL
 __global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_split_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
     wide_tiles<true>(L, s_mem);
+}
+
+// Split-product launches of 64 x 128 tiles in which every weight slice has ONE reader (a single row tile per problem: contexts of 33-64
+// rows on the wavefront engine): the weights stream as fp32 and are split in the K loop (W32, above).
+__global__ __launch_bounds__(RC_NW * 64, RC_WPS) void rc_gemm_split48_w32_kernel(const GemmLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_mem[RC_LDS_FLOATS];
+    int pi, m_tile, n_tile;
+    if (!locate_tile(L, pi, m_tile, n_tile)) return;
+    gemm_tile<4, 8, 2, true, true, true, false, true>(L.p[pi], L.B, m_tile, n_tile, s_mem);
 }
 
 // Launches whose tiles are all at most 32 x 64 (the linear1 launches; LSTM stages of batches below 128) do not need the
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(RC_NW * 64, 1) void rc_gemm_tick_kernel(const TickT
         const int Qs = P->Kp / 32, Qws = Qs / RC_NW;
         const u32x4* pbs = reinterpret_cast<const u32x4*>(tick_global(RC_SPLIT_W32 ? (const void*)P->W : P->Ws)) +
                            ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
-        load_kblock_b<MR, NC>(fa, pbs, (long long)Qs * KBU);
+        load_kblock_b(fa, pbs, (long long)Qs * KBU);
     }
 
     while (cur >= 0) {
@@ -886,29 +897,29 @@ __global__ __launch_bounds__(RC_NW * 64, 1) void rc_gemm_tick_kernel(const TickT
 #define TLOADS_A(F, QI)                                                                                             \
     do {                                                                                                            \
         const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock_a<MR, NC>(F, pa0, (long long)k_ * 16);                                             \
-        else load_kblock_a<MR, NC>(F, pa1, (long long)(k_ - K0) * 16);                                              \
+        if (k_ < K0) load_kblock_a(F, pa0, (long long)k_ * 16);                                             \
+        else load_kblock_a(F, pa1, (long long)(k_ - K0) * 16);                                              \
     } while (0)
 #define TSB() __builtin_amdgcn_sched_barrier(0)
             int q = 0;
             TLOADS_A(fa, 0);
             for (; q + 2 <= Qws; q += 2) {
                 TLOADS_A(fb, q + 1);
-                load_kblock_b<MR, NC>(fb, pbs + (long long)(q + 1) * KBU, bs);
+                load_kblock_b(fb, pbs + (long long)(q + 1) * KBU, bs);
                 TSB();
-                mma_kblock<MR, NC>(fa, acc);
+                mma_kblock(fa, acc);
                 TSB();
                 const bool own = q + 2 < Qws || !RC_TICK_FOLD;
                 TLOADS_A(fa, min(q + 2, Qws - 1));
-                load_kblock_b<MR, NC>(fa, own ? pbs + (long long)min(q + 2, Qws - 1) * KBU : npbs, own ? bs : nbs);
+                load_kblock_b(fa, own ? pbs + (long long)min(q + 2, Qws - 1) * KBU : npbs, own ? bs : nbs);
                 TSB();
-                mma_kblock<MR, NC>(fb, acc);
+                mma_kblock(fb, acc);
                 TSB();
             }
             if (q < Qws) {                                          // one k-block per wave (rnn2's linear1, K = 128)
-                mma_kblock<MR, NC>(fa, acc);
+                mma_kblock(fa, acc);
                 TSB();
-                if (RC_TICK_FOLD) load_kblock_b<MR, NC>(fa, npbs, nbs);
+                if (RC_TICK_FOLD) load_kblock_b(fa, npbs, nbs);
             }
             next_requested = RC_TICK_FOLD != 0;
 #undef TSB
@@ -942,7 +953,7 @@ __global__ __launch_bounds__(RC_NW * 64, 1) void rc_gemm_tick_kernel(const TickT
         // reduction and the epilogue
         if (nhave) {
             tick_meta_request(meta, &tab->p[npi], B, tid);
-            if (!next_requested) load_kblock_b<MR, NC>(fa, npbs, nbs);
+            if (!next_requested) load_kblock_b(fa, npbs, nbs);
         }
         __syncthreads();
         // ---- publish the claimed item (this slot of the ring was last read two tiles ago; the atomic returned long ago: it is older than every load of the K loop)
@@ -1053,7 +1064,11 @@ void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t
         if (L.split) RC_GO(rc_gemm_mid_split_kernel);
         else RC_GO(rc_gemm_mid_kernel);
     } else {
-        if (L.split) RC_GO(rc_gemm_split_kernel);
+        bool one_reader = L.split != 0;
+        for (int q = 0; q < L.n; ++q) one_reader = one_reader && L.p[q].mr == 4 && L.p[q].nc == 8 && L.p[q].m_tiles == 1;
+        static const bool w32 = !std::getenv("RC_GEMM_W32") || std::atoi(std::getenv("RC_GEMM_W32")) != 0;
+        if (one_reader && w32) RC_GO(rc_gemm_split48_w32_kernel);
+        else if (L.split) RC_GO(rc_gemm_split_kernel);
         else RC_GO(rc_gemm_kernel);
     }
 #undef RC_GO
