@@ -47,9 +47,9 @@ PRODUCTS_SPLIT = ("fp32 operands split exactly into 3 bf16 terms each; every pro
                   "v_mfma_f32_16x16x32_bf16 (all terms >= 2^-16 of the product), fp32 accumulation, fp32 gates / state")
 PRODUCTS_FP32 = "v_mfma_f32_16x16x4_f32 (fp32 operands, an fma chain per output element)"
 PACED_FRAMES = 1000                    # live_b1.paced_60fps: frames at 60 fps (16.7 s of the default run)
-CPU_FRAMES_BATCHED = 8                 # cpu_baseline: 3 samples of B x 8 frames batched (median) + 48 frames batch-1 (~10-30 s)
-CPU_FRAMES_SINGLE = 48
-CPU_SAMPLES = 3
+CPU_FRAMES_BATCHED = 8                 # cpu_baseline: 5 samples of B x 8 frames batched (median; round-4 review: three samples spread by
+CPU_FRAMES_SINGLE = 48                 # 20 %) + 48 frames batch-1 (~20-30 s of CPU work)
+CPU_SAMPLES = 5
 
 
 def pmc_traffic(batch, conf, steps):

@@ -18,7 +18,7 @@ def test_cpu_baseline_on_short_inputs(synth_assets):
     out = bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], m)
     assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert "x 4 frames" in out["sample"] and "(4 frames" in out["sample"]          # clamped to T - 1
-    assert out["samples"] == 3 and out["min"] <= out["value"] <= out["max"]        # median of three samples
+    assert out["samples"] == 5 and out["min"] <= out["value"] <= out["max"]        # median of five samples
     with pytest.raises(ValueError):
         bench.cpu_baseline(synth_assets["state_dict"], synth_assets["body"], {k: v[:, :1] if v.ndim > 2 else v for k, v in m.items()})
 
