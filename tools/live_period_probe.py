@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""How the paced live latency depends on the idle time in front of a frame (config 5): p50 / p99 of rc_live_step at several arrival
+periods, with the idle-time pre-step and without it.  python tools/live_period_probe.py [frames=500]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from robustcap_amd import synth  # noqa: E402
+import live_latency as L  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    sd, body = synth.make_state_dict(0), synth.make_body(1)
+    m = synth.make_motion(7, 1, 600, body, conf="mixed")
+    rows = []
+    for period_ms in (16.667, 4.0, 1.0, 0.3, 0.0):
+        for name, env in (("prestep", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("plain", {"RC_LIVE_PRESTEP": "0"})):
+            net = L.make(sd, body, m, env=env)
+            st = L.stats(L.run_c(net, m, n, period_ms * 1e-3))
+            rows.append({"period_ms": period_ms, "mode": name, **st, "pre": list(net.live_prestep_stats()) if hasattr(net, "live_prestep_stats") else None})
+            del net
+    print(json.dumps(rows, indent=1))
+
+
+if __name__ == "__main__":
+    main()
