@@ -128,6 +128,7 @@ struct rc_ctx {
     // the idle-time pre-step (rc_live.hip: rc_live_pre): the recurrent halves of the next frame's layer steps, computed behind a frame
     // when the caller leaves the device idle between frames (a 60 fps stream: 16.6 ms)
     int live_prestep = 1;                                   // RC_LIVE_PRESTEP: 0 = never
+    bool live_arm = true;                                   // RC_LIVE_ARM=0 switches it off: a paced caller leaves a barrier packet waiting at the head of the queue
     double live_prestep_idle_us = 500.0;                    // RC_LIVE_PRESTEP_IDLE_US: idle time in front of a frame from which the next pre-step is enqueued
     float* live_pre_buf = nullptr;                          // [tiles of the twelve layer steps][2 waves][64 lanes][4]
     int aql_prog_lean = -1, aql_prog_lean_pre = -1, aql_prog_pre = -1;     // programs of the AQL chain
@@ -1242,6 +1243,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_aql_on = tune_env("RC_LIVE_AQL", 1);
     ctx->live_prestep = tune_env("RC_LIVE_PRESTEP", 1);
     ctx->live_prestep_idle_us = (double)tune_env("RC_LIVE_PRESTEP_IDLE_US", 500);
+    ctx->live_arm = tune_env("RC_LIVE_ARM", 1) != 0;
     ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
     ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
@@ -1927,6 +1929,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (ctx->live_aql && ctx->aql_prog_pre >= 0 && idle_us >= ctx->live_prestep_idle_us) {
         if (rc_aql_submit(ctx->live_aql, ctx->aql_prog_pre) == 0) { ctx->live_pre_valid = true; ctx->stat_live_pre += 1; }
     }
+    if (ctx->live_aql && ctx->live_arm && idle_us >= ctx->live_prestep_idle_us) (void)rc_aql_arm(ctx->live_aql);
     if (lean) {
         const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::micro>(b - a).count();

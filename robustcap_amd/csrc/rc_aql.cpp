@@ -39,6 +39,9 @@ struct AqlChain {
     unsigned* seq_d = nullptr;                   // device counter of frames
     unsigned long long seq = 0;                  // frames submitted (64 bits: the completion signal counts down once per frame for the life of
                                                  // the chain; the flag word K7 stores is its low 32 bits)
+    // RC_LIVE_ARM: a barrier-AND packet left at the head of the ring while the caller is away, waiting on arm[armed]; the next push releases it
+    hsa_signal_t arm[2]{};
+    int arm_next = 0, armed = -1;
     bool dead = false;                           // a frame did not complete in time: the chain takes no further frame (rc_live_step falls back)
     long long sig0 = 0;                          // value of `done` / `bg_done` before any program: every retired one decrements it
     std::vector<AqlProgram> prog;
@@ -126,6 +129,8 @@ int rc_aql_create(int hip_device, AqlChain** out, char* err, int err_len) {
     c->sig0 = 1ll << 62;                                                     // counts down once per frame: ~10^14 years of frames
     if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
     if ((st = hsa_signal_create(c->sig0, 0, nullptr, &c->bg_done)) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
+    for (int a = 0; a < 2; ++a)
+        if ((st = hsa_signal_create(0, 0, nullptr, &c->arm[a])) != HSA_STATUS_SUCCESS) return bail(c, err, err_len, "hsa_signal_create", st);
     *out = c;
     return 0;
 }
@@ -228,6 +233,10 @@ int rc_aql_add(AqlChain* c, const LiveKernel* k, int n, int frame, char* err, in
     return (int)c->prog.size() - 1;
 }
 
+static void aql_release(AqlChain* c) {
+    if (c->armed >= 0) { hsa_signal_store_screlease(c->arm[c->armed], 0); c->armed = -1; }
+}
+
 // body first, header (which hands the packet to the packet processor) last; the barrier bit of every packet orders it behind everything
 // in front of it in the ring -- a frame behind the pre-step that ran in the idle time, the pre-step behind the frame whose state it reads
 static void aql_push(AqlChain* c, const AqlProgram& P) {
@@ -241,6 +250,31 @@ static void aql_push(AqlChain* c, const AqlProgram& P) {
     }
     hsa_queue_store_write_index_release(q, base + P.n);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + P.n - 1));
+    aql_release(c);
+}
+
+// Leave the packet processor waiting AT this queue while the caller is away (a paced caller: 16 ms between two frames): a barrier-AND
+// packet on a signal the next push sets to zero once its packets are in the ring. Two signals in turn: the barrier that waited on the
+// other one has retired by the time it is armed again (a frame has completed in between).
+int rc_aql_arm(AqlChain* c) {
+    if (!c || !c->q || c->dead || c->armed >= 0) return 0;
+    const int a = c->arm_next;
+    c->arm_next ^= 1;
+    hsa_signal_store_screlease(c->arm[a], 1);
+    hsa_queue_t* q = c->q;
+    const uint32_t mask = q->size - 1;
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);
+    hsa_barrier_and_packet_t* p = (hsa_barrier_and_packet_t*)q->base_address + (base & mask);
+    hsa_barrier_and_packet_t b;
+    std::memset(&b, 0, sizeof(b));
+    b.dep_signal[0] = c->arm[a];
+    std::memcpy((char*)p + 4, (const char*)&b + 4, sizeof(b) - 4);
+    const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+    __atomic_store_n((uint32_t*)p, (uint32_t)hdr, __ATOMIC_RELEASE);
+    hsa_queue_store_write_index_release(q, base + 1);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)base);
+    c->armed = a;
+    return 0;
 }
 
 int rc_aql_submit(AqlChain* c, int prog) {
@@ -286,6 +320,7 @@ int rc_aql_run(AqlChain* c, int prog) {
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
     if (!c || !c->q) return;
+    aql_release(c);
     if (c->seq) (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
     (void)rc_aql_wait_background(c);
 }
@@ -298,6 +333,7 @@ void rc_aql_destroy(AqlChain* c) {
     if (c->q) (void)hsa_queue_destroy(c->q);
     if (c->done.handle) (void)hsa_signal_destroy(c->done);
     if (c->bg_done.handle) (void)hsa_signal_destroy(c->bg_done);
+    for (int a = 0; a < 2; ++a) if (c->arm[a].handle) (void)hsa_signal_destroy(c->arm[a]);
     for (AqlProgram& P : c->prog) if (P.kargs) (void)hipFree(P.kargs);
     if (c->hsa_up) (void)hsa_shut_down();
     delete c;

@@ -249,6 +249,7 @@ int rc_aql_create(int hip_device, AqlChain** out, char* err, int err_len);
 int rc_aql_add(AqlChain* c, const LiveKernel* k, int n, int frame, char* err, int err_len);
 int rc_aql_run(AqlChain* c, int prog);                                // frame program: submit, then spin until it retired; 0 = done
 int rc_aql_submit(AqlChain* c, int prog);                             // background program: submit and return
+int rc_aql_arm(AqlChain* c);                         // RC_LIVE_ARM: a barrier-AND packet the next push releases
 int rc_aql_wait_background(AqlChain* c);                              // until every submitted background program has retired
 void rc_aql_destroy(AqlChain* c);
 
