@@ -212,8 +212,9 @@ def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch)
     s = np.load(path)
     live = str(s["live"])
     outs = []
-    for env in ({"RC_LIVE_PRESTEP": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US"):
+    # (the second leg also leaves the queue armed behind every frame -- rc_aql_arm, a barrier packet the next push releases; the first never)
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -260,8 +261,9 @@ def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkey
     m = synth.make_motion(31, 1, 260, body, conf="mixed")
     script = {40: "reset", 77: "eager", 101: "state", 130: "poke", 171: "reload", 200: "reset", 201: "eager", 202: "state"}
     outs = []
-    for env in ({"RC_LIVE_PRESTEP": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US"):
+    # third leg: the armed queue alone (a barrier packet behind every frame, no pre-step), through the same script
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}, {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -291,8 +293,9 @@ def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkey
         n_pre, avail = net.live_prestep_stats()
         outs.append((res, n_pre, avail, net.live_stats()))
         del net
-    a, b = outs
-    assert a[1] == 0 and (not b[2] or b[1] > 150)
-    assert a[3] == b[3] and len(a[0]) == len(b[0])
-    for x, y in zip(a[0], b[0]):
-        assert all(torch.equal(u, v) for u, v in zip(x, y))
+    a, b, c = outs
+    assert a[1] == 0 and c[1] == 0 and (not b[2] or b[1] > 150)
+    for o in (b, c):
+        assert a[3] == o[3] and len(a[0]) == len(o[0])
+        for x, y in zip(a[0], o[0]):
+            assert all(torch.equal(u, v) for u, v in zip(x, y))
