@@ -16,10 +16,14 @@ def main():
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     m = synth.make_motion(7, 1, 600, body, conf="mixed")
     rows = []
-    for period_ms in (16.667, 1.0, 0.3, 0.0):
-        for name, env in (("prestep", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("plain", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100"}),
-                          ("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "1"}),
-                          ("plain+arm", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "1"})):
+    modes = (("prestep", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "0"}), ("plain", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "0"}),
+             ("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "1"}),
+             ("plain+arm", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "1"}))
+    if os.environ.get("RC_PROBE_EXTRA"):                                # side questions on the default configuration, paced
+        modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("edge fences at agent scope", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_AQL_EDGE_SCOPE": "agent"}),
+                 ("completion by the signal", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_DONE_FLAG": "0"}), ("prestep+arm again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
+    for period_ms in ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0)):
+        for name, env in modes:
             net = L.make(sd, body, m, env=env)
             st = L.stats(L.run_c(net, m, n, period_ms * 1e-3))
             rows.append({"period_ms": period_ms, "mode": name, **st, "pre": list(net.live_prestep_stats()) if hasattr(net, "live_prestep_stats") else None})
