@@ -14,7 +14,7 @@ import live_latency as L  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     sd, body = synth.make_state_dict(0), synth.make_body(1)
-    m = synth.make_motion(7, 1, 600, body, conf="mixed")
+    m = synth.make_motion(7, 1, 600, body, conf=os.environ.get("RC_PROBE_CONF", "mixed"))
     rows = []
     modes = (("prestep", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "0"}), ("plain", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "0"}),
              ("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_ARM": "1"}),
@@ -22,6 +22,10 @@ def main():
     if os.environ.get("RC_PROBE_EXTRA"):                                # side questions on the default configuration, paced
         modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("edge fences at agent scope", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_AQL_EDGE_SCOPE": "agent"}),
                  ("completion by the signal", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_DONE_FLAG": "0"}), ("prestep+arm again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
+    if os.environ.get("RC_PROBE_EXTRA") == "2":                         # timing probe (needs profiles/r05_live_prequeue_experiment.diff applied): the next frame's packets already behind the armed barrier (RC_PROBE_CONF=high)
+        modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("prestep+arm+frame queued ahead", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}),
+                 ("plain+arm", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100"}),
+                 ("plain+arm+frame queued ahead", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}))
     for period_ms in ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0)):
         for name, env in modes:
             net = L.make(sd, body, m, env=env)
