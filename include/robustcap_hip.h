@@ -188,6 +188,10 @@ int rc_get_live_stats(rc_ctx* ctx, int64_t* lean_frames, int64_t* full_frames);
  * layer steps. Any eager call in between (reset, rc_step, ...) discards them. presteps: enqueued since rc_create; available: the AQL chain
  * carries the pre-step programs (either may be NULL). */
 int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available);
+/* Lean live frames that turned out not to be the lean plan's -- a row needed a transition step or triggered init_net (net/sig_mp.py:178-183,
+ * L264-271) and the conservative host-side mirror of those flags in rc_live_step did not foresee it. The plan's first kernel checks both on the
+ * device; such a frame changes nothing and rc_live_step replays it on the full capture, so the caller only sees a slower frame. Expected: 0. */
+int rc_get_live_replayed(rc_ctx* ctx, int64_t* frames);
 /* Host time of rc_live_step averaged over the lean frames so far, microseconds: {staging the inputs + choosing the capture, enqueue
  * (hipGraphLaunch), waiting for the frame, copying the outputs}. The frame's GPU time is inside the third. */
 int rc_get_live_profile(rc_ctx* ctx, double* avg_us4);

@@ -139,6 +139,9 @@ struct rc_ctx {
     int* live_status_h = nullptr;                           // pinned + mapped: set by a lean frame that met an init_net trigger
     std::vector<unsigned char> live_may_reach;              // host-side, conservative: the row may still trigger init_net (L178-183)
     long long stat_live_lean = 0, stat_live_full = 0;
+    long long stat_live_replayed = 0;                       // lean frames whose own check (K1) found them off the lean plan: replayed on the full capture
+    int* live_abort_d = nullptr;                            // LiveFrame.abort
+    bool live_blind = false;                                // RC_LIVE_MIRROR_BLIND=1 (tests): no host-side mirror of the transition / init_net flags
     double live_prof_us[4] = {0.0, 0.0, 0.0, 0.0};          // host time of rc_live_step: staging + choice | enqueue | wait | copy out (sums, lean frames)
     long long live_prof_n = 0;
     // timing of the gate GEMM launches
@@ -1244,6 +1247,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_prestep = tune_env("RC_LIVE_PRESTEP", 1);
     ctx->live_prestep_idle_us = (double)tune_env("RC_LIVE_PRESTEP_IDLE_US", 500);
     ctx->live_arm = tune_env("RC_LIVE_ARM", 1) != 0;
+    ctx->live_blind = tune_env("RC_LIVE_MIRROR_BLIND", 0) != 0;
     ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
     ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
@@ -1684,6 +1688,7 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
     if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
     if (ctx->live_status_h) { (void)hipHostFree(ctx->live_status_h); ctx->live_status_h = nullptr; }
+    if (ctx->live_abort_d) { (void)hipFree(ctx->live_abort_d); ctx->live_abort_d = nullptr; }
     if (ctx->live_graph_notr) { (void)hipGraphDestroy(ctx->live_graph_notr); ctx->live_graph_notr = nullptr; }
     if (ctx->live_stream) { (void)hipStreamDestroy(ctx->live_stream); ctx->live_stream = nullptr; }
     if (ctx->live_in_h) { (void)hipHostFree(ctx->live_in_h); ctx->live_in_h = nullptr; }
@@ -1746,6 +1751,7 @@ int rc_live_begin(rc_ctx* ctx) {
         auto lean_setup = [&]() -> std::string {
             if (hipHostMalloc((void**)&ctx->live_status_h, sizeof(int), hipHostMallocMapped) != hipSuccess) return "lean frame: status word allocation failed";
             *ctx->live_status_h = 0;
+            if (hipMalloc((void**)&ctx->live_abort_d, 64) != hipSuccess || hipMemset(ctx->live_abort_d, 0, 64) != hipSuccess) return "lean frame: abort word allocation failed";
             LiveFrame& F = ctx->live_frame;
             F = LiveFrame{};
             for (int i = 0; i < 6; ++i) {
@@ -1760,6 +1766,7 @@ int rc_live_begin(rc_ctx* ctx) {
             }
             F.fb = ctx->fb; F.io = io; F.prm = dev_params(ctx->prm); F.body = ctx->body; F.B = (int)B; F.nc = ctx->live_lean_nc;
             if (hipHostGetDevicePointer((void**)&F.status, ctx->live_status_h, 0) != hipSuccess) return "lean frame: status word not mapped";
+            F.abort = ctx->live_abort_d;
             std::vector<LiveKernel> plan(RC_LIVE_KERNELS);
             const int nk = rc_live_plan(F, plan.data());
             if (nk != RC_LIVE_KERNELS) return "lean frame: sub-net sizes these kernels are not compiled for";
@@ -1859,6 +1866,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         }
         ctx->live_prev_known = true;
     }
+    if (ctx->live_blind) { need_tr = false; maybe_reach = false; }       // tests: every frame is offered to the lean plan, whose own check decides
     const bool lean = ctx->live_exec_lean && !need_tr && !maybe_reach && !first_tran && !(flags & RC_FLAG_FIRST_FRAME);
     const auto t_staged = std::chrono::steady_clock::now();
     bool aql_done = false;
@@ -1917,8 +1925,15 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     }
     if (!lean) ctx->stat_live_full += 1;
     if (lean && *ctx->live_status_h != 0) {
+        // The lean plan's own check (rc_live_k1) found the frame off the plan -- a transition step or an init_net trigger the host-side
+        // mirror above did not foresee. Its kernels have changed nothing (LiveFrame.abort): the frame runs again on the full capture,
+        // from the inputs still staged in the pinned buffer.
         *ctx->live_status_h = 0;
-        return fail(ctx, RC_ERR_STATE, "rc_live_step: a lean frame met an init_net trigger (host mirror of first_reach out of date)");
+        ctx->stat_live_lean -= 1;
+        ctx->stat_live_full += 1;
+        ctx->stat_live_replayed += 1;
+        HIP_TRY(ctx, hipGraphLaunch(ctx->live_exec, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     const auto t_done = std::chrono::steady_clock::now();
     std::memcpy(pose, ctx->live_out_h, B * 216 * sizeof(float));
@@ -1955,6 +1970,12 @@ int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available) {
     if (!ctx) return RC_ERR_INVALID;
     if (presteps) *presteps = ctx->stat_live_pre;
     if (available) *available = (ctx->live_aql && ctx->aql_prog_pre >= 0) ? 1 : 0;
+    return RC_OK;
+}
+
+int rc_get_live_replayed(rc_ctx* ctx, int64_t* frames) {
+    if (!ctx || !frames) return RC_ERR_INVALID;
+    *frames = ctx->stat_live_replayed;
     return RC_OK;
 }
 

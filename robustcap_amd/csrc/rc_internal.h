@@ -215,7 +215,9 @@ struct LiveFrame {
     FrameIO io;
     rc_params_dev prm;
     const BodyConst* body;
-    int* status;                    // device word, set != 0 when a frame the lean plan does not cover reached it (init_net trigger)
+    int* status;                    // pinned host word, set != 0 by K1 when the frame is not the lean plan's (a transition step or an init_net trigger:
+                                    // the host's mirror of those flags is conservative, this is the check behind it); rc_live_step then replays the full capture
+    int* abort;                     // device word K1 writes every frame (0 / 1): set, the frame's kernels change NOTHING (no state, no step counters, no outputs)
     LiveGrid* hot[4];               // AQL path: the LiveGrid argument blocks of K2, K3 (written by K1) and K5, K6 (by K4); else null
     unsigned* done_flag;            // AQL path, one row: pinned host word K7 stores the frame's sequence number to, behind a system-scope
     unsigned* done_seq;             // release, when everything of the frame is written (device counter of frames); else null

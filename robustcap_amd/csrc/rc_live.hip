@@ -171,15 +171,23 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
     RC_LT(0, 0);
     Lin1W w;
     lin1_request(w, n, Kp1, n_tile, tid);
+    // Is this frame the lean plan's at all? A row that carries a deferred updater step INTO a frame it steps on camera data needs the
+    // transition launches, a row that reaches the high regime for the first time triggers init_net (L178-183): rc_live_step keeps such frames
+    // away with a conservative host-side mirror of the two flags; here is the check itself. Every workgroup computes it (it has the prep of
+    // every row anyway), and when it fires the frame's kernels change nothing -- no state, no step counter, no output -- so that the host
+    // can simply replay the frame on the full capture (LiveFrame.abort / status).
+    __shared__ int s_off[RC_LIVE_MAXB];
+    PrepIn in;
+    PrepVals pv;
+    int st_old = 0;
     if (wave < B) {
         const int row = wave;
-        PrepIn in;
         prep_load(in, F.io, row, lane);
-        const int pend = F.fb.pend[row], uvc = F.fb.uv_count[row];
-        const int st_old = (n_tile == 0 && lane == 0) ? n.steps[row] : 0;
+        const int pend = F.fb.pend[row], uvc = F.fb.uv_count[row], reach = F.fb.first_reach[row];
+        st_old = (n_tile == 0 && lane == 0) ? n.steps[row] : 0;
         // the deferred updater's input row (rows that are not on camera but carry a pending step read it, L264-271)
         const f32x4 xl = is4 ? *reinterpret_cast<const f32x4*>(F.fb.x4l + rc_pk(row, 4 * lane, LD_X4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const PrepVals pv = prep_values(in, F.prm, lane, 0, pend, uvc);
+        pv = prep_values(in, F.prm, lane, 0, pend, uvc);
         RC_LT(0, 1);
         float* x = s_x[row];
         if (is4) {
@@ -196,9 +204,17 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
             if (lane < 54) x[18 + lane] = pv.orir;
             if (lane < 56) x[72 + lane] = 0.0f;
         }
-        if (blockIdx.x == 0) prep_store(F.fb, in, pv, row, lane);
+        if (lane == 0) s_off[row] = ((pv.f2 & RC_ROW2_TR) || (pv.regime == 2 && F.prm.use_imu_updater && reach)) ? 1 : 0;
+    }
+    __syncthreads();
+    bool off_plan = false;
+#pragma unroll
+    for (int r = 0; r < RC_LIVE_MAXB; ++r) off_plan = off_plan || (r < B && s_off[r] != 0);
+    if (wave < B) {
+        const int row = wave;
+        if (blockIdx.x == 0 && !off_plan) prep_store(F.fb, in, pv, row, lane);
         if (n_tile == 0 && lane == 0) {                                     // the step this frame takes (rc_gemm.hip: open_step)
-            const bool on = !is4 || (pv.f2 & RC_ROW2_M4);
+            const bool on = !off_plan && (!is4 || (pv.f2 & RC_ROW2_M4));
             const int stn = st_old + (on ? 1 : 0);
             if (on) n.steps[row] = stn;
             const int p = is4 ? 0 : 1;                                      // problem order of the first stage's LSTM launches: rnn4, rnn2
@@ -206,6 +222,10 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
             for (int q = 0; q < 2; ++q)
                 if (F.hot[q]) { F.hot[q]->st[p][row] = stn; F.hot[q]->act[p][row] = on ? 1 : 0; }
         }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        *F.abort = off_plan ? 1 : 0;
+        if (off_plan) *F.status = 1;
     }
     __syncthreads();
     RC_LT(0, 2);
@@ -246,6 +266,7 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             rcr[r][q] = (r < B && (ni == LN7 || ni == LN8) && tid >= 72 && tid < 141) ? F.fb.x6[rc_pk(r, 18 + 45 + 3 * q + (tid - 72) % 3, LD_X6)] : 0.f;
+    const int off_plan = *F.abort;                                         // (K1: this frame is not the lean plan's -- change nothing)
     const float* xsrc = ni == LN6 ? F.fb.x6 : (ni == LN3 ? F.fb.x3 : F.fb.x78);
 #pragma unroll
     for (int r = 0; r < RC_LIVE_MAXB; ++r) {
@@ -299,15 +320,14 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
         }
         s_x[r][tid] = v;
         if (n_tile == 0 && tid == 0) {                                      // the step this frame takes (rc_gemm.hip: open_step)
-            const bool on = ni != LN6 || (F.fb.flags2[r] & RC_ROW2_M6);
+            const bool on = !off_plan && (ni != LN6 || (F.fb.flags2[r] & RC_ROW2_M6));
             const int stn = st_old[r] + (on ? 1 : 0);
             if (on) n.steps[r] = stn;
             const int p = ni == LN6 ? 0 : (ni == LN3 ? 1 : (ni == LN7 ? 2 : 3));   // problem order of the second stage's LSTM launches
 #pragma unroll
             for (int q = 2; q < 4; ++q)
                 if (F.hot[q]) { F.hot[q]->st[p][r] = stn; F.hot[q]->act[p][r] = on ? 1 : 0; }
-            // L178-180: a frame that would trigger init_net is not this plan's (rc_api.cpp keeps it away; checked by rc_live_step)
-            if (ni == LN6 && regime == 2 && F.prm.use_imu_updater && F.fb.first_reach[r]) *F.status = 1;
+            // (L178-180: a frame that would trigger init_net is not this plan's -- K1 has checked, LiveFrame.abort)
         }
     }
     __syncthreads();
@@ -354,7 +374,8 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     const int hs0 = G.st[pi][0], hs1 = G.st[pi][1], hs2 = G.st[pi][2], hs3 = G.st[pi][3];
     const int ha0 = G.act[pi][0], ha1 = G.act[pi][1], ha2 = G.act[pi][2], ha3 = G.act[pi][3];
     const unsigned char* const flags2 = F.fb.flags2;
-    asm volatile("; kernel arguments in" ::"s"(B), "s"(Wl), "s"(bl), "s"(cbase), "s"(hbase), "s"(x1), "s"(W2), "s"(part), "s"(steps), "s"(BpH),
+    const int* const abortp = F.abort;
+    asm volatile("; kernel arguments in" ::"s"(abortp), "s"(B), "s"(Wl), "s"(bl), "s"(cbase), "s"(hbase), "s"(x1), "s"(W2), "s"(part), "s"(steps), "s"(BpH),
                  "s"(out), "s"(outp), "s"(hot), "s"(hs0), "s"(hs1), "s"(hs2), "s"(hs3), "s"(ha0), "s"(ha1), "s"(ha2), "s"(ha3), "s"(flags2),
                  "s"(g_pre), "s"(g_pre_base), "s"(g_prebuf));
     const bool from_pre = g_pre != 0 && wave >= 2;
@@ -388,9 +409,10 @@ __device__ __forceinline__ void live_lstm_body(const LiveFrame& F, const LiveGri
     } else {
         st_a = steps[ri];
         st_e = e_on ? steps[er] : 0;
+        const int off_plan = *abortp;                                      // (with the hot words K1 / K4 have cleared `act` instead)
 #pragma unroll
         for (int r = 0; r < RC_LIVE_MAXB; ++r)
-            if (r < B && (mask == 0 || (flags2[r] & mask))) amask |= 1u << r;
+            if (r < B && !off_plan && (mask == 0 || (flags2[r] & mask))) amask |= 1u << r;
     }
     float* cst = cbase + (long long)LAYER * B * H;
     const float c_prev = e_on ? cst[(long long)er * H + n_tile * UT + eu] : 0.f;
@@ -500,6 +522,7 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) 
     s3.request(n3.part, nt3, row, tid - 64);
     s8.request(n8.part, nt8, row, tid - 128);
     const float bias_t = tid < n7.out ? n7.b2[tid] : 0.f;                 // bias of the output this thread finishes
+    const int off_plan = *F.abort;                                        // (K1: not the lean plan's frame -- no state, no outputs; the host replays it)
     // the narrow sums: wave 0 -> rnn6 (pc), wave 1 -> rnn3 (vr), wave 2 -> rnn8 (contact); lane e < out adds the bias and writes
     const int wv = tid >> 6;
     const float* nb = wv == 0 ? n6.b2 : (wv == 1 ? n3.b2 : n8.b2);
@@ -521,7 +544,7 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k7(const LiveFrame F) 
     __syncthreads();
     RC_LT(2, 2);
     if (tid >= 64) return;
-    tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub, &tr);
+    if (!off_plan) tail_impl<1, true>(F.fb, F.io, F.prm, F.body, F.B, 0, F.io, 0, WaveTail{}, s_all, s_body, &sub, &tr);
     // AQL path, one row: tell the host the frame is complete from HERE -- every write of the frame is behind this point; the host then does
     // not wait for the packet processor to retire the dispatch, run its release fence and write the completion signal (rc_aql.cpp).
     if (F.done_flag) {

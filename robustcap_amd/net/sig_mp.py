@@ -274,6 +274,13 @@ class Net:
         _lib.check(self._ctx, self._lib.rc_get_live_prestep(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_prestep")
         return a.value, bool(b.value)
 
+    def live_replayed(self):
+        """Lean live frames whose own device-side check found them off the lean plan (a transition step or an init_net trigger the host-side
+        mirror in rc_live_step did not foresee): they change nothing and are replayed on the full capture. Expected: 0."""
+        a = C.c_int64(0)
+        _lib.check(self._ctx, self._lib.rc_get_live_replayed(self._ctx, C.byref(a)), "rc_get_live_replayed")
+        return a.value
+
     @torch.no_grad()
     def forward_sequence(self, j2dc, accc, oric, first_tran=None, first_frame=False):
         """The evaluate.py frame loop (evaluate.py:75-83) for B sequences of T frames in one call.

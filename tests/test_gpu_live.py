@@ -176,6 +176,64 @@ def test_lean_frame_batch_4_rows_in_different_regimes(synth_assets):
         assert torch.equal(pc[0], pd[2]) and torch.equal(tc[0], td[2]), i
 
 
+@pytest.mark.parametrize("aql", ["1", "0"], ids=["aql", "graph_replay"])
+def test_offplan_frames_are_caught_on_the_device_and_replayed(synth_assets, monkeypatch, aql):
+    """The lean plan checks ITSELF that a frame is its own (rc_live_k1: no row needs a transition step, no row triggers init_net); the
+    host-side mirror of those flags in rc_live_step only keeps such frames away beforehand. With the mirror blinded
+    (RC_LIVE_MIRROR_BLIND=1) every steady frame is offered to the lean plan: the frames it rejects must change nothing and come back from
+    the full capture -- same branch traces as rc_step, outputs and states to rounding, thresholds hugged (conf_lo, conf_hi +- 1e-5) -- on
+    the AQL chain and on the graph replay, one row and four rows in different regimes. Without the blindfold nothing is ever replayed."""
+    from robustcap_amd import synth
+    monkeypatch.setenv("RC_LIVE_AQL", aql)
+    T = 120
+    m = _mixed_motion(synth_assets, 97, T)
+    for blind in ("1", "0"):
+        monkeypatch.setenv("RC_LIVE_MIRROR_BLIND", blind)
+        a, b = make_net(synth_assets, 1), make_net(synth_assets, 1)
+        a.gravityc = b.gravityc = t(m["gravityc"])
+        b.use_graph = True
+        worst = 0.0
+        for i in range(T):
+            args = (t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]))
+            pa, ta = a.forward_online(*args, first_frame=(i == 0))
+            pb, tb = b.forward_online(*args, first_frame=(i == 0))
+            assert a.get_trace()[0].tolist() == b.get_trace()[0].tolist(), (blind, i)
+            worst = max(worst, maxdiff(pa, pb), maxdiff(ta, tb))
+        assert worst <= 1e-5, (blind, worst)
+        for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8"):
+            (ha, ca), (hb, cb) = a.get_state(n), b.get_state(n)
+            assert maxdiff(ha, hb) <= 1e-5 and maxdiff(ca, cb) <= 1e-5, (blind, n)
+        lean, full = b.live_stats()
+        assert lean + full == T
+        if blind == "1":
+            assert b.live_replayed() >= 2 and full >= 3, (b.live_replayed(), lean, full)   # the init_net frame and the transitions
+        else:
+            assert b.live_replayed() == 0
+        del a, b
+    # four rows: one row off the plan takes the whole frame to the full capture
+    monkeypatch.setenv("RC_LIVE_MIRROR_BLIND", "1")
+    B, T = 4, 90
+    m = synth.make_motion(143, B, T, synth_assets["body"], conf="mixed")
+    m["j2dc"][1, 20:50, :, 2] = 0.45
+    m["j2dc"][2, :, :, 2] = 0.95
+    m["j2dc"][3, 5:, :, 2] = 0.3
+    m["j2dc"][3, 60:, :, 2] = 0.9                                # ... and back on camera: a transition step, later the high regime
+    a, b = make_net(synth_assets, B), make_net(synth_assets, B)
+    a.gravityc = b.gravityc = t(m["gravityc"])
+    worst = 0.0
+    for i in range(T):
+        args = (t(m["j2dc"][:, i]), t(m["accc"][:, i]), t(m["oric"][:, i]))
+        pa, ta = a.forward_batch(*args, first_frame=(i == 0))
+        pb, tb = b.forward_live(*args, first_frame=(i == 0))
+        assert a.get_trace().tolist() == b.get_trace().tolist(), i
+        worst = max(worst, maxdiff(pa, pb), maxdiff(ta, tb))
+    assert worst <= 1e-5, worst
+    assert b.live_replayed() >= 2, b.live_replayed()
+    for n in ("rnn4", "rnn6", "rnn7"):
+        (ha, ca), (hb, cb) = a.get_state(n), b.get_state(n)
+        assert maxdiff(ha, hb) <= 1e-5 and maxdiff(ca, cb) <= 1e-5, n
+
+
 def test_lean_capture_follows_reset_and_parameter_pokes(synth_assets):
     """reset_states() between sequences (init_net must run again: full capture), an attribute poke (re-capture) and a weight
     reload under a live session: the session stays equal to the frame-stepped plan to rounding."""
