@@ -287,6 +287,8 @@ class Net:
         Inputs [B,T,33,3], [B,T,6,3], [B,T,6,3,3]; returns device tensors pose [B,T,24,3,3], tran [B,T,3]."""
         B = self.batch
         T = j2dc.shape[1]
+        if T == 0:                                                          # (the reference's loop over no frames: nothing happens)
+            return torch.empty(B, 0, 24, 3, 3, device=self.device), torch.empty(B, 0, 3, device=self.device)
         self._sync_gravity()
         (j2dc, rs_j), (accc, rs_a), (oric, rs_o) = self._prep_rows(j2dc, B, T, 99), self._prep_rows(accc, B, T, 18), self._prep_rows(oric, B, T, 54)
         ft = None if first_tran is None else self._prep(first_tran, (B, 3))

@@ -79,8 +79,8 @@ def test_wavefront_vs_reference_and_vs_frame_stepped(name, synth_assets):
 
 
 def test_chunked_calls_and_short_segments(synth_assets):
-    """Segments of every length (odd and even starts -> both step parities), split over several rc_sequence calls."""
-    s, net, p, tr = _fixture_run(synth_assets, "seq_allvis_ff.npz", True, min_frames=3, chunks=[0, 1, 8, 9, 30, 33, 34, 77, 160])
+    """Segments of every length (odd and even starts -> both step parities; one call with NO frame at all), split over several rc_sequence calls."""
+    s, net, p, tr = _fixture_run(synth_assets, "seq_allvis_ff.npz", True, min_frames=3, chunks=[0, 1, 8, 8, 9, 30, 33, 34, 77, 160])
     _, ref, sp, st = _fixture_run(synth_assets, "seq_allvis_ff.npz", False)
     assert torch.equal(p, sp) and torch.equal(tr, st)
     wave, stepped, _ = net.sequence_stats()
