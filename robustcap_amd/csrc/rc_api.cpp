@@ -1523,6 +1523,7 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                 int64_t rs_ori, const float* first_tran, uint32_t flags, float* pose_out, int64_t rs_pose, float* tran_out,
                 int64_t rs_tran, void* stream) {
     if (int rc = check_ready(ctx)) return rc;
+    if (T == 0) return RC_OK;                                               // (evaluate.py:75-83 over no frames: nothing happens, whatever the pointers)
     ctx->live_prev_known = false;
     if (T < 0 || !j2dc || !accc || !oric || !pose_out || !tran_out) return fail(ctx, RC_ERR_INVALID, "rc_sequence: bad argument");
     // Very long calls are planned in pieces: the plan's tables (regime codes, frame_at) grow with batch x frames, and a piece
