@@ -15,6 +15,8 @@
 #include "rc_internal.h"
 
 #include <algorithm>
+#include <immintrin.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -128,6 +130,15 @@ struct rc_ctx {
     // the idle-time pre-step (rc_live.hip: rc_live_pre): the recurrent halves of the next frame's layer steps, computed behind a frame
     // when the caller leaves the device idle between frames (a 60 fps stream: 16.6 ms)
     int live_prestep = 1;                                   // RC_LIVE_PRESTEP: 0 = never
+    // RC_LIVE_SPIN: the first kernel of the NEXT lean frame is launched at the end of rc_live_step and waits on the device for the frame (rc_live.hip)
+    bool live_spin = true, live_spin_always = false;        // 1: behind frames of a paced caller (the pre-step's idle rule), 2: behind every lean frame
+    volatile unsigned* spin_mb = nullptr;                   // mailbox, host-writable device memory: [0] command, [16] decision
+    float* spin_in = nullptr;                               // the frame's inputs, same allocation
+    unsigned* spin_state_h = nullptr;                       // pinned: 3 = the waiting kernel gave up
+    int aql_prog_spin = -1, aql_prog_spin_pre = -1;
+    int spin_pending = -1;                                  // program whose first kernel is waiting
+    bool spin_valid = false;                                // nothing has touched weights / state since it was launched
+    long long stat_live_spin = 0, stat_live_spin_lost = 0;  // frames that started from a waiting K1 / waiting K1s sent away or timed out
     bool live_arm = true;                                   // RC_LIVE_ARM=0 switches it off: a paced caller leaves a barrier packet waiting at the head of the queue
     double live_prestep_idle_us = 500.0;                    // RC_LIVE_PRESTEP_IDLE_US: idle time in front of a frame from which the next pre-step is enqueued
     float* live_pre_buf = nullptr;                          // [tiles of the twelve layer steps][2 waves][64 lanes][4]
@@ -221,6 +232,7 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
 // (The other direction needs nothing: rc_live_step synchronises its stream before it returns.)
 int mark_eager(rc_ctx* ctx, hipStream_t st) {
     ctx->live_pre_valid = false;         // the state the pre-step read is no longer the state the next live frame starts from
+    ctx->spin_valid = false;
     if (!ctx->eager_ev) return RC_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->eager_ev, st));
     ctx->eager_dirty = true;
@@ -551,6 +563,7 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
 // run every pending (deferred) updater step now: state then equals the reference's at the end of its frame
 int flush_pending(rc_ctx* ctx, hipStream_t st) {
     ctx->live_pre_valid = false;
+    ctx->spin_valid = false;
     if (!ctx->have_weights || !ctx->prm.use_vision_updater) return RC_OK;
     const FrameBuffers& fb = ctx->fb;
     rc_launch_flush_flags(fb, ctx->B, st);
@@ -1247,6 +1260,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_prestep = tune_env("RC_LIVE_PRESTEP", 1);
     ctx->live_prestep_idle_us = (double)tune_env("RC_LIVE_PRESTEP_IDLE_US", 500);
     ctx->live_arm = tune_env("RC_LIVE_ARM", 1) != 0;
+    ctx->live_spin = tune_env("RC_LIVE_SPIN", 1) != 0;
+    ctx->live_spin_always = tune_env("RC_LIVE_SPIN", 1) >= 2;
     ctx->live_blind = tune_env("RC_LIVE_MIRROR_BLIND", 0) != 0;
     ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
     ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
@@ -1682,7 +1697,9 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_exec) { (void)hipGraphExecDestroy(ctx->live_exec); ctx->live_exec = nullptr; }
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
     if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
-    if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }     // (waits for a pre-step still in flight)
+    if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }     // (waits for a pre-step still in flight; tells a waiting K1 to leave)
+    ctx->spin_mb = nullptr; ctx->spin_in = nullptr; ctx->aql_prog_spin = ctx->aql_prog_spin_pre = -1; ctx->spin_pending = -1; ctx->spin_valid = false;
+    if (ctx->spin_state_h) { (void)hipHostFree(ctx->spin_state_h); ctx->spin_state_h = nullptr; }
     if (ctx->live_pre_buf) { (void)hipFree(ctx->live_pre_buf); ctx->live_pre_buf = nullptr; }
     ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
     ctx->live_pre_valid = false; ctx->live_have_return = false;
@@ -1806,6 +1823,29 @@ int rc_live_begin(rc_ctx* ctx) {
                     } else { ctx->live_pre_buf = nullptr; (void)hipGetLastError(); }
                     if (ctx->aql_prog_pre < 0) ctx->aql_prog_lean_pre = -1;
                 }
+                // RC_LIVE_SPIN: the same programs once more with the inputs and a mailbox in host-writable device memory; their first
+                // kernel is launched ahead of the frame and waits there (rc_live_k1)
+                if (ctx->live_aql && ctx->live_spin && ctx->aql_prog_lean >= 0) {
+                    void* shared = nullptr;
+                    unsigned* state_d = nullptr;
+                    if (rc_aql_alloc_shared(ctx->live_aql, 4096 + B * 171 * sizeof(float), &shared) == 0 &&
+                        hipHostMalloc((void**)&ctx->spin_state_h, 64, hipHostMallocMapped) == hipSuccess &&
+                        hipHostGetDevicePointer((void**)&state_d, ctx->spin_state_h, 0) == hipSuccess) {
+                        *ctx->spin_state_h = 0;
+                        ctx->spin_mb = (volatile unsigned*)shared;
+                        ctx->spin_in = (float*)((char*)shared + 4096);
+                        for (int q = 0; q < 64; ++q) ctx->spin_mb[q] = 0u;
+                        LiveFrame Fs = F;
+                        Fs.io.j2d = ctx->spin_in; Fs.io.acc = ctx->spin_in + B * 99; Fs.io.ori = ctx->spin_in + B * 117;
+                        Fs.spin_mb = (unsigned*)shared; Fs.spin_state = state_d;
+                        std::vector<LiveKernel> ps(RC_LIVE_KERNELS);
+                        if (rc_live_plan(Fs, ps.data()) == RC_LIVE_KERNELS) ctx->aql_prog_spin = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
+                        if (ctx->aql_prog_spin >= 0 && ctx->aql_prog_lean_pre >= 0 && rc_live_plan(Fs, ps.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS)
+                            ctx->aql_prog_spin_pre = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
+                        if (ctx->aql_prog_spin >= 0) rc_aql_set_mailbox(ctx->live_aql, ctx->spin_mb);
+                    }
+                    if (ctx->aql_prog_spin < 0) { ctx->spin_mb = nullptr; ctx->spin_in = nullptr; (void)hipGetLastError(); }
+                }
             } else ctx->live_aql_note = "switched off";
             return std::string();
         };
@@ -1873,6 +1913,29 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     bool aql_done = false;
     const bool use_pre = lean && ctx->live_aql && ctx->live_pre_valid && ctx->aql_prog_lean_pre >= 0;
     ctx->live_pre_valid = false;                                  // (whatever this frame is, it moves the state on)
+    // A first kernel launched ahead of this frame (RC_LIVE_SPIN) is waiting on the device: it takes the frame if the frame is what it was
+    // launched for (lean, same program, nothing touched weights or state since, and it has not given up); otherwise it is sent away.
+    bool spin_go = false;
+    if (ctx->spin_pending >= 0 && ctx->live_aql) {
+        const int want = use_pre ? ctx->aql_prog_spin_pre : ctx->aql_prog_spin;
+        const bool gone = __atomic_load_n(ctx->spin_state_h, __ATOMIC_ACQUIRE) == 3u;
+        spin_go = lean && !gone && ctx->spin_valid && ctx->spin_pending == want && !waited_eager;
+        if (spin_go) {
+            std::memcpy(ctx->spin_in, ctx->live_in_h, B * 171 * sizeof(float));
+            _mm_sfence();
+            ctx->spin_mb[0] = 1u;                                           // go: behind the inputs (stores to the device are posted in order; 0.1 us of host time)
+            _mm_sfence();
+        } else {
+            // skip: the kernel leaves and the six behind it change nothing (LiveFrame.abort); frames on this queue are ordered behind them, a
+            // frame on the HIP stream waits for them here (a kernel that has given up is no longer there to read the word)
+            ctx->spin_mb[0] = 2u;
+            _mm_sfence();
+            if (!(lean && ctx->live_aql) && rc_aql_wait_frame(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the frame queued ahead did not leave");
+            *ctx->spin_state_h = 0;
+            ctx->stat_live_spin_lost += 1;
+            ctx->spin_pending = -1;
+        }
+    }
     if (!(lean && ctx->live_aql) && ctx->live_aql) {
         // this frame runs on the HIP stream: a pre-step still in the HSA queue must not read the state while the frame rewrites it
         if (rc_aql_wait_background(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the pre-step did not complete");
@@ -1887,7 +1950,19 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     } else if (lean) {
         if (ctx->live_aql) {
             if (waited_eager) HIP_TRY(ctx, hipStreamSynchronize(st));        // the AQL queue is not ordered behind the stream: wait here
-            if (rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean) != 0) {
+            int arc = 0;
+            if (spin_go) {
+                arc = rc_aql_wait_frame(ctx->live_aql);
+                ctx->spin_pending = -1;
+                if (arc == 0 && __atomic_load_n(ctx->spin_state_h, __ATOMIC_ACQUIRE) == 3u) {
+                    // the waiting kernel gave up in the very moment the frame arrived: the six kernels behind it have changed nothing
+                    // (LiveFrame.abort) -- the frame runs on the ordinary program
+                    *ctx->spin_state_h = 0;
+                    ctx->stat_live_spin_lost += 1;
+                    arc = rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean);
+                } else if (arc == 0) ctx->stat_live_spin += 1;
+            } else arc = rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean);
+            if (arc != 0) {
                 // The frame did not retire in time (a tool on the queue, a wedged device): the chain is dropped -- its destructor waits
                 // for whatever is still in flight before the ring and the argument blocks go -- and the following frames replay the
                 // captured graph of the same seven kernels. THIS frame's state is unknown: the caller gets the error.
@@ -1895,6 +1970,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
                 ctx->live_aql = nullptr;
                 ctx->live_aql_note = "an AQL frame did not complete: back on hipGraphLaunch";
                 ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
+                ctx->aql_prog_spin = ctx->aql_prog_spin_pre = -1; ctx->spin_pending = -1; ctx->spin_mb = nullptr; ctx->spin_in = nullptr;
                 ctx->live_prev_known = false;
                 return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete (later frames use the graph replay)");
             }
@@ -1945,7 +2021,14 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (ctx->live_aql && ctx->aql_prog_pre >= 0 && idle_us >= ctx->live_prestep_idle_us) {
         if (rc_aql_submit(ctx->live_aql, ctx->aql_prog_pre) == 0) { ctx->live_pre_valid = true; ctx->stat_live_pre += 1; }
     }
-    if (ctx->live_aql && ctx->live_arm && idle_us >= ctx->live_prestep_idle_us) (void)rc_aql_arm(ctx->live_aql);
+    if (ctx->live_aql && ctx->aql_prog_spin >= 0 && ctx->spin_pending < 0 && lean && idle_us < 50000.0 && (ctx->live_spin_always || idle_us >= ctx->live_prestep_idle_us)) {
+        // the next frame's first kernel, now (RC_LIVE_SPIN): command and decision words cleared first -- every workgroup of the launch reads them after this
+        const int prog = (ctx->live_pre_valid && ctx->aql_prog_spin_pre >= 0) ? ctx->aql_prog_spin_pre : ctx->aql_prog_spin;
+        ctx->spin_mb[0] = 0u; ctx->spin_mb[16] = 0u;
+        _mm_sfence();
+        *ctx->spin_state_h = 0;
+        if (rc_aql_submit_ahead(ctx->live_aql, prog) == 0) { ctx->spin_pending = prog; ctx->spin_valid = true; }
+    } else if (ctx->live_aql && ctx->live_arm && ctx->spin_pending < 0 && idle_us >= ctx->live_prestep_idle_us) (void)rc_aql_arm(ctx->live_aql);
     if (lean) {
         const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::micro>(b - a).count();
@@ -1971,6 +2054,13 @@ int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available) {
     if (!ctx) return RC_ERR_INVALID;
     if (presteps) *presteps = ctx->stat_live_pre;
     if (available) *available = (ctx->live_aql && ctx->aql_prog_pre >= 0) ? 1 : 0;
+    return RC_OK;
+}
+
+int rc_get_live_spin(rc_ctx* ctx, int64_t* taken, int64_t* lost) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (taken) *taken = ctx->stat_live_spin;
+    if (lost) *lost = ctx->stat_live_spin_lost;
     return RC_OK;
 }
 

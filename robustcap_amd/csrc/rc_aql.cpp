@@ -13,6 +13,8 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 
+#include <immintrin.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +44,10 @@ struct AqlChain {
     // RC_LIVE_ARM: a barrier-AND packet left at the head of the ring while the caller is away, waiting on arm[armed]; the next push releases it
     hsa_signal_t arm[2]{};
     int arm_next = 0, armed = -1;
+    hsa_agent_t cpu{};
+    bool have_cpu = false;
+    std::vector<void*> shared;                   // rc_aql_alloc_shared
+    volatile unsigned* mailbox = nullptr;        // of a spinning K1 (rc_aql_set_mailbox)
     bool dead = false;                           // a frame did not complete in time: the chain takes no further frame (rc_live_step falls back)
     long long sig0 = 0;                          // value of `done` / `bg_done` before any program: every retired one decrements it
     std::vector<AqlProgram> prog;
@@ -52,11 +58,13 @@ struct AqlChain {
 namespace {
 constexpr size_t kKargStride = 2048;
 
-struct FindAgent { uint32_t bdf; uint32_t domain = 0; int count = 0; hsa_agent_t first{}, match{}; bool have_match = false; };
+struct FindAgent { uint32_t bdf; uint32_t domain = 0; int count = 0; hsa_agent_t first{}, match{}; bool have_match = false; hsa_agent_t cpu{}; bool have_cpu = false; };
 hsa_status_t agent_cb(hsa_agent_t a, void* d) {
     FindAgent* f = (FindAgent*)d;
     hsa_device_type_t t;
-    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->cpu = a; f->have_cpu = true; }
+    if (t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
     if (f->count++ == 0) f->first = a;
     uint32_t bdf = 0, dom = 0;
     if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) != HSA_STATUS_SUCCESS) dom = f->domain;   // (older runtimes: bus / device / function only)
@@ -124,6 +132,7 @@ int rc_aql_create(int hip_device, AqlChain** out, char* err, int err_len) {
     if ((st = hsa_iterate_agents(agent_cb, &fa)) != HSA_STATUS_SUCCESS || fa.count == 0) return bail(c, err, err_len, "no GPU agent", st);
     if (!fa.have_match && fa.count != 1) return bail(c, err, err_len, "cannot match the HIP device to an HSA agent");
     c->gpu = fa.have_match ? fa.match : fa.first;
+    c->cpu = fa.cpu; c->have_cpu = fa.have_cpu;
     if ((st = hsa_queue_create(c->gpu, 64, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->q)) != HSA_STATUS_SUCCESS)
         return bail(c, err, err_len, "hsa_queue_create", st);
     c->sig0 = 1ll << 62;                                                     // counts down once per frame: ~10^14 years of frames
@@ -239,17 +248,18 @@ static void aql_release(AqlChain* c) {
 
 // body first, header (which hands the packet to the packet processor) last; the barrier bit of every packet orders it behind everything
 // in front of it in the ring -- a frame behind the pre-step that ran in the idle time, the pre-step behind the frame whose state it reads
-static void aql_push(AqlChain* c, const AqlProgram& P) {
+static void aql_push(AqlChain* c, const AqlProgram& P, int i0 = 0, int i1 = -1) {
     hsa_queue_t* q = c->q;
+    if (i1 < 0) i1 = P.n;
     const uint32_t mask = q->size - 1;
     const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; at most one frame + one background program are in the ring
-    for (int i = 0; i < P.n; ++i) {
-        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + i) & mask);
+    for (int i = i0; i < i1; ++i) {
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + (i - i0)) & mask);
         std::memcpy((char*)p + 4, (const char*)&P.pkt[i] + 4, sizeof(*p) - 4);
         __atomic_store_n((uint32_t*)p, (uint32_t)P.hdr[i] | ((uint32_t)P.pkt[i].setup << 16), __ATOMIC_RELEASE);
     }
-    hsa_queue_store_write_index_release(q, base + P.n);
-    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + P.n - 1));
+    hsa_queue_store_write_index_release(q, base + (i1 - i0));
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + (i1 - i0) - 1));
     aql_release(c);
 }
 
@@ -285,6 +295,81 @@ int rc_aql_submit(AqlChain* c, int prog) {
     return 0;
 }
 
+// ---- a frame program queued AHEAD of its frame: its first kernel (rc_live_k1) waits on the device for the mailbox, the six behind it for
+// the first; when the frame arrives the host only writes the inputs and the command word, then waits like for any frame
+int rc_aql_submit_ahead(AqlChain* c, int prog) {
+    if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || !c->prog[prog].frame) return -1;
+    if (c->dead) return -3;
+    aql_push(c, c->prog[prog]);
+    c->seq += 1;
+    return 0;
+}
+
+static int aql_wait_frame(AqlChain* c);
+int rc_aql_wait_frame(AqlChain* c) {                                        // the frame submitted last (rc_aql_submit_ahead) has retired
+    if (!c || !c->q) return -1;
+    if (c->dead) return -3;
+    return aql_wait_frame(c);
+}
+
+// everything in front of this packet has retired when the background signal has counted it (its barrier bit orders it)
+int rc_aql_fence_background(AqlChain* c) {
+    if (!c || !c->q) return -1;
+    if (c->dead) return -3;
+    hsa_queue_t* q = c->q;
+    const uint32_t mask = q->size - 1;
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);
+    hsa_barrier_and_packet_t* p = (hsa_barrier_and_packet_t*)q->base_address + (base & mask);
+    hsa_barrier_and_packet_t b;
+    std::memset(&b, 0, sizeof(b));
+    b.completion_signal = c->bg_done;
+    std::memcpy((char*)p + 4, (const char*)&b + 4, sizeof(b) - 4);
+    const uint16_t hdr = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+    __atomic_store_n((uint32_t*)p, (uint32_t)hdr, __ATOMIC_RELEASE);
+    hsa_queue_store_write_index_release(q, base + 1);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)base);
+    aql_release(c);
+    c->bg_seq += 1;
+    return 0;
+}
+
+// Device memory the host writes directly (large BAR): the extended-scope fine-grained pool of the GPU (a kernel that is already running
+// sees the host's stores: tools/spin_probe), made accessible to the CPU agent. Freed with the chain.
+namespace {
+struct PoolPick { hsa_amd_memory_pool_t pool{}; bool have = false; hsa_agent_t cpu; };
+hsa_status_t pool_cb(hsa_amd_memory_pool_t p, void* d) {
+    PoolPick* k = (PoolPick*)d;
+    hsa_amd_segment_t seg;
+    uint32_t flags = 0;
+    bool alloc = false;
+    if (hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+    (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    hsa_amd_memory_pool_access_t acc = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+    (void)hsa_amd_agent_memory_pool_get_info(k->cpu, p, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &acc);
+    if (!alloc || acc == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED || !(flags & 8u)) return HSA_STATUS_SUCCESS;   // 8: extended-scope fine-grained
+    if (!k->have) { k->pool = p; k->have = true; }
+    return HSA_STATUS_SUCCESS;
+}
+}  // namespace
+
+int rc_aql_alloc_shared(AqlChain* c, size_t bytes, void** ptr) {
+    if (!c || !ptr || !c->have_cpu) return -1;
+    *ptr = nullptr;
+    PoolPick k;
+    k.cpu = c->cpu;
+    if (hsa_amd_agent_iterate_memory_pools(c->gpu, pool_cb, &k) != HSA_STATUS_SUCCESS || !k.have) return -2;
+    void* q = nullptr;
+    if (hsa_amd_memory_pool_allocate(k.pool, (bytes + 4095) & ~(size_t)4095, 0, &q) != HSA_STATUS_SUCCESS) return -3;
+    hsa_agent_t both[2] = {c->cpu, c->gpu};
+    if (hsa_amd_agents_allow_access(2, both, nullptr, q) != HSA_STATUS_SUCCESS) { (void)hsa_amd_memory_pool_free(q); return -4; }
+    c->shared.push_back(q);
+    *ptr = q;
+    return 0;
+}
+
+void rc_aql_set_mailbox(AqlChain* c, volatile unsigned* mb) { if (c) c->mailbox = mb; }
+
 int rc_aql_wait_background(AqlChain* c) {
     if (!c || !c->q || c->bg_seq == 0) return 0;
     const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)c->bg_seq);
@@ -292,12 +377,8 @@ int rc_aql_wait_background(AqlChain* c) {
     return hsa_signal_wait_scacquire(c->bg_done, HSA_SIGNAL_CONDITION_LT, retired + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) <= retired ? 0 : -2;
 }
 
-int rc_aql_run(AqlChain* c, int prog) {
-    if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || !c->prog[prog].frame) return -1;
-    if (c->dead) return -3;
-    // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
-    aql_push(c, c->prog[prog]);
-    const unsigned long long seq = ++c->seq;
+static int aql_wait_frame(AqlChain* c) {
+    const unsigned long long seq = c->seq;
     const unsigned seq32 = (unsigned)seq;                                   // what K7 stores: its device counter wraps the same way
     const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)seq);
     const auto t0 = std::chrono::steady_clock::now();
@@ -317,10 +398,21 @@ int rc_aql_run(AqlChain* c, int prog) {
     return 0;
 }
 
+int rc_aql_run(AqlChain* c, int prog) {
+    if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || !c->prog[prog].frame) return -1;
+    if (c->dead) return -3;
+    // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
+    aql_push(c, c->prog[prog]);
+    c->seq += 1;
+    return aql_wait_frame(c);
+}
+
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
     if (!c || !c->q) return;
+    if (c->mailbox) { c->mailbox[0] = 2u; _mm_sfence(); }                  // a K1 still spinning (rc_live.hip) leaves: nothing is queued behind it
     aql_release(c);
+    if (c->mailbox && !c->dead) (void)rc_aql_fence_background(c);           // ... and the wait below covers it
     if (c->seq) (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
     (void)rc_aql_wait_background(c);
 }
@@ -331,6 +423,7 @@ void rc_aql_destroy(AqlChain* c) {
     if (c->flag_h) (void)hipHostFree(c->flag_h);
     if (c->seq_d) (void)hipFree(c->seq_d);
     if (c->q) (void)hsa_queue_destroy(c->q);
+    for (void* q : c->shared) (void)hsa_amd_memory_pool_free(q);
     if (c->done.handle) (void)hsa_signal_destroy(c->done);
     if (c->bg_done.handle) (void)hsa_signal_destroy(c->bg_done);
     for (int a = 0; a < 2; ++a) if (c->arm[a].handle) (void)hsa_signal_destroy(c->arm[a]);

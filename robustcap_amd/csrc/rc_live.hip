@@ -35,6 +35,7 @@ enum { LN2 = 0, LN3 = 1, LN4 = 2, LN6 = 3, LN7 = 4, LN8 = 5 };     // rc_api.cpp
 #define LIVE_H5 512
 __host__ __device__ constexpr int live_H(int ni) { return ni == LN4 ? LIVE_H4 : (ni == LN6 ? LIVE_H6 : LIVE_H5); }
 
+#define RC_LIVE_SPIN_TICKS 10000000ull   // 100 ms of the 100 MHz counter: how long a K1 launched ahead of its frame waits for it
 #define LIVE_XLD 260          // floats per A row in LDS (256 + 4: the 16 rows of a fragment read land on different banks)
 
 __device__ __forceinline__ f32x4 ldg_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
@@ -171,6 +172,44 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k1(const LiveFrame F) 
     RC_LT(0, 0);
     Lin1W w;
     lin1_request(w, n, Kp1, n_tile, tid);
+    // ---- launched AHEAD of the frame (LiveFrame.spin_mb, rc_api.cpp: RC_LIVE_SPIN): the kernel arguments are in, the linear1 weights are
+    // requested, and the workgroups wait here for the frame -- rc_live_step writes the inputs and then the command word into device memory
+    // (large BAR) instead of ringing a doorbell for this kernel, and the packet processor's dispatch (~5 us) is behind us when the frame
+    // arrives. ONE waiter decides (workgroup 0, thread 0: it polls the host's word, bounded, and publishes what it saw); everybody else
+    // follows its decision, so a time-out can never split the grid. "skip" / "timed out": the kernel leaves, and neither it nor the six
+    // kernels queued behind it change anything (LiveFrame.abort, the cleared `act` words).
+    if (F.spin_mb) {
+        __shared__ unsigned s_cmd;
+        if (tid == 0) {
+            unsigned v = 0;
+            if (blockIdx.x == 0) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    v = __hip_atomic_load(F.spin_mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (v != 0u) break;
+                    if (wall_clock64() - t0 > RC_LIVE_SPIN_TICKS) { v = 3u; break; }
+                }                                                           // (no s_sleep: after milliseconds of idling the shader clock is low and a sleep of
+                                                                            // a few hundred cycles is microseconds -- one wave polling costs nothing)
+                if (v != 1u) {                                              // sent away, or gave up: the six kernels queued behind this one change nothing
+                    *F.abort = 1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (F.hot[q])
+                            for (int p = 0; p < 2; ++p)
+                                for (int r = 0; r < RC_LIVE_MAXB; ++r) F.hot[q]->act[p][r] = 0;
+                    if (v == 3u) __hip_atomic_store(F.spin_state, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __hip_atomic_store(F.spin_mb + 16, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                while ((v = __hip_atomic_load(F.spin_mb + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0u) __builtin_amdgcn_s_sleep(1);
+            }
+            s_cmd = v;
+        }
+        __syncthreads();
+        if (s_cmd != 1u) return;
+        RC_LT(0, 5);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                       // (system scope) the inputs the host wrote in front of the command
+    }
     // Is this frame the lean plan's at all? A row that carries a deferred updater step INTO a frame it steps on camera data needs the
     // transition launches, a row that reaches the high regime for the first time triggers init_net (L178-183): rc_live_step keeps such frames
     // away with a conservative host-side mirror of the two flags; here is the check itself. Every workgroup computes it (it has the prep of

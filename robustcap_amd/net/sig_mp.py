@@ -274,6 +274,12 @@ class Net:
         _lib.check(self._ctx, self._lib.rc_get_live_prestep(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_prestep")
         return a.value, bool(b.value)
 
+    def live_spin_stats(self):
+        """(frames that started from a first kernel launched ahead of them, such kernels sent away or timed out): rc_get_live_spin (RC_LIVE_SPIN=1)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._ctx, self._lib.rc_get_live_spin(self._ctx, C.byref(a), C.byref(b)), "rc_get_live_spin")
+        return a.value, b.value
+
     def live_replayed(self):
         """Lean live frames whose own device-side check found them off the lean plan (a transition step or an init_net trigger the host-side
         mirror in rc_live_step did not foresee): they change nothing and are replayed on the full capture. Expected: 0."""

@@ -271,8 +271,9 @@ def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch)
     live = str(s["live"])
     outs = []
     # (the second leg also leaves the queue armed behind every frame -- rc_aql_arm, a barrier packet the next push releases; the first never)
-    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM"):
+    # ... and queues the NEXT frame ahead behind every lean frame, its first kernel waiting on the device for the inputs (RC_LIVE_SPIN)
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -298,12 +299,13 @@ def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch)
                 traces.append(net.get_trace()[0].tolist())
         n_pre, avail = net.live_prestep_stats()
         states = {n: net.get_state(n) for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8")}
-        outs.append((torch.stack(poses), torch.stack(trans), traces, states, n_pre, avail, net.live_stats()))
+        outs.append((torch.stack(poses), torch.stack(trans), traces, states, n_pre, avail, net.live_stats(), net.live_spin_stats()))
         del net
     a, b = outs
-    assert a[4] == 0
+    assert a[4] == 0 and a[7] == (0, 0)
     if b[5]:                                                              # (a profiler on the queue, RC_LIVE_AQL=0: no AQL chain, no pre-step)
         assert b[4] >= b[6][0] - 1 and b[4] > 0                           # behind every frame
+        assert b[7][0] >= b[6][0] // 2, (b[7], b[6])                      # most lean frames started from a kernel that was already waiting
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and a[6] == b[6]
     for n in a[3]:
         assert torch.equal(a[3][n][0], b[3][n][0]) and torch.equal(a[3][n][1], b[3][n][1]), n
@@ -320,8 +322,10 @@ def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkey
     script = {40: "reset", 77: "eager", 101: "state", 130: "poke", 171: "reload", 200: "reset", 201: "eager", 202: "state"}
     outs = []
     # third leg: the armed queue alone (a barrier packet behind every frame, no pre-step), through the same script
-    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}, {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM"):
+    # fourth: the frame queued ahead alone (no pre-step): reset, eager steps, pokes and reloads send the waiting kernel away
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"},
+                {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -349,11 +353,14 @@ def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkey
             p, tr = net.forward_online(t(m["j2dc"][0, i]), t(m["accc"][0, i]), t(m["oric"][0, i]), None, i == 0 or op == "reset")
             res.append((p.clone(), tr.clone()))
         n_pre, avail = net.live_prestep_stats()
-        outs.append((res, n_pre, avail, net.live_stats()))
+        outs.append((res, n_pre, avail, net.live_stats(), net.live_spin_stats()))
         del net
-    a, b, c = outs
-    assert a[1] == 0 and c[1] == 0 and (not b[2] or b[1] > 150)
-    for o in (b, c):
+    a, b, c, d = outs
+    assert a[1] == 0 and c[1] == 0 and d[1] == 0 and (not b[2] or b[1] > 150)
+    assert a[4] == (0, 0) and c[4] == (0, 0)
+    if b[2]:
+        assert d[4][0] > 150 and d[4][1] >= 3, d[4]                      # taken / sent away (the script's resets, eager steps, pokes, reloads)
+    for o in (b, c, d):
         assert a[3] == o[3] and len(a[0]) == len(o[0])
         for x, y in zip(a[0], o[0]):
             assert all(torch.equal(u, v) for u, v in zip(x, y))

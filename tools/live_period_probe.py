@@ -22,15 +22,19 @@ def main():
     if os.environ.get("RC_PROBE_EXTRA"):                                # side questions on the default configuration, paced
         modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("edge fences at agent scope", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_AQL_EDGE_SCOPE": "agent"}),
                  ("completion by the signal", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_DONE_FLAG": "0"}), ("prestep+arm again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
+    if os.environ.get("RC_PROBE_EXTRA") == "3":                         # the next frame's first kernel launched ahead and waiting on the device (RC_LIVE_SPIN)
+        modes = (("default", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("frame queued ahead, first kernel waiting (paced callers)", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_SPIN": "1"}),
+                 ("... behind every lean frame", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_SPIN": "2"}), ("default again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
     if os.environ.get("RC_PROBE_EXTRA") == "2":                         # timing probe (needs profiles/r05_live_prequeue_experiment.diff applied): the next frame's packets already behind the armed barrier (RC_PROBE_CONF=high)
         modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("prestep+arm+frame queued ahead", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}),
                  ("plain+arm", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100"}),
                  ("plain+arm+frame queued ahead", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}))
-    for period_ms in ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0)):
+    for period_ms in ((16.667, 0.0) if os.environ.get("RC_PROBE_EXTRA") == "3" else ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0))):
         for name, env in modes:
             net = L.make(sd, body, m, env=env)
             st = L.stats(L.run_c(net, m, n, period_ms * 1e-3))
-            rows.append({"period_ms": period_ms, "mode": name, **st, "pre": list(net.live_prestep_stats()) if hasattr(net, "live_prestep_stats") else None})
+            rows.append({"period_ms": period_ms, "mode": name, **st, "pre": list(net.live_prestep_stats()) if hasattr(net, "live_prestep_stats") else None,
+                         "spin": list(net.live_spin_stats()) if hasattr(net, "live_spin_stats") else None})
             del net
     print(json.dumps(rows, indent=1))
 

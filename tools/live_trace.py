@@ -74,21 +74,29 @@ def main_sync(conf, period):
         assert rd(buf) == 0
         st = np.array(buf[:], dtype=np.float64).reshape(4, 16)
         if i >= 60:
-            rows.append((t0, t1, st[0, 0] * nspt, st[2, 9] * nspt))
+            rows.append((t0, t1, st[0, 0] * nspt, st[2, 9] * nspt, st[0, 3] * nspt, st[0, 5] * nspt))
     off1, _, _ = clock_offset()
     ts1 = time.perf_counter_ns() - 50e6                                    # (the second calibration takes 50 ms; its best sample can be anywhere in it)
     r = np.array(rows)
+    if len(r) == 0:
+        print('no frames'); return
     lean, full = net.live_stats()
     # the two clocks drift (~10 ppm: tens of us over a paced run): the offset of a frame is interpolated between the two calibrations
     off = off0 + (off1 - off0) * (r[:, 0] - ts0) / max(ts1 - ts0, 1.0)
     sub = (r[:, 2] + off - r[:, 0]) * 1e-3
     gpu = (r[:, 3] - r[:, 2]) * 1e-3
     fin = (r[:, 1] - (r[:, 3] + off)) * 1e-3
-    ok = gpu > 0                                                           # (frames off the lean plan leave stale stamps)
+    ok = (gpu > 0) & (gpu < 1e6)                                           # (frames off the lean plan leave stale stamps)
     print(f"clock offset {off0 * 1e-3:.2f} us before, {off1 * 1e-3:.2f} us after the run ({moved} samples each; interpolated per frame; it contains one posted write over PCIe "
           f"and, paced, up to ~0.5 us of interpolation error: 'call -> K1' reads that much long and 'K7 -> return' that much short)")
     print(f"  call -> K1 entry      p50 {np.percentile(sub[ok], 50):6.2f}  mean {sub[ok].mean():6.2f} us")
     print(f"  K1 entry -> K7 end    p50 {np.percentile(gpu[ok], 50):6.2f}  mean {gpu[ok].mean():6.2f} us")
+    k1e = (r[:, 4] + off - r[:, 0]) * 1e-3
+    rest = (r[:, 3] - r[:, 4]) * 1e-3
+    print(f"  call -> K1 end        p50 {np.percentile(k1e[ok], 50):6.2f} us      K1 end -> K7 end  p50 {np.percentile(rest[ok], 50):6.2f} us")
+    if os.environ.get("RC_LIVE_SPIN"):
+        seen = (r[:, 5] + off - r[:, 0]) * 1e-3
+        print(f"  call -> K1 has the command (block 0)  p50 {np.percentile(seen[ok], 50):6.2f} us")
     print(f"  K7 end -> return      p50 {np.percentile(fin[ok], 50):6.2f}  mean {fin[ok].mean():6.2f} us")
     print(f"  call -> return        p50 {np.percentile((r[:, 1] - r[:, 0])[ok] * 1e-3, 50):6.2f} us   ({int(ok.sum())} frames, lean/full {lean}/{full}, pre-steps {net.live_prestep_stats()[0]})")
 
