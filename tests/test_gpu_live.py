@@ -210,8 +210,10 @@ def test_offplan_frames_are_caught_on_the_device_and_replayed(synth_assets, monk
         else:
             assert b.live_replayed() == 0
         del a, b
-    # four rows: one row off the plan takes the whole frame to the full capture
+    # four rows: one row off the plan takes the whole frame to the full capture -- here with the next frame queued ahead of every lean frame
+    # (RC_LIVE_SPIN=2), so the frames that are off the plan are caught by a first kernel that was already waiting for them
     monkeypatch.setenv("RC_LIVE_MIRROR_BLIND", "1")
+    monkeypatch.setenv("RC_LIVE_SPIN", "2")
     B, T = 4, 90
     m = synth.make_motion(143, B, T, synth_assets["body"], conf="mixed")
     m["j2dc"][1, 20:50, :, 2] = 0.45
@@ -229,6 +231,9 @@ def test_offplan_frames_are_caught_on_the_device_and_replayed(synth_assets, monk
         worst = max(worst, maxdiff(pa, pb), maxdiff(ta, tb))
     assert worst <= 1e-5, worst
     assert b.live_replayed() >= 2, b.live_replayed()
+    if aql == "1":
+        taken, lost = b.live_spin_stats()
+        assert taken >= T // 2, (taken, lost)
     for n in ("rnn4", "rnn6", "rnn7"):
         (ha, ca), (hb, cb) = a.get_state(n), b.get_state(n)
         assert maxdiff(ha, hb) <= 1e-5 and maxdiff(ca, cb) <= 1e-5, n
