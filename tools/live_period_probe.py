@@ -22,6 +22,8 @@ def main():
     if os.environ.get("RC_PROBE_EXTRA"):                                # side questions on the default configuration, paced
         modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("edge fences at agent scope", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_AQL_EDGE_SCOPE": "agent"}),
                  ("completion by the signal", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_DONE_FLAG": "0"}), ("prestep+arm again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
+    if os.environ.get("RC_PROBE_EXTRA") == "4":                         # one paced leg of the default configuration (A/B of library builds through RC_LIB_PATH)
+        modes = (("default", {}),)
     if os.environ.get("RC_PROBE_EXTRA") == "3":                         # the next frame's first kernel launched ahead and waiting on the device (RC_LIVE_SPIN)
         modes = (("default", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("frame queued ahead, first kernel waiting (paced callers)", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_SPIN": "1"}),
                  ("... behind every lean frame", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_SPIN": "2"}), ("default again", {"RC_LIVE_PRESTEP_IDLE_US": "100"}))
@@ -29,7 +31,7 @@ def main():
         modes = (("prestep+arm", {"RC_LIVE_PRESTEP_IDLE_US": "100"}), ("prestep+arm+frame queued ahead", {"RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}),
                  ("plain+arm", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100"}),
                  ("plain+arm+frame queued ahead", {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "100", "RC_LIVE_PREQUEUE": "1"}))
-    for period_ms in ((16.667, 0.0) if os.environ.get("RC_PROBE_EXTRA") == "3" else ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0))):
+    for period_ms in ((16.667,) if os.environ.get("RC_PROBE_EXTRA") == "4" else (16.667, 0.0) if os.environ.get("RC_PROBE_EXTRA") == "3" else ((16.667, 1.0) if os.environ.get("RC_PROBE_EXTRA") else (16.667, 1.0, 0.3, 0.0))):
         for name, env in modes:
             net = L.make(sd, body, m, env=env)
             st = L.stats(L.run_c(net, m, n, period_ms * 1e-3))
