@@ -135,8 +135,11 @@ struct rc_ctx {
     volatile unsigned* spin_mb = nullptr;                   // mailbox, host-writable device memory: [0] command, [16] decision
     float* spin_in = nullptr;                               // the frame's inputs, same allocation
     unsigned* spin_state_h = nullptr;                       // pinned: 3 = the waiting kernel gave up
-    int aql_prog_spin = -1, aql_prog_spin_pre = -1;
+    int aql_prog_spin[2] = {-1, -1}, aql_prog_spin_pre[2] = {-1, -1};   // by mailbox (frames queued ahead alternate between two)
     int spin_pending = -1;                                  // program whose first kernel is waiting
+    int spin_pending_par = 0, spin_next_par = 0;            // its mailbox / the next one's
+    unsigned long long spin_pending_seq = 0;                // its frame number on the chain
+    bool live_spin_b2b = true;                              // RC_LIVE_SPIN_B2B: a back-to-back caller's next frame is queued while this one runs, its K1 beside it
     bool spin_valid = false;                                // nothing has touched weights / state since it was launched
     long long stat_live_spin = 0, stat_live_spin_lost = 0;  // frames that started from a waiting K1 / waiting K1s sent away or timed out
     bool live_arm = true;                                   // RC_LIVE_ARM=0 switches it off: a paced caller leaves a barrier packet waiting at the head of the queue
@@ -1262,6 +1265,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_arm = tune_env("RC_LIVE_ARM", 1) != 0;
     ctx->live_spin = tune_env("RC_LIVE_SPIN", 1) != 0;
     ctx->live_spin_always = tune_env("RC_LIVE_SPIN", 1) >= 2;
+    ctx->live_spin_b2b = tune_env("RC_LIVE_SPIN_B2B", 1) != 0;
     ctx->live_blind = tune_env("RC_LIVE_MIRROR_BLIND", 0) != 0;
     ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
     ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
@@ -1698,7 +1702,8 @@ int rc_live_end(rc_ctx* ctx) {
     if (ctx->live_graph) { (void)hipGraphDestroy(ctx->live_graph); ctx->live_graph = nullptr; }
     if (ctx->live_exec_notr) { (void)hipGraphExecDestroy(ctx->live_exec_notr); ctx->live_exec_notr = nullptr; }
     if (ctx->live_aql) { rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr; }     // (waits for a pre-step still in flight; tells a waiting K1 to leave)
-    ctx->spin_mb = nullptr; ctx->spin_in = nullptr; ctx->aql_prog_spin = ctx->aql_prog_spin_pre = -1; ctx->spin_pending = -1; ctx->spin_valid = false;
+    ctx->spin_mb = nullptr; ctx->spin_in = nullptr; ctx->spin_pending = -1; ctx->spin_valid = false;
+    for (int q = 0; q < 2; ++q) ctx->aql_prog_spin[q] = ctx->aql_prog_spin_pre[q] = -1;
     if (ctx->spin_state_h) { (void)hipHostFree(ctx->spin_state_h); ctx->spin_state_h = nullptr; }
     if (ctx->live_pre_buf) { (void)hipFree(ctx->live_pre_buf); ctx->live_pre_buf = nullptr; }
     ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
@@ -1825,26 +1830,32 @@ int rc_live_begin(rc_ctx* ctx) {
                 }
                 // RC_LIVE_SPIN: the same programs once more with the inputs and a mailbox in host-writable device memory; their first
                 // kernel is launched ahead of the frame and waits there (rc_live_k1)
-                if (ctx->live_aql && ctx->live_spin && ctx->aql_prog_lean >= 0) {
+                if (ctx->live_aql && ctx->live_spin && ctx->aql_prog_lean >= 0 && RC_LIVE_KERNELS * 6 + 8 <= 64) {
                     void* shared = nullptr;
                     unsigned* state_d = nullptr;
                     if (rc_aql_alloc_shared(ctx->live_aql, 4096 + B * 171 * sizeof(float), &shared) == 0 &&
                         hipHostMalloc((void**)&ctx->spin_state_h, 64, hipHostMallocMapped) == hipSuccess &&
                         hipHostGetDevicePointer((void**)&state_d, ctx->spin_state_h, 0) == hipSuccess) {
-                        *ctx->spin_state_h = 0;
+                        for (int q = 0; q < 16; ++q) ctx->spin_state_h[q] = 0;
                         ctx->spin_mb = (volatile unsigned*)shared;
                         ctx->spin_in = (float*)((char*)shared + 4096);
                         for (int q = 0; q < 64; ++q) ctx->spin_mb[q] = 0u;
                         LiveFrame Fs = F;
                         Fs.io.j2d = ctx->spin_in; Fs.io.acc = ctx->spin_in + B * 99; Fs.io.ori = ctx->spin_in + B * 117;
-                        Fs.spin_mb = (unsigned*)shared; Fs.spin_state = state_d;
                         std::vector<LiveKernel> ps(RC_LIVE_KERNELS);
-                        if (rc_live_plan(Fs, ps.data()) == RC_LIVE_KERNELS) ctx->aql_prog_spin = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
-                        if (ctx->aql_prog_spin >= 0 && ctx->aql_prog_lean_pre >= 0 && rc_live_plan(Fs, ps.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS)
-                            ctx->aql_prog_spin_pre = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
-                        if (ctx->aql_prog_spin >= 0) rc_aql_set_mailbox(ctx->live_aql, ctx->spin_mb);
+                        bool ok = true;
+                        for (int par = 0; par < 2 && ok; ++par) {                   // two mailboxes (and give-up marks): the next frame is queued while this one may still be read
+                            Fs.spin_mb = (unsigned*)shared + 32 * par; Fs.spin_state = state_d + 4 * par;
+                            if (rc_live_plan(Fs, ps.data()) == RC_LIVE_KERNELS) ctx->aql_prog_spin[par] = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
+                            ok = ctx->aql_prog_spin[par] >= 0;
+                            if (ok && ctx->aql_prog_lean_pre >= 0 && rc_live_plan(Fs, ps.data(), ctx->live_pre_buf) == RC_LIVE_KERNELS)
+                                ctx->aql_prog_spin_pre[par] = rc_aql_add(ctx->live_aql, ps.data(), RC_LIVE_KERNELS, 1, msg, (int)sizeof(msg));
+                        }
+                        if (!ok) ctx->aql_prog_spin[0] = ctx->aql_prog_spin[1] = -1;
+                        if (ctx->aql_prog_spin_pre[0] < 0 || ctx->aql_prog_spin_pre[1] < 0) ctx->aql_prog_spin_pre[0] = ctx->aql_prog_spin_pre[1] = -1;
+                        if (ok) rc_aql_set_mailbox(ctx->live_aql, ctx->spin_mb);
                     }
-                    if (ctx->aql_prog_spin < 0) { ctx->spin_mb = nullptr; ctx->spin_in = nullptr; (void)hipGetLastError(); }
+                    if (ctx->aql_prog_spin[0] < 0) { ctx->spin_mb = nullptr; ctx->spin_in = nullptr; (void)hipGetLastError(); }
                 }
             } else ctx->live_aql_note = "switched off";
             return std::string();
@@ -1917,25 +1928,38 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     // launched for (lean, same program, nothing touched weights or state since, and it has not given up); otherwise it is sent away.
     bool spin_go = false;
     if (ctx->spin_pending >= 0 && ctx->live_aql) {
-        const int want = use_pre ? ctx->aql_prog_spin_pre : ctx->aql_prog_spin;
-        const bool gone = __atomic_load_n(ctx->spin_state_h, __ATOMIC_ACQUIRE) == 3u;
+        const int par = ctx->spin_pending_par;
+        const int want = use_pre ? ctx->aql_prog_spin_pre[par] : ctx->aql_prog_spin[par];
+        const bool gone = __atomic_load_n(ctx->spin_state_h + 4 * par, __ATOMIC_ACQUIRE) == 3u;
         spin_go = lean && !gone && ctx->spin_valid && ctx->spin_pending == want && !waited_eager;
         if (spin_go) {
             std::memcpy(ctx->spin_in, ctx->live_in_h, B * 171 * sizeof(float));
             _mm_sfence();
-            ctx->spin_mb[0] = 1u;                                           // go: behind the inputs (stores to the device are posted in order; 0.1 us of host time)
+            ctx->spin_mb[32 * par] = 1u;                                    // go: behind the inputs (stores to the device are posted in order; 0.1 us of host time)
             _mm_sfence();
         } else {
             // skip: the kernel leaves and the six behind it change nothing (LiveFrame.abort); frames on this queue are ordered behind them, a
             // frame on the HIP stream waits for them here (a kernel that has given up is no longer there to read the word)
-            ctx->spin_mb[0] = 2u;
+            ctx->spin_mb[32 * par] = 2u;
             _mm_sfence();
             if (!(lean && ctx->live_aql) && rc_aql_wait_frame(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the frame queued ahead did not leave");
-            *ctx->spin_state_h = 0;
+            ctx->spin_state_h[4 * par] = 0;
             ctx->stat_live_spin_lost += 1;
             ctx->spin_pending = -1;
         }
     }
+    // the next frame queued ahead (all seven packets; its first kernel waits on the device for the command word): mailbox and give-up mark cleared first
+    auto queue_ahead = [&](const bool with_pre, const bool beside) {
+        const int par = ctx->spin_next_par;
+        const int prog = (with_pre && ctx->aql_prog_spin_pre[par] >= 0) ? ctx->aql_prog_spin_pre[par] : ctx->aql_prog_spin[par];
+        ctx->spin_mb[32 * par] = 0u; ctx->spin_mb[32 * par + 16] = 0u;
+        _mm_sfence();
+        ctx->spin_state_h[4 * par] = 0;
+        if (rc_aql_submit_ahead(ctx->live_aql, prog, beside ? 1 : 0) == 0) {
+            ctx->spin_pending = prog; ctx->spin_pending_par = par; ctx->spin_pending_seq = rc_aql_seq(ctx->live_aql);
+            ctx->spin_next_par = par ^ 1; ctx->spin_valid = true;
+        }
+    };
     if (!(lean && ctx->live_aql) && ctx->live_aql) {
         // this frame runs on the HIP stream: a pre-step still in the HSA queue must not read the state while the frame rewrites it
         if (rc_aql_wait_background(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the pre-step did not complete");
@@ -1951,17 +1975,23 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         if (ctx->live_aql) {
             if (waited_eager) HIP_TRY(ctx, hipStreamSynchronize(st));        // the AQL queue is not ordered behind the stream: wait here
             int arc = 0;
-            if (spin_go) {
-                arc = rc_aql_wait_frame(ctx->live_aql);
-                ctx->spin_pending = -1;
-                if (arc == 0 && __atomic_load_n(ctx->spin_state_h, __ATOMIC_ACQUIRE) == 3u) {
-                    // the waiting kernel gave up in the very moment the frame arrived: the six kernels behind it have changed nothing
-                    // (LiveFrame.abort) -- the frame runs on the ordinary program
-                    *ctx->spin_state_h = 0;
-                    ctx->stat_live_spin_lost += 1;
-                    arc = rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean);
-                } else if (arc == 0) ctx->stat_live_spin += 1;
-            } else arc = rc_aql_run(ctx->live_aql, use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean);
+            const int plain = use_pre ? ctx->aql_prog_lean_pre : ctx->aql_prog_lean;
+            const int my_par = ctx->spin_pending_par;
+            unsigned long long my_seq = ctx->spin_pending_seq;
+            if (spin_go) ctx->spin_pending = -1;
+            else { arc = rc_aql_submit_ahead(ctx->live_aql, plain, 0); my_seq = rc_aql_seq(ctx->live_aql); }
+            // A back-to-back caller (no idle time in front of this call): the NEXT frame is queued now, its first kernel beside this frame's last ones --
+            // when the caller comes back that kernel has its arguments and weights and is polling. (A paced caller's is queued behind the pre-step, below.)
+            if (arc == 0 && ctx->live_spin_b2b && ctx->aql_prog_spin[0] >= 0 && ctx->spin_pending < 0 && idle_us < ctx->live_prestep_idle_us) queue_ahead(false, true);
+            if (arc == 0) arc = rc_aql_wait_seq(ctx->live_aql, my_seq);
+            if (spin_go && arc == 0 && __atomic_load_n(ctx->spin_state_h + 4 * my_par, __ATOMIC_ACQUIRE) == 3u) {
+                // the waiting kernel gave up in the very moment the frame arrived: the six kernels behind it have changed nothing
+                // (LiveFrame.abort) -- the frame runs on the ordinary program, in front of which nothing may be waiting
+                ctx->spin_state_h[4 * my_par] = 0;
+                ctx->stat_live_spin_lost += 1;
+                if (ctx->spin_pending >= 0) { ctx->spin_mb[32 * ctx->spin_pending_par] = 2u; _mm_sfence(); ctx->spin_pending = -1; ctx->stat_live_spin_lost += 1; }
+                arc = rc_aql_run(ctx->live_aql, plain);
+            } else if (spin_go && arc == 0) ctx->stat_live_spin += 1;
             if (arc != 0) {
                 // The frame did not retire in time (a tool on the queue, a wedged device): the chain is dropped -- its destructor waits
                 // for whatever is still in flight before the ring and the argument blocks go -- and the following frames replay the
@@ -1970,7 +2000,8 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
                 ctx->live_aql = nullptr;
                 ctx->live_aql_note = "an AQL frame did not complete: back on hipGraphLaunch";
                 ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
-                ctx->aql_prog_spin = ctx->aql_prog_spin_pre = -1; ctx->spin_pending = -1; ctx->spin_mb = nullptr; ctx->spin_in = nullptr;
+                for (int q = 0; q < 2; ++q) ctx->aql_prog_spin[q] = ctx->aql_prog_spin_pre[q] = -1;
+                ctx->spin_pending = -1; ctx->spin_mb = nullptr; ctx->spin_in = nullptr;
                 ctx->live_prev_known = false;
                 return fail(ctx, RC_ERR_HIP, "rc_live_step: the AQL frame did not complete (later frames use the graph replay)");
             }
@@ -2021,13 +2052,8 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (ctx->live_aql && ctx->aql_prog_pre >= 0 && idle_us >= ctx->live_prestep_idle_us) {
         if (rc_aql_submit(ctx->live_aql, ctx->aql_prog_pre) == 0) { ctx->live_pre_valid = true; ctx->stat_live_pre += 1; }
     }
-    if (ctx->live_aql && ctx->aql_prog_spin >= 0 && ctx->spin_pending < 0 && lean && idle_us < 50000.0 && (ctx->live_spin_always || idle_us >= ctx->live_prestep_idle_us)) {
-        // the next frame's first kernel, now (RC_LIVE_SPIN): command and decision words cleared first -- every workgroup of the launch reads them after this
-        const int prog = (ctx->live_pre_valid && ctx->aql_prog_spin_pre >= 0) ? ctx->aql_prog_spin_pre : ctx->aql_prog_spin;
-        ctx->spin_mb[0] = 0u; ctx->spin_mb[16] = 0u;
-        _mm_sfence();
-        *ctx->spin_state_h = 0;
-        if (rc_aql_submit_ahead(ctx->live_aql, prog) == 0) { ctx->spin_pending = prog; ctx->spin_valid = true; }
+    if (ctx->live_aql && ctx->aql_prog_spin[0] >= 0 && ctx->spin_pending < 0 && lean && idle_us < 50000.0 && (ctx->live_spin_always || idle_us >= ctx->live_prestep_idle_us)) {
+        queue_ahead(ctx->live_pre_valid, false);                            // (RC_LIVE_SPIN) behind this frame and its pre-step
     } else if (ctx->live_aql && ctx->live_arm && ctx->spin_pending < 0 && idle_us >= ctx->live_prestep_idle_us) (void)rc_aql_arm(ctx->live_aql);
     if (lean) {
         const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {

@@ -248,7 +248,7 @@ static void aql_release(AqlChain* c) {
 
 // body first, header (which hands the packet to the packet processor) last; the barrier bit of every packet orders it behind everything
 // in front of it in the ring -- a frame behind the pre-step that ran in the idle time, the pre-step behind the frame whose state it reads
-static void aql_push(AqlChain* c, const AqlProgram& P, int i0 = 0, int i1 = -1) {
+static void aql_push(AqlChain* c, const AqlProgram& P, int i0 = 0, int i1 = -1, const bool first_beside = false) {
     hsa_queue_t* q = c->q;
     if (i1 < 0) i1 = P.n;
     const uint32_t mask = q->size - 1;
@@ -256,7 +256,9 @@ static void aql_push(AqlChain* c, const AqlProgram& P, int i0 = 0, int i1 = -1) 
     for (int i = i0; i < i1; ++i) {
         hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + (i - i0)) & mask);
         std::memcpy((char*)p + 4, (const char*)&P.pkt[i] + 4, sizeof(*p) - 4);
-        __atomic_store_n((uint32_t*)p, (uint32_t)P.hdr[i] | ((uint32_t)P.pkt[i].setup << 16), __ATOMIC_RELEASE);
+        // (first_beside: the first packet without the barrier bit -- it may start beside what is still running in front of it)
+        const uint32_t hdr = (first_beside && i == i0) ? ((uint32_t)P.hdr[i] & ~(1u << HSA_PACKET_HEADER_BARRIER)) : (uint32_t)P.hdr[i];
+        __atomic_store_n((uint32_t*)p, hdr | ((uint32_t)P.pkt[i].setup << 16), __ATOMIC_RELEASE);
     }
     hsa_queue_store_write_index_release(q, base + (i1 - i0));
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(base + (i1 - i0) - 1));
@@ -297,20 +299,24 @@ int rc_aql_submit(AqlChain* c, int prog) {
 
 // ---- a frame program queued AHEAD of its frame: its first kernel (rc_live_k1) waits on the device for the mailbox, the six behind it for
 // the first; when the frame arrives the host only writes the inputs and the command word, then waits like for any frame
-int rc_aql_submit_ahead(AqlChain* c, int prog) {
+// beside != 0: the first kernel may start while the frame in front of it is still running (a back-to-back caller: it waits for ITS frame anyway,
+// and then it is already there) -- every other packet keeps its barrier bit, i.e. waits for everything in front of it including that kernel
+int rc_aql_submit_ahead(AqlChain* c, int prog, int beside) {
     if (!c || !c->q || prog < 0 || prog >= (int)c->prog.size() || !c->prog[prog].frame) return -1;
     if (c->dead) return -3;
-    aql_push(c, c->prog[prog]);
+    aql_push(c, c->prog[prog], 0, -1, beside != 0);
     c->seq += 1;
     return 0;
 }
+unsigned long long rc_aql_seq(const AqlChain* c) { return c ? c->seq : 0ull; }   // number of the frame submitted last
 
-static int aql_wait_frame(AqlChain* c);
-int rc_aql_wait_frame(AqlChain* c) {                                        // the frame submitted last (rc_aql_submit_ahead) has retired
+static int aql_wait_frame(AqlChain* c, unsigned long long seq);
+int rc_aql_wait_seq(AqlChain* c, unsigned long long seq) {                  // frame number `seq` has retired (frames retire in order; none behind it has STARTED yet)
     if (!c || !c->q) return -1;
     if (c->dead) return -3;
-    return aql_wait_frame(c);
+    return aql_wait_frame(c, seq);
 }
+int rc_aql_wait_frame(AqlChain* c) { return rc_aql_wait_seq(c, c ? c->seq : 0ull); }
 
 // everything in front of this packet has retired when the background signal has counted it (its barrier bit orders it)
 int rc_aql_fence_background(AqlChain* c) {
@@ -377,8 +383,7 @@ int rc_aql_wait_background(AqlChain* c) {
     return hsa_signal_wait_scacquire(c->bg_done, HSA_SIGNAL_CONDITION_LT, retired + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) <= retired ? 0 : -2;
 }
 
-static int aql_wait_frame(AqlChain* c) {
-    const unsigned long long seq = c->seq;
+static int aql_wait_frame(AqlChain* c, const unsigned long long seq) {
     const unsigned seq32 = (unsigned)seq;                                   // what K7 stores: its device counter wraps the same way
     const hsa_signal_value_t retired = (hsa_signal_value_t)(c->sig0 - (long long)seq);
     const auto t0 = std::chrono::steady_clock::now();
@@ -404,13 +409,13 @@ int rc_aql_run(AqlChain* c, int prog) {
     // `done` is never re-armed: every retired frame decrements it once (sig0 - seq when frame seq has retired)
     aql_push(c, c->prog[prog]);
     c->seq += 1;
-    return aql_wait_frame(c);
+    return aql_wait_frame(c, c->seq);
 }
 
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
     if (!c || !c->q) return;
-    if (c->mailbox) { c->mailbox[0] = 2u; _mm_sfence(); }                  // a K1 still spinning (rc_live.hip) leaves: nothing is queued behind it
+    if (c->mailbox) { c->mailbox[0] = 2u; c->mailbox[32] = 2u; _mm_sfence(); }                  // a K1 still spinning (rc_live.hip) leaves: nothing is queued behind it
     aql_release(c);
     if (c->mailbox && !c->dead) (void)rc_aql_fence_background(c);           // ... and the wait below covers it
     if (c->seq) (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);

@@ -218,7 +218,7 @@ struct LiveFrame {
     int* status;                    // pinned host word, set != 0 by K1 when the frame is not the lean plan's (a transition step or an init_net trigger:
                                     // the host's mirror of those flags is conservative, this is the check behind it); rc_live_step then replays the full capture
     int* abort;                     // device word K1 writes every frame (0 / 1): set, the frame's kernels change NOTHING (no state, no step counters, no outputs)
-    unsigned* spin_mb;              // spinning K1 (rc_live.hip, RC_LIVE_SPIN): mailbox in host-writable device memory -- [0] the host's command (0 none, 1 go,
+    unsigned* spin_mb;              // waiting K1 (rc_live.hip, RC_LIVE_SPIN): its mailbox (one of two, frames alternate) in host-writable device memory -- [0] the host's command (0 none, 1 go,
                                     // 2 skip), [16] the decision workgroup 0 publishes (1 go, 2 skip, 3 timed out); else null
     unsigned* spin_state;           // pinned host word: 3 when the spinning K1 gave up waiting
     LiveGrid* hot[4];               // AQL path: the LiveGrid argument blocks of K2, K3 (written by K1) and K5, K6 (by K4); else null
@@ -255,8 +255,11 @@ int rc_aql_add(AqlChain* c, const LiveKernel* k, int n, int frame, char* err, in
 int rc_aql_run(AqlChain* c, int prog);                                // frame program: submit, then spin until it retired; 0 = done
 int rc_aql_submit(AqlChain* c, int prog);                             // background program: submit and return
 int rc_aql_alloc_shared(AqlChain* c, size_t bytes, void** ptr);         // device memory the host can write (large BAR), freed with the chain; 0 = ok
-int rc_aql_submit_ahead(AqlChain* c, int prog);                         // a whole frame program queued ahead of its frame (its K1 waits on the mailbox)
-int rc_aql_wait_frame(AqlChain* c);                                     // spin until the frame submitted last has retired
+int rc_aql_submit_ahead(AqlChain* c, int prog, int beside);             // a whole frame program submitted without waiting (queued ahead: its K1 waits on the mailbox;
+                                                                        // beside: that K1 may start beside the frame in front of it)
+unsigned long long rc_aql_seq(const AqlChain* c);                       // number of the frame submitted last
+int rc_aql_wait_seq(AqlChain* c, unsigned long long seq);               // spin until frame `seq` has retired
+int rc_aql_wait_frame(AqlChain* c);                                     // ... the frame submitted last
 int rc_aql_fence_background(AqlChain* c);                               // a barrier packet that counts as a background program (rc_aql_wait_background)
 void rc_aql_set_mailbox(AqlChain* c, volatile unsigned* mb);            // the drain tells a K1 still spinning to leave
 int rc_aql_arm(AqlChain* c);                         // RC_LIVE_ARM: a barrier-AND packet the next push releases
