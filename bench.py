@@ -226,7 +226,8 @@ class Workload:
         if W > 0:
             self.run(0, W, True)
         torch.cuda.synchronize()
-        net.gemm_timing(2)
+        lds = net.launch_stats()[0] > 0          # this context's LSTM layer steps run on the shared-weight kernel: that is the dominant kernel
+        net.gemm_timing(3 if lds else 2)
         self.run(W, W + K, W == 0)
         torch.cuda.synchronize()
         ms, launches = net.gemm_timing_read()
@@ -234,7 +235,7 @@ class Workload:
         net.gemm_timing(0)
         if launches <= 0 or ms <= 0 or busy_ms <= 0:
             raise RuntimeError("no gate-GEMM launch was timed")
-        flop_per_launch = B * (C.FLOPS_PER_BODY_FRAME - C.FLOPS_LINEAR2_PER_BODY_FRAME) * K / launches
+        flop_per_launch = B * (C.FLOPS_LSTM_PER_BODY_FRAME if lds else C.FLOPS_PER_BODY_FRAME - C.FLOPS_LINEAR2_PER_BODY_FRAME) * K / launches
         avg_s = ms * 1e-3 / launches
         # The wavefront engine issues the two wide launches of a tick on two streams: they share the chip, so a launch's own
         # duration covers time in which the other one holds part of the CUs. The kernel's rate is its FLOPs over the time during
@@ -468,28 +469,6 @@ def main():
             else:
                 v["strong"] = sv
         if world == 1:
-            def one_launch_per_tick():
-                """The resident-workgroup form of a tick (rc_gemm_tick_kernel, RC_SEQ_TICK=1: built in round 5, bitwise equal, off by
-                default because it is slower -- DESIGN.md 3.1 "Round 5"): the main schedule at 512 frames per call, on this box."""
-                old = {k: os.environ.get(k) for k in ("RC_SEQ_TICK", "RC_TICK_GRID")}
-                os.environ.update({"RC_SEQ_TICK": "1", "RC_TICK_GRID": "224"})
-                try:
-                    w = Workload(sd, body, args.conf, B, W, LONG_FRAMES, 0, 1, 2, split_total)     # (the switches are read when the context is created)
-                finally:
-                    for k, v_ in old.items():
-                        if v_ is None:
-                            os.environ.pop(k, None)
-                        else:
-                            os.environ[k] = v_
-                dts_ = w.timed_reps(LONG_FRAMES, 3)
-                r = rate(dts_, LONG_FRAMES, bodies_total, "the main schedule, 512 frames per call, ONE launch per tick on 224 resident workgroups "
-                                                            "(rc_gemm_tick_kernel; the product runs two wide launches per tick)")
-                rf = w.roofline(LONG_FRAMES, dts_[len(dts_) // 2], bodies_total)
-                r.update({k: rf[k] for k in ("kernel", "launches_per_step", "avg_launch_us", "frac")})
-                r["tick_launches"], r["other_wide_launches"] = w.net.launch_stats()
-                return r
-            v["one_launch_per_tick"] = guarded(one_launch_per_tick)
-
             def occ():
                 w = Workload(sd, body, "occ", 1024, 8, 64, 0, 1)
                 return rate(w.timed_reps(64, 3), 64, 1024, "BASELINE config 4: batch 1024, occlusion-masked keypoints (runs of "

@@ -149,12 +149,11 @@ int rc_default_gemm_mode(int32_t total_rows);   /* the default of a context of t
  * (ints) is too small. */
 int rc_set_sequence_mode(rc_ctx* ctx, int32_t mode, int32_t min_frames);
 int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_frames, int64_t* ticks);
-/* Round 5: a tick of the wavefront engine whose wide problems all run 64 x 128 split-product tiles is ONE launch of resident
- * workgroups (rc_gemm_tick_kernel: tiles pulled from per-XCD queues, the next tile's operands requested behind the current tile's
- * last MFMA, the problem table read from device memory); other ticks keep the two wide launches. Launch counts since rc_create:
- * tick launches, and launches of the other wide / mid-tile kernels (either may be NULL). Replaces nothing in the reference: its
- * per-frame loop (net/sig_mp.py:126-129) has no launch structure to mirror; this is introspection for bench.py and the tests. */
-int rc_get_launch_stats(rc_ctx* ctx, int64_t* tick_launches, int64_t* other_wide_launches);
+/* Launch counts since rc_create: launches of the shared-weight kernel of the LSTM layer steps (rc_gemm_lds_kernel, round 6: contexts of
+ * >= RC_LDS_MIN_ROWS rows in split-product mode), and launches of the other wide / mid-tile kernels (either may be NULL). Replaces
+ * nothing in the reference: its per-frame loop (net/sig_mp.py:126-129) has no launch structure to mirror; this is introspection for
+ * bench.py and the tests. (Round 5 counted its one-launch-per-tick kernel in the first slot; removed, profiles/r06_tick_path_removed.diff.) */
+int rc_get_launch_stats(rc_ctx* ctx, int64_t* lds_launches, int64_t* other_wide_launches);
 int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* pend, uint32_t flags, int32_t use_vision_updater,
                      uint8_t* mode_out);
 int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const int32_t* first_reach, const int32_t* pend,

@@ -63,3 +63,6 @@ def state_dict_spec():
             for i, (a, b) in zip((0, 2, 4), INIT_NET):
                 spec += [(f"{name}.init_net.{i}.weight", (b, a)), (f"{name}.init_net.{i}.bias", (b,))]
     return spec
+
+# the twelve LSTM layer steps alone (2 layers x [B, 2H] x [2H, 4H] per sub-net): what rc_gemm_lds_kernel computes
+FLOPS_LSTM_PER_BODY_FRAME = 2 * sum(2 * (2 * H) * (4 * H) for H in (512, 512, 1280, 1024, 512, 512))

@@ -160,7 +160,7 @@ struct rc_ctx {
     long long live_prof_n = 0;
     // timing of the gate GEMM launches
     bool timing = false;
-    int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernel (rc_gemm_kernel)
+    int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernels, 3: only the shared-weight kernel (rc_gemm_lds_kernel)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     double timed_ms = 0.0;
@@ -179,6 +179,8 @@ struct rc_ctx {
     hipStream_t aux_stream = nullptr;    // per-row kernels of a tick run beside the tick's GEMM launch
     hipStream_t h512_stream = nullptr;   // the tick's {H = 512 nets, linear1} launch, beside the {rnn6, rnn4} launch on the caller's stream
     hipEvent_t ev_main[8] = {}, ev_aux[8] = {}, ev_h512[4] = {};
+    hipStream_t lin1_stream = nullptr;   // round 6 (regrouped ticks): the tick's {linear1, init_net} launch on a stream of its own
+    hipEvent_t ev_lin1[4] = {}, ev_h5[4] = {};
     float* x1_alt2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // third relu(linear1) buffer per net (h512_stream runs a tick ahead)
     signed char* scan_codes_d = nullptr; // [cap] regime code per (frame, row)
     signed char* scan_codes_h = nullptr; // pinned
@@ -197,15 +199,15 @@ struct rc_ctx {
                                                          // per-layer tick estimate, hand-over per tick, frame-stepped frame, its transition launches
     SmplifyState* smplify = nullptr;     // optimiser work space (rc_smplify_api.cpp)
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
-    // one launch per tick (rc_gemm_tick_kernel): problem tables of a planned call and the per-tick queue counters
-    int seq_tick = 0;                    // RC_SEQ_TICK: 1 = one launch per tick on resident workgroups (built and measured in round 5: 9-13 % slower
-                                         // than the two wide launches per tick, profiles/r05_tick_notes.txt; off by default)
-    int tick_grid = 248;                 // RC_TICK_GRID: resident workgroups of a tick launch (the rest of the 256 CUs serve the per-row kernels)
-    TickTable* tick_tab_d = nullptr;     // [tick_cap]
-    TickTable* tick_tab_h = nullptr;     // pinned
-    int* tick_queue_d = nullptr;         // [tick_cap][8 queues][16 ints]
-    size_t tick_cap = 0;
-    long long stat_tick_launches = 0, stat_wide_launches = 0;
+    long long stat_wide_launches = 0;    // launches of the wide-tile kernels (rc_get_launch_stats)
+    // shared-weight gate GEMM (rc_gemm_lds.hip): LSTM layer steps of >= lds_min_rows rows in split-product mode
+    int lds_min_rows = 160;              // RC_LDS_MIN_ROWS (0 = never): below, a 256-row tile is mostly padding and the 64-row tiles win
+    int lds_ksplit[3] = {2, 2, 2};       // RC_LDS_KSPLIT_512 / _1024 / _1280: workgroups per tile (1: both K halves in one workgroup)
+    float* lds_slab = nullptr;           // [kLdsRegions][lds_region_tiles][RC_LDS_SLAB_FLOATS]: half sums in flight, one region per launch
+    int* lds_tickets = nullptr;          // [kLdsRegions][lds_region_tiles]
+    size_t lds_region_tiles = 0;
+    unsigned lds_rot = 0;
+    long long stat_lds_launches = 0;
 };
 
 namespace {
@@ -428,6 +430,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
         if (s.net == N4 && c->tile4[0]) { mr = c->tile4[0]; nc = c->tile4[1]; }
     }
     const int rows = s.rows_hint < 0 ? c->B : (s.rows_hint < c->B ? s.rows_hint : c->B);
+    if (c->gemm_split && c->lds_min_rows > 0 && rows >= c->lds_min_rows) { mr = 16; nc = 8; }   // the shared-weight kernel (rc_gemm_lds.hip)
     p.n_tiles = n.H / (4 * nc); p.m_tiles = (rows + 16 * mr - 1) / (16 * mr); p.Kp = 2 * n.H; p.nc = nc; p.mr = mr;
     p.nt = (c->live_nt_mask >> s.net) & 1u;
     return p;
@@ -442,12 +445,103 @@ GemmProblem lin2_problem(const rc_ctx* c, const Stage& s) {
     return p;
 }
 
+const int kLdsRegions = 12;               // launches whose half sums can be in flight at once (three streams, a tick ahead: <= 6)
+
+// slabs + tickets of the shared-weight kernel: allocated on first use, sized for the widest launch of this context
+int ensure_lds_pool(rc_ctx* ctx) {
+    if (ctx->lds_slab) return RC_OK;
+    const size_t m_tiles = ((size_t)ctx->B + 255) / 256;
+    const size_t tiles = 272 * m_tiles;    // all twelve layer steps in one launch: 2 x (40 + 32 + 4 x 16) column tiles per row tile
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->lds_slab, (size_t)kLdsRegions * tiles * RC_LDS_SLAB_FLOATS * sizeof(float)));
+    ctx->allocs.push_back(ctx->lds_slab);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->lds_tickets, (size_t)kLdsRegions * tiles * sizeof(int)));
+    ctx->allocs.push_back(ctx->lds_tickets);
+    HIP_TRY(ctx, hipMemset(ctx->lds_tickets, 0, (size_t)kLdsRegions * tiles * sizeof(int)));   // (the kernel leaves every ticket at zero)
+    ctx->lds_region_tiles = tiles;
+    return RC_OK;
+}
+
+bool timing_pair(rc_ctx* ctx, hipEvent_t** a, hipEvent_t** b) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        ctx->ev_pool.emplace_back(x, y);
+    }
+    auto& ev = ctx->ev_pool[ctx->ev_used++];
+    *a = &ev.first; *b = &ev.second;
+    return true;
+}
+
+// LSTM layer steps on the shared-weight kernel (rc_gemm_lds.hip): problems marked mr = 16
+int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, hipStream_t st, hipEvent_t stop, bool* launched) {
+    if (int rc = ensure_lds_pool(ctx)) return rc;
+    LdsLaunch L{};
+    L.B = ctx->B; L.n = (int)ps.size();
+    const size_t region = ctx->lds_rot++ % kLdsRegions;
+    float* slab = ctx->lds_slab + region * ctx->lds_region_tiles * RC_LDS_SLAB_FLOATS;
+    int* tickets = ctx->lds_tickets + region * ctx->lds_region_tiles;
+    // longest items first (K' = 2560 rnn4, 2048 rnn6, 1024 the H = 512 nets): the launch ends on short ones
+    std::vector<GemmProblem> ord(ps);
+    std::stable_sort(ord.begin(), ord.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.Kp > b.Kp; });
+    int base = 0;
+    size_t tiles = 0;
+    for (size_t i = 0; i < ord.size(); ++i) {
+        const GemmProblem& g = ord[i];
+        LdsProblem& p = L.p[i];
+        p.seg[0] = g.seg[0]; p.seg[1] = g.seg[1];
+        p.Ws = g.Ws; p.bias = g.bias; p.hstate = g.hstate; p.cstate = g.cstate; p.steps = g.steps;
+        p.flags = flags_override ? flags_override : g.flags; p.flag_bit = g.flag_bit;
+        p.h_par_stride = g.h_par_stride; p.H = g.H; p.step_off = g.step_off;
+        p.n_tiles = g.H / 32; p.m_tiles = g.m_tiles; p.Qs = g.Kp / 32;
+        p.ksplit = ctx->lds_ksplit[g.H == 512 ? 0 : (g.H == 1024 ? 1 : 2)];
+        p.wg_base = base;
+        p.slab = slab + tiles * RC_LDS_SLAB_FLOATS; p.tickets = tickets + tiles;
+        tiles += (size_t)p.n_tiles * p.m_tiles;
+        base += round_up(p.n_tiles * p.m_tiles * p.ksplit, 8);
+    }
+    if (tiles > ctx->lds_region_tiles) return fail(ctx, RC_ERR_INVALID, "shared-weight launch: more tiles than its slab region holds");
+    ctx->stat_lds_launches += 1;
+    if (ctx->timing) {
+        hipEvent_t *a, *b;
+        if (!timing_pair(ctx, &a, &b)) return fail(ctx, RC_ERR_HIP, "hipEventCreate");
+        HIP_TRY(ctx, hipEventRecord(*a, st));
+        rc_launch_gemm_lds(L, base, st);
+        HIP_TRY(ctx, hipEventRecord(*b, st));
+    } else {
+        rc_launch_gemm_lds(L, base, st, stop);
+        if (launched && stop) *launched = true;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return RC_OK;
+}
+
 // stop: event to be signalled by this launch's completion (used only when the launch is not being timed); *launched tells the
 // caller whether a kernel went out at all
 int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st, bool fp32 = false,
                     hipEvent_t stop = nullptr, bool* launched = nullptr) {
     if (launched) *launched = false;
     if (ps.empty()) return RC_OK;
+    // LSTM layer steps marked for the shared-weight kernel (mr = 16) leave in a launch of their own behind the rest (everything
+    // handed to one call is independent of everything else in it); outside split-product mode they take the 64 x 128 tile instead
+    {
+        std::vector<GemmProblem> lds, rest;
+        for (GemmProblem& p : ps) {
+            if (p.mr == 16) {
+                if (ctx->gemm_split && !fp32 && p.epi == RC_EPI_LSTM && (int)lds.size() < RC_LDS_MAXP) { lds.push_back(p); continue; }
+                p.mr = 4; p.nc = 8; p.m_tiles *= 4;
+            }
+            rest.push_back(p);
+        }
+        if (!lds.empty()) {
+            if (!rest.empty()) if (int rc = launch_problems(ctx, rest, flags_override, st, fp32)) return rc;
+            return launch_lds(ctx, lds, flags_override, st, stop, launched);
+        }
+    }
+    if ((int)ps.size() > RC_MAX_PROB) {        // (a regrouped tick of a mixed batch: linear1 + init_net + the few-row layer steps) two launches
+        std::vector<GemmProblem> head(ps.begin(), ps.begin() + RC_MAX_PROB), tail(ps.begin() + RC_MAX_PROB, ps.end());
+        if (int rc = launch_problems(ctx, head, flags_override, st, fp32)) return rc;
+        return launch_problems(ctx, tail, flags_override, st, fp32, stop, launched);
+    }
     GemmLaunch L{};
     L.B = ctx->B;
     L.split = (ctx->gemm_split && !fp32) ? 1 : 0;
@@ -468,17 +562,12 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     L.n = (int)ordered.size();
     ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
     if (!rc_gemm_is_small(L)) ctx->stat_wide_launches += 1;
-    if (ctx->timing && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
-        if (ctx->ev_used == ctx->ev_pool.size()) {
-            hipEvent_t a, b;
-            HIP_TRY(ctx, hipEventCreate(&a));
-            HIP_TRY(ctx, hipEventCreate(&b));
-            ctx->ev_pool.emplace_back(a, b);
-        }
-        auto& ev = ctx->ev_pool[ctx->ev_used++];
-        HIP_TRY(ctx, hipEventRecord(ev.first, st));
+    if (ctx->timing && ctx->timing_mode != 3 && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
+        hipEvent_t *a, *b;
+        if (!timing_pair(ctx, &a, &b)) return fail(ctx, RC_ERR_HIP, "hipEventCreate");
+        HIP_TRY(ctx, hipEventRecord(*a, st));
         rc_launch_gemm(L, base, st);
-        HIP_TRY(ctx, hipEventRecord(ev.second, st));
+        HIP_TRY(ctx, hipEventRecord(*b, st));
     } else {
         rc_launch_gemm(L, base, st, stop);
         if (launched && stop) *launched = true;
@@ -750,7 +839,16 @@ static int ensure_wave2_buffers_once(rc_ctx* ctx) {
         if (int rc = dev_alloc(ctx, &ctx->x1_alt[i], Bp * ctx->net[i].H)) return rc;
         if (int rc = dev_alloc(ctx, &ctx->x1_alt2[i], Bp * ctx->net[i].H)) return rc;
     }
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->h512_stream, hipStreamNonBlocking));
+    {
+        // RC_SEQ_H512_PRIO: queue priority of the third stream (-1 lowest, +1 highest, 0 default). With the shared-weight kernel the caller's
+        // stream carries the longest items of a tick (rnn4: the chain h(t) -> h(t + 1) is one item long); the third stream's are the filler.
+        const int want = tune_env("RC_SEQ_H512_PRIO", 0);
+        int lo = 0, hi = 0;
+        if (want != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->h512_stream, hipStreamNonBlocking, want < 0 ? lo : hi));
+        else
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->h512_stream, hipStreamNonBlocking));
+    }
     {
         // RC_SEQ_AUX_PRIO: -1 lowest / +1 highest queue priority for the second stream (0: default) -- its short kernels share the
         // CUs with the wide tiles of the caller's stream
@@ -761,12 +859,15 @@ static int ensure_wave2_buffers_once(rc_ctx* ctx) {
         else
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     }
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lin1_stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) {
         // device-scope release: the hand-over is between two streams of this GPU
         const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_main[i], evf));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_aux[i], evf));
         if (i < 4) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h512[i], evf));
+        if (i < 4) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_lin1[i], evf));
+        if (i < 4) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h5[i], evf));
     }
     ctx->ring2_ready = true;
     ctx->wave2_valid = false;
@@ -830,13 +931,17 @@ inline int w2_stage(int q) { return q < RC_TICK_PROB ? kTick[q].stage : kInitSta
 // merge_big: rnn6's and rnn4's layer steps share one launch as well (rnn6's longer tiles first): two launches per tick.
 // Measured on one box (mixed 512 frames, body-frames/s): 4 launches 1.005 M, H = 512 merged 1.037 M, both merged 1.066 M;
 // 20-frame calls 0.890 -> 0.913 M (every launch boundary of a tick is a drain + ramp of all 256 CUs)
-inline int w2_group(int q, bool merge_h512, bool merge_big) {
+// regroup (round 6, two-stream ticks): rnn6's two layer steps and the init_net layers ride the {H = 512 nets, linear1} stream, the caller's
+// stream keeps rnn4 alone. With the shared-weight kernel (rc_gemm_lds.hip) the items of a tick are 160 of 40 k-blocks (rnn4, K halved),
+// 128 of 32 (rnn6, K halved) and 128 of 32 (the H = 512 nets): {rnn4} is one round of the CUs on one stream, {rnn6, H = 512} one round
+// of equal items on the other, instead of 288 items (two rounds) behind the init_net launch on the caller's stream and a short launch
+// on the other (profiles/r06_timeline_lds_v1.txt). Race-free on the stream model: tests/test_wave_streams.py.
+inline int w2_group(int q, bool merge_h512, bool merge_big, bool regroup = false) {
+    if (regroup && merge_h512 && (q >= RC_TICK_PROB || (kTick[q].net == N6 && (kTick[q].kind == 1 || kTick[q].kind == 2)))) return 2;
     int g = q >= RC_TICK_PROB ? (merge_h512 ? 1 : 2) : ((merge_h512 && kTick[q].group == 3) ? 2 : kTick[q].group);
     if (merge_big && g == 1) g = 0;
     return g;
 }
-
-int reserve_tick_tables(rc_ctx* ctx, size_t n_ticks);
 
 int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0, int t_last, hipStream_t st) {
     if (int rc = ensure_wave2_buffers(ctx)) return rc;
@@ -876,20 +981,21 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // calls 862k -> 917k, fp32 MFMA 662k -> 725k, batch 1024 970k -> 1,012k, 128: 613k -> 631k, 64: 398k -> 418k; batch 32: 329k ->
     // 299k, 16: 214k -> 178k (a tick there is launch latency, and a third stream adds two hand-overs to it): from 48 rows.
     static const int split_main_env = tune_env("RC_SEQ_SPLIT_MAIN", -1);      // 0 / 1 force, default: by batch
-    // Round 5, one launch per tick: every wide problem of a tick (all of them 64 x 128 split-product tiles in the steady state) in ONE
-    // launch of resident workgroups that pull tiles from per-XCD queues and request the next tile's operands behind the current
-    // tile's last MFMA (rc_gemm.hip: rc_gemm_tick_kernel). The launch reads its problem table from device memory: the tables of all
-    // ticks of the call are built here, before the first tick, and uploaded in one copy. Ticks with another tile shape in them (few
-    // rows: transition / init_net problems, lagging rows only) or with fewer tiles than CUs take the launches below.
-    const bool tick_mode = ctx->seq_tick && ctx->gemm_split && two && merge_h512 && merge_big && !merge_fill && ext_events &&
-                           B <= 256 * RC_TICK_CH;
-    const bool split_main = !tick_mode && (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 &&
+    const bool split_main = (split_main_env < 0 ? B >= RC_SPLIT_MAIN_MIN_BATCH : split_main_env != 0) && two && merge_h512 &&
                             merge_big && !merge_fill && ext_events;
-    hipStream_t s2 = ctx->h512_stream;
+    hipStream_t s2 = ctx->h512_stream, s4 = ctx->lin1_stream;
+    static const int regroup_env = tune_env("RC_SEQ_REGROUP", 1);
+    static const int lin1_env = tune_env("RC_SEQ_LIN1_STREAM", 1);
+    const bool regroup = split_main && regroup_env != 0 && ctx->gemm_split && ctx->lds_min_rows > 0 && B >= ctx->lds_min_rows;   // (with the shared-weight kernel only)
+    const bool lin1_own = regroup && lin1_env != 0;
+    // tri: THREE streams of layer steps -- rnn4 | rnn6 | the H = 512 nets -- and {linear1, init_net} at the head of the second stream's
+    // tick. Each net's chain h(t) -> h(t + 1) then follows its own predecessor only; the drain of one launch is filled by the other two.
+    static const int tri_env = tune_env("RC_SEQ_TRI", 1);
+    const bool tri = lin1_own && tri_env != 0;
     // 64-row tile shapes of the wide launches. With both launches of a tick on one stream rnn4 ran best on 64 x 80 tiles (256 tiles
     // per layer = whole rounds of the 256 CUs); on two streams the other launch fills what a round leaves idle and the 64 x 128 tile's
     // 13 % fewer operand bytes per MFMA win: mixed 512 frames 1,030k -> 1,120k, all-visible 1,208k -> 1,258k, batch 1024 999k -> 1,088k
-    int t4[2] = {4, (split_main || tick_mode) ? 8 : 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
+    int t4[2] = {4, split_main ? 8 : 5}, t6[2] = {4, 8}, t5[2] = {4, 8};
     tile_env("RC_SEQ_RNN4", &t4[0], &t4[1]);
     tile_env("RC_SEQ_RNN6", &t6[0], &t6[1]);
     tile_env("RC_SEQ_H512", &t5[0], &t5[1]);
@@ -901,7 +1007,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         std::vector<GemmProblem> ps;
         for (int qi = 0; qi < W2_PROB; ++qi) {
             const int q = (merge_big && qi < 4) ? (qi ^ 2) : qi;               // rnn6 (kTick 2, 3) in front of rnn4 (0, 1): longest tiles first
-            if (w2_group(q, merge_h512, merge_big) != g) continue;
+            if (w2_group(q, merge_h512, merge_big, regroup) != g) continue;
             const int e = k - w2_stage(q);
             if (e < 0 || e >= P.n_prep) continue;
             const int net = q < RC_TICK_PROB ? kTick[q].net : -1;
@@ -917,7 +1023,9 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (kind == 1 || kind == 2) {
                 const NetDev& n = ctx->net[net];
                 int mr, nc;
-                if (ctx->gemm_split && rows >= tile64_rows) {                  // (split products: the K loop is operand-bound, 64-row tiles)
+                if (ctx->gemm_split && ctx->lds_min_rows > 0 && rows >= ctx->lds_min_rows) {   // the shared-weight kernel (rc_gemm_lds.hip)
+                    mr = 16; nc = 8;
+                } else if (ctx->gemm_split && rows >= tile64_rows) {           // (split products: the K loop is operand-bound, 64-row tiles)
                     const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
                     mr = t[0]; nc = t[1];
                 } else {
@@ -956,69 +1064,6 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     auto group = [&](int k, int g, hipStream_t s, hipEvent_t stop = nullptr, bool* launched = nullptr) -> int {
         return launch_problems(ctx, collect(k, g), nullptr, s, g == 5, stop, launched);   // linear2 on the fp32-input kernel, as in run_stage
     };
-    std::vector<unsigned char> tick_ok((size_t)P.n_ticks, 0);
-    std::vector<std::vector<GemmProblem>> tick_rest((size_t)(tick_mode ? P.n_ticks : 0));
-    if (tick_mode) {
-        static const int min_tiles = tune_env("RC_TICK_MIN_TILES", 129);          // fewer: a tile per CU at most, nothing to hand over
-        static const int max_tiles = tune_env("RC_TICK_MAX_TILES", 1 << 30);      // (A/B: one launch only for the filling / draining ticks)
-        if ((size_t)P.n_ticks > ctx->tick_cap) {
-            HIP_TRY(ctx, hipDeviceSynchronize());                                  // nothing in flight may still read the old tables
-            if (int rc = reserve_tick_tables(ctx, (size_t)P.n_ticks)) return rc;
-        }
-        bool any = false;
-        for (int k = 0; k < P.n_ticks; ++k) {
-            std::vector<GemmProblem> all;
-            for (int g = 0; g <= last_group; ++g) {
-                std::vector<GemmProblem> v = collect(k, g, false);
-                all.insert(all.end(), v.begin(), v.end());
-            }
-            // problems of another shape (few rows: init_net layers, a slot that only carries lagging rows) go out in front of the tick
-            // launch on the kernels they always ran on; everything in a tick is independent of everything else in it
-            std::vector<GemmProblem> rest;
-            long long tiles = 0;
-            {
-                std::vector<GemmProblem> keep;
-                for (const GemmProblem& p : all) {
-                    const bool relu4 = p.epi == RC_EPI_RELU && p.out_packed && p.out_bit == 0 && ((p.out_col0 | p.N) & 3) == 0;
-                    if (p.mr == 4 && p.nc == 8 && (p.epi == RC_EPI_LSTM || relu4) && p.open_step == 0 && p.Kp % 128 == 0) {
-                        keep.push_back(p);
-                        tiles += (long long)p.n_tiles * p.m_tiles;
-                    } else rest.push_back(p);
-                }
-                all.swap(keep);
-            }
-            const bool ok = !all.empty() && (int)all.size() <= RC_TICK_MAXP && (int)rest.size() <= RC_MAX_PROB;
-            if (!ok || tiles < min_tiles || tiles > max_tiles) continue;
-            tick_rest[(size_t)k] = std::move(rest);
-            // longest tiles first (K' = 2560 rnn4, 2048 rnn6, 1024 the H = 512 nets, 128 / 256 linear1): the queues end on short tiles
-            std::stable_sort(all.begin(), all.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.Kp > b.Kp; });
-            TickTable& T = ctx->tick_tab_h[k];
-            T.n_prob = (int)all.size();
-            T.trace_base = ctx->trace_next;
-            T.pad_ = 0;
-            int base = 0;
-            for (int q = 0; q < RC_TICK_MAXP + 4; ++q) T.item_base[q] = 0x7fffffff;
-            for (size_t q = 0; q < all.size(); ++q) {
-                GemmProblem p = all[q];
-                p.wg_base = base;
-                // (the kernel requests flag / select / step words of every problem, used or not: a valid array behind each)
-                if (!p.flags) { p.flags = ctx->ring2[0].flags2; p.flag_bit = 0; }
-                if (!p.sel_flags) { p.sel_flags = ctx->ring2[0].flags2; p.sel_bit = 0; }
-                if (!p.steps) p.steps = ctx->net[0].steps;
-                T.item_base[q] = base;
-                T.p[q] = p;
-                base += round_up(p.n_tiles * p.m_tiles, 8);
-            }
-            T.n_items = base;
-            ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
-            tick_ok[k] = 1;
-            any = true;
-        }
-        if (any) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->tick_tab_d, ctx->tick_tab_h, (size_t)P.n_ticks * sizeof(TickTable), hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->tick_queue_d, 0, (size_t)P.n_ticks * 128 * sizeof(int), st));
-        }
-    }
     WavePrep wp{};
     for (int i = 0; i < 6; ++i) wp.steps[i] = ctx->net[i].steps;
     wp.cx4l = ctx->fb.x4l; wp.cx6l = ctx->fb.x6l;
@@ -1029,11 +1074,23 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     HIP_TRY(ctx, hipEventRecord(ctx->ev_main[7], st));                    // the second stream joins (also: the table upload)
     if (two) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
     if (split_main) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_main[7], 0));
+    if (lin1_own) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_main[7], 0));
     for (int k = 0; k < P.n_ticks; ++k) {
         const int e = k & 3, ep = (k + 3) & 3;
+        std::vector<GemmProblem> tri_l1, tri_ls6, tri_ls5;
+        if (tri) {
+            // {linear1, init_net} of tick k read what the second stream wrote in tick k - 1 and nothing else: at the head of this tick's
+            // second-stream work, in front of its waits for the layer steps of tick k - 1
+            for (const GemmProblem& p : collect(k, last_group)) (p.epi != RC_EPI_LSTM ? tri_l1 : (p.H == 1024 ? tri_ls6 : tri_ls5)).push_back(p);
+            bool sigl = false;
+            if (int rc = launch_problems(ctx, tri_l1, nullptr, aux, false, ctx->ev_lin1[e], &sigl)) return rc;
+            if (!sigl) HIP_TRY(ctx, hipEventRecord(ctx->ev_lin1[e], aux));
+        }
         // ---- per-row kernels and linear2 of tick k (second stream: after the previous tick's wide launches)
+        if (tri && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_h5[ep], 0));
         if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
         if (split_main && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_h512[ep], 0));
+        if (lin1_own && !tri && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_lin1[ep], 0));   // (init_net's last layer -> the tail)
         if (k < P.n_prep) {
             wp.frame_at = ctx->frame_at_d + (size_t)k * B;
             wp.first_tick = k == 0 ? 1 : 0;
@@ -1060,36 +1117,52 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         std::vector<GemmProblem> gp[4];
         size_t n_prob = 0;
         long long n_tiles = 0;
-        for (int g = 0; g <= last_group && !tick_ok[k]; ++g) {
+        for (int g = 0; g <= last_group; ++g) {
             gp[g] = collect(k, g);
             n_prob += gp[g].size();
             for (const GemmProblem& p : gp[g]) n_tiles += (long long)p.n_tiles * p.m_tiles;
         }
         bool main_signalled = false;
         hipEvent_t stop_ev = (two && ext_events) ? ctx->ev_main[e] : nullptr;
-        if (tick_ok[k]) {
-            // ONE launch: linear1 (and nothing else of it) reads what the second stream wrote in tick k - 1
-            if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
-            if (!tick_rest[(size_t)k].empty()) if (int rc = launch_problems(ctx, tick_rest[(size_t)k], nullptr, st, false)) return rc;
-            const TickTable* tab = ctx->tick_tab_d + k;
-            int* queue = ctx->tick_queue_d + (size_t)k * 128;
-            if (ctx->timing) {
-                if (ctx->ev_used == ctx->ev_pool.size()) {
-                    hipEvent_t a, b;
-                    HIP_TRY(ctx, hipEventCreate(&a));
-                    HIP_TRY(ctx, hipEventCreate(&b));
-                    ctx->ev_pool.emplace_back(a, b);
+        if (tri) {
+            bool sig6 = false, sig5 = false, sig0 = false;
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_lin1[ep], 0));
+            if (int rc = launch_problems(ctx, tri_ls6, nullptr, s2, false, ctx->ev_h512[e], &sig6)) return rc;
+            if (!sig6) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s2));
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_aux[ep], 0));      // (rnn2 l0 behind the tail's init_net state write; linear1(k - 1) sits in front of it)
+            if (int rc = launch_problems(ctx, tri_ls5, nullptr, s4, false, ctx->ev_h5[e], &sig5)) return rc;
+            if (!sig5) HIP_TRY(ctx, hipEventRecord(ctx->ev_h5[e], s4));
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lin1[ep], 0));
+            for (int g = 0; g < last_group; ++g)
+                if (!gp[g].empty()) {
+                    bool sig = false;
+                    if (int rc = launch_problems(ctx, gp[g], nullptr, st, false, sig0 ? nullptr : ctx->ev_main[e], &sig)) return rc;
+                    sig0 = sig0 || sig;
                 }
-                auto& ev = ctx->ev_pool[ctx->ev_used++];
-                HIP_TRY(ctx, hipEventRecord(ev.first, st));
-                rc_launch_gemm_tick(tab, queue, B, ctx->tick_grid, st);
-                HIP_TRY(ctx, hipEventRecord(ev.second, st));
-            } else {
-                rc_launch_gemm_tick(tab, queue, B, ctx->tick_grid, st, stop_ev);
-                main_signalled = stop_ev != nullptr;
-            }
-            HIP_TRY(ctx, hipGetLastError());
-            ctx->stat_tick_launches += 1;
+            main_signalled = sig0;
+        } else if (lin1_own) {
+            // Regrouped tick with {linear1, init_net} on a stream of its own: linear1(k) needs only the second stream's work of tick k - 1,
+            // so it runs beside the previous tick's layer steps instead of behind them, and neither wide launch waits for the other's
+            // END any more -- {rnn4} on the caller's stream follows its predecessor as soon as linear1(k - 1) is done (the chain
+            // h(t) -> h(t + 1) of rnn4 runs back to back), {rnn6, H = 512} likewise behind the second stream's previous tick.
+            std::vector<GemmProblem> l1, ls;
+            for (const GemmProblem& p : gp[last_group]) (p.epi == RC_EPI_LSTM ? ls : l1).push_back(p);
+            bool sigl = false, sig2 = false, sig0 = false;
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_aux[ep], 0));
+            if (int rc = launch_problems(ctx, l1, nullptr, s4, false, ctx->ev_lin1[e], &sigl)) return rc;
+            if (!sigl) HIP_TRY(ctx, hipEventRecord(ctx->ev_lin1[e], s4));
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_aux[ep], 0));      // (rnn2 l0 behind the tail's init_net state write)
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_lin1[ep], 0));
+            if (int rc = launch_problems(ctx, ls, nullptr, s2, false, ctx->ev_h512[e], &sig2)) return rc;
+            if (!sig2) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s2));
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lin1[ep], 0));
+            for (int g = 0; g < last_group; ++g)
+                if (!gp[g].empty()) {
+                    bool sig = false;
+                    if (int rc = launch_problems(ctx, gp[g], nullptr, st, false, sig0 ? nullptr : ctx->ev_main[e], &sig)) return rc;
+                    sig0 = sig0 || sig;
+                }
+            main_signalled = sig0;
         } else if (split_main) {
             // {H = 512 nets, linear1} (reads what the second stream wrote in tick k - 1) on its own stream ...
             bool sig2 = false, sig0 = false;
@@ -1098,7 +1171,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (!sig2) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s2));
             // ... {rnn6, rnn4 (+ init_net)} behind the previous tick's linear1 (init_net also reads the previous tick's fuse)
             if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h512[ep], 0));
-            if (k > 0 && init_now) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
+            if (k > 0 && init_now && !regroup) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[ep], 0));
             for (int g = 0; g < last_group; ++g)
                 if (!gp[g].empty()) {
                     bool sig = false;
@@ -1126,6 +1199,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     }
     if (two && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[(P.n_ticks - 1) & 3], 0));
     if (split_main && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h512[(P.n_ticks - 1) & 3], 0));
+    if (lin1_own && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lin1[(P.n_ticks - 1) & 3], 0));
+    if (tri && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h5[(P.n_ticks - 1) & 3], 0));
     HIP_TRY(ctx, hipGetLastError());
     ctx->stat_wave_frames += t_last - t0 + 1;
     return RC_OK;
@@ -1191,25 +1266,10 @@ int reserve_plan_tables(rc_ctx* ctx, int T) {
         HIP_TRY(ctx, hipHostMalloc((void**)&ctx->frame_at_h, fneed * sizeof(int), hipHostMallocDefault));
         ctx->frame_at_cap = fneed;
     }
-    if (ctx->seq_tick) if (int rc = reserve_tick_tables(ctx, (size_t)T + 64)) return rc;
     return RC_OK;
 }
 
 // tables of the one-launch-per-tick path for a call of n_ticks ticks (grow-only; the caller makes sure nothing in flight reads them)
-int reserve_tick_tables(rc_ctx* ctx, size_t n_ticks) {
-    if (n_ticks <= ctx->tick_cap) return RC_OK;
-    if (ctx->tick_tab_d) (void)hipFree(ctx->tick_tab_d);
-    if (ctx->tick_tab_h) (void)hipHostFree(ctx->tick_tab_h);
-    if (ctx->tick_queue_d) (void)hipFree(ctx->tick_queue_d);
-    ctx->tick_tab_d = nullptr; ctx->tick_tab_h = nullptr; ctx->tick_queue_d = nullptr; ctx->tick_cap = 0;
-    const size_t cap = n_ticks + n_ticks / 4 + 64;
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->tick_tab_d, cap * sizeof(TickTable)));
-    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->tick_tab_h, cap * sizeof(TickTable), hipHostMallocDefault));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->tick_queue_d, cap * 128 * sizeof(int)));
-    ctx->tick_cap = cap;
-    return RC_OK;
-}
-
 int check_ready(rc_ctx* ctx) {
     if (!ctx) return RC_ERR_INVALID;
     if (!ctx->have_weights) return fail(ctx, RC_ERR_STATE, "weights not finalized (rc_finalize_weights)");
@@ -1267,14 +1327,16 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_spin_always = tune_env("RC_LIVE_SPIN", 1) >= 2;
     ctx->live_spin_b2b = tune_env("RC_LIVE_SPIN_B2B", 1) != 0;
     ctx->live_blind = tune_env("RC_LIVE_MIRROR_BLIND", 0) != 0;
-    ctx->seq_tick = tune_env("RC_SEQ_TICK", 0) != 0 ? 1 : 0;
-    ctx->tick_grid = std::min(256, std::max(8, tune_env("RC_TICK_GRID", 248)));
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
     if (ctx->seq_mode < 0 || ctx->seq_mode > 2) ctx->seq_mode = 1;
     ctx->cost_tick_us = tune_env("RC_COST_TICK_PCT", 100) / 100.0;
     ctx->cost_tick_small_us = tune_env("RC_COST_HANDOVER_US", (int)ctx->cost_tick_small_us);
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
     ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
+    ctx->lds_min_rows = tune_env("RC_LDS_MIN_ROWS", ctx->lds_min_rows);
+    ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 2) == 1 ? 1 : 2;
+    ctx->lds_ksplit[1] = tune_env("RC_LDS_KSPLIT_1024", 2) == 1 ? 1 : 2;
+    ctx->lds_ksplit[2] = tune_env("RC_LDS_KSPLIT_1280", 2) == 1 ? 1 : 2;
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
     // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
     // only lengthens the launch). 64-row tiles halve the weight bytes a CU pulls per product -- with the MFMA time cut 2.7x
@@ -1334,6 +1396,9 @@ int rc_destroy(rc_ctx* ctx) {
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->h512_stream) (void)hipStreamDestroy(ctx->h512_stream);
     for (hipEvent_t e : ctx->ev_h512) if (e) (void)hipEventDestroy(e);
+    if (ctx->lin1_stream) (void)hipStreamDestroy(ctx->lin1_stream);
+    for (hipEvent_t e : ctx->ev_lin1) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_h5) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 8; ++i) {
         if (ctx->ev_main[i]) (void)hipEventDestroy(ctx->ev_main[i]);
         if (ctx->ev_aux[i]) (void)hipEventDestroy(ctx->ev_aux[i]);
@@ -1344,9 +1409,6 @@ int rc_destroy(rc_ctx* ctx) {
     if (ctx->sweep_scratch) (void)hipFree(ctx->sweep_scratch);
     if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
     if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
-    if (ctx->tick_tab_d) (void)hipFree(ctx->tick_tab_d);
-    if (ctx->tick_tab_h) (void)hipHostFree(ctx->tick_tab_h);
-    if (ctx->tick_queue_d) (void)hipFree(ctx->tick_queue_d);
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ctx;
     return RC_OK;
@@ -1664,7 +1726,8 @@ int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_fr
 
 int rc_get_launch_stats(rc_ctx* ctx, int64_t* tick_launches, int64_t* other_wide_launches) {
     if (!ctx) return RC_ERR_INVALID;
-    if (tick_launches) *tick_launches = ctx->stat_tick_launches;
+    if (tick_launches) *tick_launches = ctx->stat_lds_launches;   // round 6: launches of the shared-weight kernel (rc_gemm_lds_kernel); round 5 counted its
+                                                                  // one-launch-per-tick kernel here (removed: profiles/r06_tick_path_removed.diff)
     if (other_wide_launches) *other_wide_launches = ctx->stat_wide_launches;
     return RC_OK;
 }

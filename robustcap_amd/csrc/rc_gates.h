@@ -15,3 +15,13 @@ __device__ __forceinline__ float rc_gate_tanh(float x) {
 __device__ __forceinline__ float rc_gate_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float rc_gate_tanh(float x) { return tanhf(x); }
 #endif
+
+// One LSTM cell update from the four gate pre-activations (torch order i, f, g, o; articulate/utils/torch/rnn.py:129-133 -> aten::lstm):
+// c' = sigma(f) c + sigma(i) tanh(g), h' = sigma(o) tanh(c'). ONE definition with the contraction written out (fma(f, c, i * g)), so
+// that every tile shape of rc_gemm.hip and the shared-weight kernel of rc_gemm_lds.hip produce the same bits.
+__device__ __forceinline__ void rc_lstm_cell(float gi, float gf, float gg, float go, float c_prev, float& c_new, float& h_new) {
+    const float ig = rc_gate_sigmoid(gi), fg = rc_gate_sigmoid(gf);
+    const float cg = rc_gate_tanh(gg), og = rc_gate_sigmoid(go);
+    c_new = __builtin_fmaf(fg, c_prev, ig * cg);
+    h_new = og * rc_gate_tanh(c_new);
+}

@@ -454,18 +454,19 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& P, const int B, con
             const int rr = item / UT, u = item - rr * UT;
             if (item >= MT * UT || rr >= nrows) continue;
             const int unit = n_tile * UT + u;
-            f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + 4 * u]);
-#pragma unroll
-            for (int w = 1; w < RC_NW; ++w) g4 += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + 4 * u]);
+            // (p0 + p1) + (p2 + p3): the two halves of K -- seg[0] | seg[1] of a layer step -- are summed on their own first, which is
+            // what lets rc_gemm_lds.hip compute them in two workgroups and still produce these bits (round 6)
+            static_assert(RC_NW == 4, "the reduction order below names the four K quarters");
+            f32x4 g4 = (*reinterpret_cast<const f32x4*>(&s_part[rr * LD + 4 * u]) + *reinterpret_cast<const f32x4*>(&s_part[(MT + rr) * LD + 4 * u])) +
+                       (*reinterpret_cast<const f32x4*>(&s_part[(2 * MT + rr) * LD + 4 * u]) + *reinterpret_cast<const f32x4*>(&s_part[(3 * MT + rr) * LD + 4 * u]));
             if constexpr (BIAS_ONE) g4 += bias4; else g4 += *reinterpret_cast<const f32x4*>(&P.bias[n_tile * NT + 4 * u]);
             const int r2 = s_rows[rr];
             const int dst = (st_row[k] + P.step_off) % RC_HBUF;
             const long long ci = (long long)r2 * P.H + unit;
-            const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]);
-            const float gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
-            const float cn = fg * c_prev[k] + ig * gg;
+            float cn, hn;
+            rc_lstm_cell(g4[0], g4[1], g4[2], g4[3], c_prev[k], cn, hn);
             P.cstate[ci] = cn;
-            P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = og * tanhf_(cn);
+            P.hstate[(long long)dst * P.h_par_stride + rc_pk(r2, unit, P.H)] = hn;
         }
     } else {
         // packed outputs whose columns come in whole groups of four (linear1 -> x1: the A operand of the LSTM's first layer):
@@ -644,398 +645,6 @@ __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_nt_kernel(const G
 __global__ __launch_bounds__(RC_NW * 64, 4) void rc_gemm_small_split_kernel(const GemmLaunch L) {
     __shared__ __attribute__((aligned(16))) float s_mem[RC_SMALL_LDS_FLOATS];
     small_tiles<true>(L, s_mem);
-}
-
-// =====================================================================================================================
-// One launch per wavefront tick (round 5): resident workgroups with a tile loop.
-//
-// rc_gemm_tick_kernel runs ALL wide problems of a sequence-mode tick (rc_api.cpp: run_wave2_segment) -- the twelve LSTM layer
-// steps and the six linear1 of the six sub-nets, each on a different ring slot, all independent of one another -- as 64 x 128
-// split-product tiles pulled from per-XCD queues by `grid` resident workgroups (one per CU; the host leaves a few CUs to the
-// tick's per-row kernels, which run beside it on the second stream). What a resident workgroup buys over one workgroup per tile
-// (profiles/r04_tile_trace_engine.txt: 19.8 % of a 64 x 128 tile outside its K loop -- 3.5 us of prologue, ~2 us of waiting
-// for the first weights, 4.2 us of reduction and epilogue):
-//   * the NEXT tile is known while the current one computes (claimed two tiles ahead by an atomic whose latency hides in the K
-//     loop), so its row flags, step words and FIRST WEIGHT K-BLOCK are requested behind the current tile's last MFMA and travel
-//     during its split-K reduction and epilogue; the next K loop starts on operands that are already in registers;
-//   * the problem table lives in device memory and is read through the scalar cache (constant address space: s_load), not
-//     through a 3.4 KB by-value kernel argument that hipcc copies to scratch as soon as the tile code sits in a loop
-//     (profiles/r02_persist_experiment.diff, r04_small_batch_tiles.txt);
-//   * the K loop no longer re-reads its last k-block (the clamped prefetch of gemm_tile: 1/9 of the operand bytes of a K = 1024 tile).
-// Arithmetic per output element is gemm_tile<4, 8, ..., SPLIT>'s, operation for operation (same K split over the four waves,
-// same MFMA order, same reduction order, same epilogue): results are bitwise those of the one-tile-per-workgroup launches
-// (tests/test_gpu_sequence_mode.py). Tiles of one weight slice sit next to each other in ONE XCD's queue (item id % 8 = queue), so
-// that the row tiles of a slice still share it through that XCD's L2.
-#define RC_AS4 __attribute__((address_space(4)))
-#define RC_AS1 __attribute__((address_space(1)))
-#ifndef RC_TICK_FOLD
-#define RC_TICK_FOLD 1        // 1: the next tile's first weight k-block rides the K loop's last load slot (it lands before the epilogue's own
-#endif                        // reads, which are younger); 0: requested behind them (it travels during the reduction and the epilogue; the
-                              // loop's last slot then re-reads the wave's last k-block like gemm_tile)
-#define RC_TICK_HEAD 144      // ints per row-list buffer: rows [64], step words [64], per-wave counts [4] (+ padding)
-#define RC_TICK_LDS_FLOATS (2 * RC_TICK_HEAD + 16 + RC_NW * 64 * (16 * 8 + LDS_PAD))
-typedef const RC_AS4 TickTable* TickTabP;
-typedef const RC_AS4 GemmProblem* TickProbP;
-
-template <class T>
-__device__ __forceinline__ T* tick_global(T* p) {      // a pointer read from the table is global memory (else hipcc emits flat loads)
-    return (T*)(RC_AS1 T*)(unsigned long long)p;
-}
-
-// item id -> (problem, row tile, column tile); false for the padding items behind a problem whose tile count is no multiple of 8.
-// mybase: lane q < RC_TICK_MAXP holds item_base[q] (INT_MAX in the unused slots), so the problem is one ballot away.
-__device__ __forceinline__ bool tick_locate(TickTabP tab, const int mybase, const int vb, int& pi, int& m_tile, int& n_tile) {
-    pi = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(vb >= mybase)) - 1);
-    const int local = vb - __builtin_amdgcn_readlane(mybase, pi);
-    const int n_tiles = tab->p[pi].n_tiles, m_tiles = tab->p[pi].m_tiles;
-    if ((n_tiles & 7) == 0) {     // XCD-aware: the row tiles of one weight slice share item id % 8 (= their queue)
-        const int xcd = local & 7, s2 = local >> 3;
-        m_tile = s2 % m_tiles;
-        n_tile = (s2 / m_tiles) * 8 + xcd;
-    } else {
-        m_tile = local % m_tiles;
-        n_tile = local / m_tiles;
-    }
-    return n_tile < n_tiles;
-}
-
-// Queue protocol. queue[x * 16] counts the items claimed from XCD x's queue (items x, x + 8, x + 16, ...), zeroed by the host
-// before the launch. One lane per workgroup claims; a workgroup whose own queue is empty goes on with the next XCD's (the
-// launch ends level instead of leaving a whole XCD idle behind the slowest one).
-#define RC_TICK_QSTRIDE 16    // ints between two queue counters (64 B: a counter per cache line)
-__device__ __forceinline__ int tick_claim(int* queue, const int n_items, const int x0, int& tried) {
-    while (tried < 8) {
-        const int xx = (x0 + tried) & 7;
-        const int vb = atomicAdd(&queue[xx * RC_TICK_QSTRIDE], 1) * 8 + xx;
-        if (vb < n_items) return vb;
-        ++tried;
-    }
-    return -1;
-}
-
-template <int CH>
-struct TickMeta {             // what a tile reads before its row compaction, requested one tile ahead: for the candidate rows
-    unsigned fl[CH];  // tid + 256 c the dword that holds the row's flag byte, the one with its select byte, and the step number.
-    unsigned sel[CH]; // Twelve unconditional loads and NO arithmetic on the results here: whatever uses a loaded value makes hipcc
-    int st[CH];       // wait for it, and -- vmcnt completes in order -- for the next tile's weights requested just before
-};
-
-// (the host puts a valid array behind flags / sel_flags / steps of every problem of the table, used or not)
-template <int CH>
-__device__ __forceinline__ void tick_meta_request(TickMeta<CH>& m, TickProbP P, const int B, const int tid) {
-    const int* steps = tick_global(P->steps);
-    const unsigned* flags = reinterpret_cast<const unsigned*>(tick_global(P->flags));
-    const unsigned* sel_flags = reinterpret_cast<const unsigned*>(tick_global(P->sel_flags));
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int r = min(tid + c * RC_NW * 64, B - 1);             // (clamped, not predicated: no branch between the loads)
-        m.fl[c] = flags[r >> 2];
-        m.st[c] = steps[r];
-        m.sel[c] = sel_flags[r >> 2];
-    }
-}
-
-// rows of the tile -> head[0 .. 64) (row ids) and head[64 .. 128) (step word | bit 31: the row lacks sel_bit); returns their number
-template <int CH>
-__device__ __forceinline__ int tick_compact(const TickMeta<CH>& m, TickProbP P, const int m_tile, const int B, int* head, const int tid,
-                                            const int wave) {
-    const int lane = tid & 63;
-    int* s_rows = head;
-    int* s_st = head + 64;
-    int* s_cnt = head + 128;
-    const int lo = m_tile * 64;
-    const int sel_bit = P->sel_bit, flag_bit = P->flag_bit;
-    const bool need_st = ((P->seg[0].par_mode | P->seg[1].par_mode) != 0) || P->epi == RC_EPI_LSTM;
-    int nrows;
-#define RC_TICK_WORD(C, R) ((need_st ? m.st[C] : 0) | ((sel_bit && !((m.sel[C] >> (8 * ((R) & 3))) & sel_bit)) ? (int)0x80000000 : 0))
-    if (flag_bit == 0) {                                            // every row: the tile's rows are lo .. lo + 63, all in chunk lo / 256
-        nrows = min(64, B - lo);
-        const int c0 = lo >> 8;
-        const int r = tid + c0 * RC_NW * 64;
-        int word = RC_TICK_WORD(0, r);
-#pragma unroll
-        for (int c = 1; c < CH; ++c) if (c0 == c) word = RC_TICK_WORD(c, r);
-        if (r >= lo && r < lo + nrows) { s_rows[r - lo] = r; s_st[r - lo] = word; }
-        __syncthreads();
-    } else {
-        int total = 0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (c * RC_NW * 64 < B && total < lo + 64) {            // (uniform)
-                const int r = tid + c * RC_NW * 64;
-                const bool f = r < B && ((m.fl[c] >> (8 * (r & 3))) & flag_bit);
-                const unsigned long long bal = __ballot(f);
-                if (lane == 0) s_cnt[wave] = __popcll(bal);
-                __syncthreads();
-                int woff = 0, sum = 0;
-#pragma unroll
-                for (int w = 0; w < RC_NW; ++w) {
-                    const int cw = s_cnt[w];
-                    woff += (w < wave) ? cw : 0;
-                    sum += cw;
-                }
-                sum = __builtin_amdgcn_readfirstlane(sum);
-                const int idx = total + woff + __popcll(bal & ((1ull << lane) - 1ull));
-                if (f && idx >= lo && idx < lo + 64) {
-                    s_rows[idx - lo] = r;
-                    s_st[idx - lo] = RC_TICK_WORD(c, r);
-                }
-                total += sum;
-                __syncthreads();
-            }
-        }
-        nrows = min(64, total - lo);
-    }
-#undef RC_TICK_WORD
-    if (nrows > 0 && tid < 64 && tid >= nrows) { s_rows[tid] = s_rows[0]; s_st[tid] = s_st[0]; }
-    __syncthreads();
-    return nrows;
-}
-
-// CH: chunks of 256 candidate rows (contexts of up to 256 CH rows)
-template <int CH>
-__global__ __launch_bounds__(RC_NW * 64, 1) void rc_gemm_tick_kernel(const TickTable* tab_, int* queue, const int B) {
-    constexpr int MR = 4, NC = 8, MT = 64, NT = 128, UT = 32, LD = NT + LDS_PAD;
-    constexpr int KBU = RC_WPL * 64;
-    __shared__ __attribute__((aligned(16))) float s_mem[RC_TICK_LDS_FLOATS];
-    const TickTabP tab = (TickTabP)(unsigned long long)tab_;
-    int* s_head = reinterpret_cast<int*>(s_mem);                    // [2][RC_TICK_HEAD]
-    int* s_item = s_head + 2 * RC_TICK_HEAD;                        // [3] ring of claimed items
-    float* s_part = s_mem + 2 * RC_TICK_HEAD + 16;                  // [RC_NW][MT][LD]
-    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: the K-segment select of the loop is scalar code)
-    const int n_items = tab->n_items;
-#ifdef RC_TRACE_TILES
-    unsigned long long trace_t[4] = {0, 0, 0, 0};
-#endif
-
-    // ---- the first two items of this workgroup
-    int mybase = lane < RC_TICK_MAXP ? tab_->item_base[lane] : 0x7fffffff;
-    const int x0 = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);      // HW_REG_XCC_ID: the XCD this workgroup runs on
-    int tried = 0;                                                  // (lane 0 of wave 0 only) queues found empty so far
-    if (tid == 0) {
-        s_item[0] = tick_claim(queue, n_items, x0, tried);
-        s_item[1] = tick_claim(queue, n_items, x0, tried);
-    }
-    __syncthreads();
-    asm volatile("s_waitcnt vmcnt(0)\n" : "+v"(mybase));           // (a value of this lane from here on, not a pending load)
-    int cur = __builtin_amdgcn_readfirstlane(s_item[0]);
-    int nxt = __builtin_amdgcn_readfirstlane(s_item[1]);
-    int it = 0;                                                     // tiles done: s_item[(it + k) % 3] = item it + k
-    int pi = 0, m_tile = 0, n_tile = 0;
-    bool have = cur >= 0 && tick_locate(tab, mybase, cur, pi, m_tile, n_tile);
-    // (a padding item has no tile: the loop below then only moves on)
-    TickMeta<CH> meta = {};
-    FragS<MR, NC> fa = {}, fb = {};
-    if (have) {
-        const TickProbP P = &tab->p[pi];
-        tick_meta_request(meta, P, B, tid);
-        const int Qs = P->Kp / 32, Qws = Qs / RC_NW;
-        const u32x4* pbs = reinterpret_cast<const u32x4*>(tick_global(RC_SPLIT_W32 ? (const void*)P->W : P->Ws)) +
-                           ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
-        load_kblock_b(fa, pbs, (long long)Qs * KBU);
-    }
-
-    while (cur >= 0) {
-        // ---- claim the item after next: the atomic's latency hides in this tile's K loop
-        int claim_raw = 0;
-        const int claim_x = (x0 + tried) & 7;
-        if (tid == 0 && nxt >= 0 && tried < 8) claim_raw = atomicAdd(&queue[claim_x * RC_TICK_QSTRIDE], 1);
-        int npi = 0, nm_tile = 0, nn_tile = 0;
-        const bool nhave = nxt >= 0 && tick_locate(tab, mybase, nxt, npi, nm_tile, nn_tile);
-        // first weight k-block of the next tile (this wave's K range of it): requested from inside this tile's K loop
-        const TickProbP PN = &tab->p[nhave ? npi : pi];
-        const int nQs = PN->Kp / 32, nQws = nQs / RC_NW;
-        const long long nbs = (long long)nQs * KBU;
-        const u32x4* npbs = reinterpret_cast<const u32x4*>(tick_global(RC_SPLIT_W32 ? (const void*)PN->W : PN->Ws)) +
-                            ((long long)((nhave ? nn_tile : n_tile) * NC) * nQs + (long long)wave * nQws) * KBU + lane;
-        const TickProbP P = &tab->p[pi];
-        int* head = s_head + (it & 1) * RC_TICK_HEAD;
-        int nrows = 0;
-        bool next_requested = false;
-        TRACE_T(0);
-        if (have) nrows = tick_compact(meta, P, m_tile, B, head, tid, wave);
-        const int epi = P->epi, H = P->H;
-        constexpr int EPI_ITEMS = (MT * UT) / (RC_NW * 64);         // 8
-        float c_prev[EPI_ITEMS];
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nrows > 0) {
-            // ---- per-lane A pointers of the four 16-row blocks
-            const float* pa0[MR];
-            const float* pa1[MR];
-            {
-                const int pm0 = P->seg[0].par_mode, pm1 = P->seg[1].par_mode, step_off = P->step_off;
-                const float* b0 = tick_global(P->seg[0].base);
-                const float* b1 = tick_global(P->seg[1].base);
-                const float* balt = tick_global(P->alt_base);
-                const long long ps0 = P->seg[0].par_stride, ps1 = P->seg[1].par_stride;
-                const int ld0 = P->seg[0].ld, ld1 = P->seg[1].ld;
-#pragma unroll
-                for (int r = 0; r < MR; ++r) {
-                    const int row = head[16 * r + i], sw = head[64 + 16 * r + i];
-                    const int st = (sw & 0x7fffffff) + ((pm0 | pm1) ? step_off : 0);
-                    const int par0 = pm0 == RC_PAR_SRC ? ((st - 1) % RC_HBUF) : (pm0 == RC_PAR_DST ? (st % RC_HBUF) : 0);
-                    const int par1 = pm1 == RC_PAR_SRC ? ((st - 1) % RC_HBUF) : (pm1 == RC_PAR_DST ? (st % RC_HBUF) : 0);
-                    pa0[r] = (sw < 0 ? balt : b0) + (long long)par0 * ps0 + rc_pk(row, 4 * kq, ld0);
-                    pa1[r] = b1 + (long long)par1 * ps1 + rc_pk(row, 4 * kq, ld1);
-                }
-            }
-            const int Qs = P->Kp / 32, Qws = Qs / RC_NW, K0 = P->seg[0].K;
-            const long long bs = (long long)Qs * KBU;
-            const u32x4* pbs = reinterpret_cast<const u32x4*>(tick_global(RC_SPLIT_W32 ? (const void*)P->W : P->Ws)) +
-                               ((long long)(n_tile * NC) * Qs + (long long)wave * Qws) * KBU + lane;
-            const int kb0 = wave * Qws * 32;
-            TRACE_T(1);
-            f32x4 acc[MR][NC];
-#pragma unroll
-            for (int r = 0; r < MR; ++r)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // ---- K loop: gemm_tile's two-buffer loop (the first block's weight planes are already on their way). Its last load
-            // slot -- a clamped re-read of the wave's last k-block there, 1/9 of the operand bytes of a K = 1024 tile -- carries
-            // the NEXT tile's first weight k-block instead (a pointer select, no branch in the loop).
-#define TLOADS_A(F, QI)                                                                                             \
-    do {                                                                                                            \
-        const int k_ = kb0 + (QI) * 32;                                                                             \
-        if (k_ < K0) load_kblock_a(F, pa0, (long long)k_ * 16);                                             \
-        else load_kblock_a(F, pa1, (long long)(k_ - K0) * 16);                                              \
-    } while (0)
-#define TSB() __builtin_amdgcn_sched_barrier(0)
-            int q = 0;
-            TLOADS_A(fa, 0);
-            for (; q + 2 <= Qws; q += 2) {
-                TLOADS_A(fb, q + 1);
-                load_kblock_b(fb, pbs + (long long)(q + 1) * KBU, bs);
-                TSB();
-                mma_kblock(fa, acc);
-                TSB();
-                const bool own = q + 2 < Qws || !RC_TICK_FOLD;
-                TLOADS_A(fa, min(q + 2, Qws - 1));
-                load_kblock_b(fa, own ? pbs + (long long)min(q + 2, Qws - 1) * KBU : npbs, own ? bs : nbs);
-                TSB();
-                mma_kblock(fb, acc);
-                TSB();
-            }
-            if (q < Qws) {                                          // one k-block per wave (rnn2's linear1, K = 128)
-                mma_kblock(fa, acc);
-                TSB();
-                if (RC_TICK_FOLD) load_kblock_b(fa, npbs, nbs);
-            }
-            next_requested = RC_TICK_FOLD != 0;
-#undef TSB
-#undef TLOADS_A
-            TRACE_T(2);
-            // ---- the epilogue's own global reads
-            const float* bias = tick_global(P->bias);
-            if (epi == RC_EPI_LSTM) {
-                const float* cstate = tick_global(P->cstate);
-#pragma unroll
-                for (int k = 0; k < EPI_ITEMS; ++k) {
-                    const int item = tid + k * RC_NW * 64;
-                    const int rr = item / UT, u = item - rr * UT;
-                    const bool ok = rr < nrows;
-                    c_prev[k] = ok ? cstate[(long long)head[ok ? rr : 0] * H + n_tile * UT + u] : 0.f;
-                }
-                bias4 = *reinterpret_cast<const f32x4*>(&bias[n_tile * NT + 4 * (tid % UT)]);
-            } else {
-                bias4 = *reinterpret_cast<const f32x4*>(&bias[n_tile * NT + (tid % (NT / 4)) * 4]);
-            }
-            // ---- split-K partial sums to LDS (C layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg)
-#pragma unroll
-            for (int r = 0; r < MR; ++r)
-#pragma unroll
-                for (int j = 0; j < NC; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        s_part[(wave * MT + 16 * r + 4 * kq + e) * LD + 16 * j + i] = acc[r][j][e];
-        }
-        // ---- the next tile's flag / step words (and, when this item had no tile, its first weights): they travel during the
-        // reduction and the epilogue
-        if (nhave) {
-            tick_meta_request(meta, &tab->p[npi], B, tid);
-            if (!next_requested) load_kblock_b(fa, npbs, nbs);
-        }
-        __syncthreads();
-        // ---- publish the claimed item (this slot of the ring was last read two tiles ago; the atomic returned long ago: it is older than every load of the K loop)
-        if (tid == 0) {
-            int vb = -1;
-            if (nxt >= 0 && tried < 8) {
-                asm volatile("" : "+v"(claim_raw));                  // (first use HERE: hipcc otherwise waits for the atomic where it is issued)
-                vb = claim_raw * 8 + claim_x;
-                if (vb >= n_items) { ++tried; vb = tick_claim(queue, n_items, x0, tried); }
-            }
-            s_item[(it + 2) % 3] = vb;
-        }
-        if (nrows > 0) {
-            if (epi == RC_EPI_LSTM) {
-                float* cstate = tick_global(P->cstate);
-                float* hstate = tick_global(P->hstate);
-                const long long hps = P->h_par_stride;
-                const int step_off = P->step_off;
-#pragma unroll
-                for (int k = 0; k < EPI_ITEMS; ++k) {
-                    const int item = tid + k * RC_NW * 64;
-                    const int rr = item / UT, u = item - rr * UT;
-                    if (rr >= nrows) continue;
-                    const int unit = n_tile * UT + u;
-                    f32x4 g4 = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + 4 * u]);
-#pragma unroll
-                    for (int w = 1; w < RC_NW; ++w) g4 += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + 4 * u]);
-                    g4 += bias4;
-                    const int r2 = head[rr];
-                    const int dst = ((head[64 + rr] & 0x7fffffff) + step_off) % RC_HBUF;
-                    const long long ci = (long long)r2 * H + unit;
-                    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]);
-                    const float gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
-                    const float cn = fg * c_prev[k] + ig * gg;
-                    cstate[ci] = cn;
-                    hstate[(long long)dst * hps + rc_pk(r2, unit, H)] = og * tanhf_(cn);
-                }
-            } else {
-                // linear1 -> relu -> x1 (rc_pk order): four columns per item, the sums of gemm_tile's vec4 epilogue in its order
-                float* out = tick_global(P->out);
-                const int N = P->N, ldo = P->ldo, out_col0 = P->out_col0;
-                constexpr int V4_ITEMS = (MT * (NT / 4)) / (RC_NW * 64);   // 8
-#pragma unroll
-                for (int k = 0; k < V4_ITEMS; ++k) {
-                    const int item = tid + k * RC_NW * 64;
-                    const int rr = item / (NT / 4), c4 = (item - rr * (NT / 4)) * 4;
-                    const int n = n_tile * NT + c4;
-                    if (rr >= nrows || n >= N) continue;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&s_part[rr * LD + c4]);
-#pragma unroll
-                    for (int w = 1; w < RC_NW; ++w) v += *reinterpret_cast<const f32x4*>(&s_part[(w * MT + rr) * LD + c4]);
-                    v += bias4;
-                    if (epi == RC_EPI_RELU) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
-                    *reinterpret_cast<f32x4*>(&out[rc_pk(head[rr], out_col0 + n, ldo)]) = v;
-                }
-            }
-#ifdef RC_TRACE_TILES
-            if (threadIdx.x == 0 && g_trace_buf) {
-                const unsigned long long idx = (unsigned long long)tab->trace_base + cur;
-                if (idx < g_trace_cap) {
-                    unsigned long long* rec = g_trace_buf + idx * 8;
-                    rec[0] = (unsigned long long)cur + 1; rec[1] = (unsigned long long)(MR * 16 + NC) | ((unsigned long long)nrows << 16);
-                    rec[2] = __smid(); rec[3] = (unsigned long long)n_tile | ((unsigned long long)m_tile << 32);
-                    rec[4] = trace_t[0]; rec[5] = trace_t[1]; rec[6] = trace_t[2]; rec[7] = wall_clock64();
-                }
-            }
-#endif
-        }
-        __syncthreads();              // (also: every wave is done with s_part and with this tile's row list)
-        cur = nxt; pi = nhave ? npi : pi; m_tile = nm_tile; n_tile = nn_tile; have = nhave;
-        nxt = __builtin_amdgcn_readfirstlane(s_item[(it + 2) % 3]);
-        ++it;
-    }
-}
-
-void rc_launch_gemm_tick(const TickTable* tab_dev, int* queue_dev, int B, int grid, hipStream_t s, hipEvent_t stop) {
-    const dim3 g(grid), b(RC_NW * 64);
-#define RC_GO(K) do { if (stop) hipExtLaunchKernelGGL(K, g, b, 0, s, nullptr, stop, 0, tab_dev, queue_dev, B); else hipLaunchKernelGGL(K, g, b, 0, s, tab_dev, queue_dev, B); } while (0)
-    if (B <= 256) RC_GO(rc_gemm_tick_kernel<1>);
-    else if (B <= 512) RC_GO(rc_gemm_tick_kernel<2>);
-    else RC_GO(rc_gemm_tick_kernel<RC_TICK_CH>);
-#undef RC_GO
 }
 
 bool rc_gemm_is_small(const GemmLaunch& L) {

@@ -96,19 +96,28 @@ struct GemmLaunch {
 
 #define RC_TICK_PROB 24   // GEMM problems of one sequence-mode tick (6 sub-nets x {linear1, LSTM l0, LSTM l1, linear2})
 
-// ---- one launch per tick (rc_gemm_tick_kernel, rc_gemm.hip): the tick's wide problems as a table in DEVICE memory, read through the
-// scalar cache; resident workgroups pull 64 x 128 split-product tiles ("items") from per-XCD queues
-#define RC_TICK_MAXP 24   // wide problems of a tick: 12 LSTM layer steps + 6 linear1 (+ head room)
-#define RC_TICK_CH 4      // chunks of 256 candidate rows whose flag / step words a tile requests ahead: contexts of up to 1024 rows
-struct TickTable {
-    int n_prob;             // problems
-    int n_items;            // items = tiles incl. the padding that keeps every problem's first item a multiple of 8
-    int trace_base;         // first record slot of this launch (-DRC_TRACE_TILES builds)
-    int pad_;
-    int item_base[RC_TICK_MAXP + 4];   // first item of problem q (multiples of 8), ascending
-    GemmProblem p[RC_TICK_MAXP];       // every problem: split products, 64 x 128 tiles (mr 4, nc 8), epilogue LSTM or packed relu
+// ---- shared-weight gate GEMM of the LSTM layer steps (rc_gemm_lds.hip): 256-row x 128-column tiles, 8 waves, the weight planes of
+// a k-block staged once per workgroup in LDS, K halved across two workgroups (seg[0] | seg[1]) that meet through a slab in device memory
+#define RC_LDS_MAXP 12    // layer steps fused in one launch
+#define RC_LDS_SLAB_FLOATS 65536   // per tile: two half sums of 256 x 128 floats
+struct LdsProblem {
+    GemmSeg seg[2];         // A = [seg0 | seg1] along K, each H long: the layer's input and its own h(t - 1)
+    const void* Ws;         // weight planes (pack_weights_split)
+    const float* bias;
+    float* hstate;
+    float* cstate;
+    const int* steps;
+    const unsigned char* flags;
+    float* slab;            // [tiles][2][256 x 128]: the half sums
+    int* tickets;           // [tiles], zero between launches
+    long long h_par_stride;
+    int H, flag_bit, n_tiles, m_tiles, wg_base, Qs, step_off, ksplit;
 };
-void rc_launch_gemm_tick(const TickTable* tab_dev, int* queue_dev, int B, int grid, hipStream_t s, hipEvent_t stop = nullptr);
+struct LdsLaunch {
+    int n, B;
+    LdsProblem p[RC_LDS_MAXP];
+};
+void rc_launch_gemm_lds(const LdsLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
 
 // ---- per-frame small kernels -------------------------------------------------------------------------------
 struct BodyConst {          // device copy of the body constants the path needs

@@ -364,23 +364,24 @@ class Net:
         return t
 
     def gemm_kernel_name(self):
-        """Name of the kernel the timed wide-tile gate-GEMM launches run on (what a rocprofv3 kernel summary lists)."""
+        """Name of the kernel that carries the path's FLOPs in this context (what a rocprofv3 kernel summary lists): the
+        shared-weight kernel of the LSTM layer steps where it has run, else the wide-tile kernel of the context's arithmetic."""
         try:
-            tick, other = self.launch_stats()
+            lds, other = self.launch_stats()
         except AttributeError:                                              # (an older build of the library under RC_LIB_PATH: A/B runs)
-            tick, other = 0, 0
-        if tick > other:
-            return "rc_gemm_tick_kernel"
+            lds, other = 0, 0
+        if lds > 0:
+            return "rc_gemm_lds_kernel"
         return "rc_gemm_split_kernel" if self.gemm_mode else "rc_gemm_kernel"
 
     def launch_stats(self):
-        """(one-launch-per-tick launches, launches of the other wide-tile kernels) since construction."""
+        """(launches of the shared-weight kernel rc_gemm_lds_kernel, launches of the other wide-tile kernels) since construction."""
         a, b = C.c_int64(), C.c_int64()
         _lib.check(self._ctx, self._lib.rc_get_launch_stats(self._ctx, C.byref(a), C.byref(b)), "rc_get_launch_stats")
         return a.value, b.value
 
     def gemm_timing(self, enable):
-        """0 off, 1 (True) every gate-GEMM launch, 2 only the launches of the wide-tile kernel rc_gemm_kernel."""
+        """0 off, 1 (True) every gate-GEMM launch, 2 only the launches of the wide-tile kernels, 3 only those of rc_gemm_lds_kernel."""
         _lib.check(self._ctx, self._lib.rc_gemm_timing(self._ctx, int(enable)), "rc_gemm_timing")
 
     def gemm_timing_read(self):

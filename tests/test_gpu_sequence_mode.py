@@ -116,6 +116,34 @@ def test_batched_wavefront_equals_frame_stepped(B, conf, synth_assets):
     assert sstat[0] == 0 and sstat[1] == T
 
 
+@pytest.mark.parametrize("B,conf,ksplit", [(256, "mixed", 2), (256, "high", 1), (200, "occ", 2), (520, "mixed", 2)])
+def test_shared_weight_kernel_equals_the_64_row_tiles(B, conf, ksplit, synth_assets, monkeypatch):
+    """Round 6: LSTM layer steps of >= RC_LDS_MIN_ROWS rows run on rc_gemm_lds_kernel (256-row tiles, weight planes staged in LDS once
+    per workgroup, the two halves of K in two workgroups). Per element it forms the sums of the 64-row tiles in their order: outputs,
+    states and traces are BITWISE those of a context that never uses it -- on the wavefront engine and frame-stepped, with one or two
+    workgroups per tile, full row tiles and ragged ones (200 rows; 520 = two full tiles + 8 rows; compacted subsets in 'mixed')."""
+    import bench
+    T = 40
+    m = bench.make_inputs(synth_assets["body"], B, T, conf, seed=11)
+    outs = []
+    for min_rows, seq in (("0", True), ("160", True), ("160", False)):
+        monkeypatch.setenv("RC_LDS_MIN_ROWS", min_rows)                      # (read when the context is created)
+        for k in ("512", "1024", "1280"):
+            monkeypatch.setenv("RC_LDS_KSPLIT_" + k, str(ksplit))
+        net = _net(synth_assets, B, seq, 8)
+        net.gravityc = t(m["gravityc"])
+        p, tr = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_tran=t(m["first_tran"]))
+        torch.cuda.synchronize()
+        outs.append((p, tr, [net.get_state(n) for n in ("rnn2", "rnn3", "rnn4", "rnn6", "rnn7", "rnn8")], net.get_trace(), net.launch_stats()))
+    ref = outs[0]
+    assert ref[4][0] == 0                                                    # no shared-weight launch there
+    for o in outs[1:]:
+        assert o[4][0] > 0
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[3], ref[3])
+        for (h, c), (hr, cr) in zip(o[2], ref[2]):
+            assert torch.equal(h, hr) and torch.equal(c, cr)
+
+
 def test_sequence_mode_respects_switches_and_live(synth_assets):
     """use_reproj_opt / no updaters run through the skewed tail as well; live contexts never use the planner."""
     import bench

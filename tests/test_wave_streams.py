@@ -48,7 +48,7 @@ def frame_ops(e, hbuf, x1buf, init=True):
     return ops
 
 
-def build(mode, hbuf, x1buf, init=True):
+def build(mode, hbuf, x1buf, init=True, g0_nets=G0_NETS, init_in="G0"):
     """nodes = launches; returns (accesses per node, happens-before matrix)."""
     per_tick = {k: {"prep": [], "lin2": [], "fuse": [], "tail": [], "G0": [], "G2": []} for k in range(TICKS)}
     for e in range(TICKS):
@@ -60,9 +60,9 @@ def build(mode, hbuf, x1buf, init=True):
                 if kern in ("prep", "lin2", "fuse", "tail"):
                     per_tick[k][kern].append((rd, wr))
                 elif kern == "init0":
-                    per_tick[k]["G0"].append((rd, wr))
+                    per_tick[k][init_in].append((rd, wr))
                 else:
-                    per_tick[k]["G0" if (kern in ("l0", "l1") and net in G0_NETS) else "G2"].append((rd, wr))
+                    per_tick[k]["G0" if (kern in ("l0", "l1") and net in g0_nets) else "G2"].append((rd, wr))
     nodes, idx = [], {}
     for k in range(TICKS):
         for name in ("prep", "lin2", "fuse", "tail", "G0", "G2"):
@@ -84,7 +84,7 @@ def build(mode, hbuf, x1buf, init=True):
                 edge((k - 1, "tail"), (k, "G2"))                                       # ... behind the second stream's previous tick
                 edge((k - 1, "G0"), (k, "G0"))                                         # caller's stream, in order
                 edge((k - 1, "G2"), (k, "G0"))                                         # ... behind the previous linear1
-                if init:
+                if init and init_in == "G0":
                     edge((k - 1, "tail"), (k, "G0"))                                   # init_net problems read the previous fuse
         else:                                                                           # one stream: G0 then G2, the wait in front of G2 ...
             edge((k, "G0"), (k, "G2"))
@@ -96,8 +96,8 @@ def build(mode, hbuf, x1buf, init=True):
     return nodes, hb
 
 
-def races(mode, hbuf=3, x1buf=3, init=True):
-    nodes, hb = build(mode, hbuf, x1buf, init)
+def races(mode, hbuf=3, x1buf=3, init=True, g0_nets=G0_NETS, init_in="G0"):
+    nodes, hb = build(mode, hbuf, x1buf, init, g0_nets, init_in)
     touched = {}
     out = []
     for i, (k, name, probs) in enumerate(nodes):
