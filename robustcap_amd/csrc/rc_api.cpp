@@ -202,7 +202,8 @@ struct rc_ctx {
     long long stat_wide_launches = 0;    // launches of the wide-tile kernels (rc_get_launch_stats)
     // shared-weight gate GEMM (rc_gemm_lds.hip): LSTM layer steps of >= lds_min_rows rows in split-product mode
     int lds_min_rows = 160;              // RC_LDS_MIN_ROWS (0 = never): below, a 256-row tile is mostly padding and the 64-row tiles win
-    int lds_ksplit[3] = {2, 2, 2};       // RC_LDS_KSPLIT_512 / _1024 / _1280: workgroups per tile (1: both K halves in one workgroup)
+    int lds_ksplit[3] = {1, 2, 2};       // RC_LDS_KSPLIT_512 / _1024 / _1280: workgroups per tile (1: both K halves in one workgroup; the H = 512
+                                         // nets' items are short -- 2 x 16 k-blocks -- and a hand-over per tile costs more than it levels: +1 %)
     float* lds_slab = nullptr;           // [kLdsRegions][lds_region_tiles][RC_LDS_SLAB_FLOATS]: half sums in flight, one region per launch
     int* lds_tickets = nullptr;          // [kLdsRegions][lds_region_tiles]
     size_t lds_region_tiles = 0;
@@ -992,6 +993,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // tick. Each net's chain h(t) -> h(t + 1) then follows its own predecessor only; the drain of one launch is filled by the other two.
     static const int tri_env = tune_env("RC_SEQ_TRI", 1);
     const bool tri = lin1_own && tri_env != 0;
+    static const int tri_swap_env = tune_env("RC_SEQ_TRI_SWAP", 0);
+    const bool tri_swap = tri && tri_swap_env != 0;
     // 64-row tile shapes of the wide launches. With both launches of a tick on one stream rnn4 ran best on 64 x 80 tiles (256 tiles
     // per layer = whole rounds of the 256 CUs); on two streams the other launch fills what a round leaves idle and the 64 x 128 tile's
     // 13 % fewer operand bytes per MFMA win: mixed 512 frames 1,030k -> 1,120k, all-visible 1,208k -> 1,258k, batch 1024 999k -> 1,088k
@@ -1126,20 +1129,24 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         hipEvent_t stop_ev = (two && ext_events) ? ctx->ev_main[e] : nullptr;
         if (tri) {
             bool sig6 = false, sig5 = false, sig0 = false;
-            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_lin1[ep], 0));
-            if (int rc = launch_problems(ctx, tri_ls6, nullptr, s2, false, ctx->ev_h512[e], &sig6)) return rc;
-            if (!sig6) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s2));
+            // (tri_swap: rnn4 -- the longest chain of a tick -- on the context's own stream, which may carry a queue priority
+            // (RC_SEQ_H512_PRIO), rnn6 on the caller's)
+            hipStream_t s_r6 = tri_swap ? st : s2, s_r4 = tri_swap ? s2 : st;
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s_r6, ctx->ev_lin1[ep], 0));
+            if (int rc = launch_problems(ctx, tri_ls6, nullptr, s_r6, false, ctx->ev_h512[e], &sig6)) return rc;
+            if (!sig6) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s_r6));
             if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_aux[ep], 0));      // (rnn2 l0 behind the tail's init_net state write; linear1(k - 1) sits in front of it)
             if (int rc = launch_problems(ctx, tri_ls5, nullptr, s4, false, ctx->ev_h5[e], &sig5)) return rc;
             if (!sig5) HIP_TRY(ctx, hipEventRecord(ctx->ev_h5[e], s4));
-            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lin1[ep], 0));
+            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s_r4, ctx->ev_lin1[ep], 0));
             for (int g = 0; g < last_group; ++g)
                 if (!gp[g].empty()) {
                     bool sig = false;
-                    if (int rc = launch_problems(ctx, gp[g], nullptr, st, false, sig0 ? nullptr : ctx->ev_main[e], &sig)) return rc;
+                    if (int rc = launch_problems(ctx, gp[g], nullptr, s_r4, false, sig0 ? nullptr : ctx->ev_main[e], &sig)) return rc;
                     sig0 = sig0 || sig;
                 }
-            main_signalled = sig0;
+            if (!sig0) HIP_TRY(ctx, hipEventRecord(ctx->ev_main[e], s_r4));
+            main_signalled = true;
         } else if (lin1_own) {
             // Regrouped tick with {linear1, init_net} on a stream of its own: linear1(k) needs only the second stream's work of tick k - 1,
             // so it runs beside the previous tick's layer steps instead of behind them, and neither wide launch waits for the other's
@@ -1201,6 +1208,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     if (split_main && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h512[(P.n_ticks - 1) & 3], 0));
     if (lin1_own && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_lin1[(P.n_ticks - 1) & 3], 0));
     if (tri && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_h5[(P.n_ticks - 1) & 3], 0));
+    if (tri && P.n_ticks > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_main[(P.n_ticks - 1) & 3], 0));
     HIP_TRY(ctx, hipGetLastError());
     ctx->stat_wave_frames += t_last - t0 + 1;
     return RC_OK;
@@ -1334,7 +1342,7 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
     ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
     ctx->lds_min_rows = tune_env("RC_LDS_MIN_ROWS", ctx->lds_min_rows);
-    ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 2) == 1 ? 1 : 2;
+    ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 1) == 1 ? 1 : 2;
     ctx->lds_ksplit[1] = tune_env("RC_LDS_KSPLIT_1024", 2) == 1 ? 1 : 2;
     ctx->lds_ksplit[2] = tune_env("RC_LDS_KSPLIT_1280", 2) == 1 ? 1 : 2;
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
