@@ -48,8 +48,52 @@ def frame_ops(e, hbuf, x1buf, init=True):
     return ops
 
 
+def build_tri(hbuf, x1buf, init=True):
+    """Round 6, contexts on the shared-weight kernel: THREE streams of layer steps -- G4 {rnn4} on the caller's, G6 {rnn6} and G5 {the
+    H = 512 nets} on streams of the context -- and L1 {linear1 of every net, init_net} at the head of the second stream's tick, in
+    front of that stream's waits for the layer steps of the previous tick (rc_api.cpp: run_wave2_segment, `tri`)."""
+    names = ("L1", "prep", "lin2", "fuse", "tail", "G4", "G6", "G5")
+    per_tick = {k: {n: [] for n in names} for k in range(TICKS)}
+    for e in range(TICKS):
+        for s, lst in frame_ops(e, hbuf, x1buf, init).items():
+            k = e + s
+            if k >= TICKS:
+                continue
+            for kern, net, rd, wr in lst:
+                if kern in ("prep", "lin2", "fuse", "tail"):
+                    per_tick[k][kern].append((rd, wr))
+                elif kern in ("init0", "lin1"):
+                    per_tick[k]["L1"].append((rd, wr))
+                else:
+                    per_tick[k]["G4" if net == "rnn4" else ("G6" if net == "rnn6" else "G5")].append((rd, wr))
+    nodes, idx = [], {}
+    for k in range(TICKS):
+        for name in names:
+            idx[(k, name)] = len(nodes)
+            nodes.append((k, name, per_tick[k][name]))
+    n = len(nodes)
+    hb = np.zeros((n, n), bool)
+    edge = lambda a, b: hb.__setitem__((idx[a], idx[b]), True)
+    for k in range(TICKS):
+        for a, b in (("L1", "prep"), ("prep", "lin2"), ("lin2", "fuse"), ("fuse", "tail")):   # second stream, in order
+            edge((k, a), (k, b))
+        if k:
+            edge((k - 1, "tail"), (k, "L1"))
+            for g in ("G4", "G6", "G5"):
+                edge((k - 1, g), (k, "prep"))                                          # the per-row kernels wait for every layer step of the previous tick
+                edge((k - 1, g), (k, g))                                               # each stream in order
+            edge((k - 1, "L1"), (k, "G4"))
+            edge((k - 1, "L1"), (k, "G6"))
+            edge((k - 1, "tail"), (k, "G5"))                                           # (rnn2 l0 behind the tail's init_net state write; L1(k - 1) sits in front of it)
+    for m in range(n):
+        hb |= np.outer(hb[:, m], hb[m, :])
+    return nodes, hb
+
+
 def build(mode, hbuf, x1buf, init=True, g0_nets=G0_NETS, init_in="G0"):
     """nodes = launches; returns (accesses per node, happens-before matrix)."""
+    if mode == "tri":
+        return build_tri(hbuf, x1buf, init)
     per_tick = {k: {"prep": [], "lin2": [], "fuse": [], "tail": [], "G0": [], "G2": []} for k in range(TICKS)}
     for e in range(TICKS):
         for s, lst in frame_ops(e, hbuf, x1buf, init).items():
@@ -115,7 +159,7 @@ def races(mode, hbuf=3, x1buf=3, init=True, g0_nets=G0_NETS, init_in="G0"):
     return out
 
 
-@pytest.mark.parametrize("mode,init", [("two", True), ("two", False), ("one", True), ("one", False)])
+@pytest.mark.parametrize("mode,init", [("two", True), ("two", False), ("one", True), ("one", False), ("tri", True), ("tri", False)])
 def test_a_tick_as_issued_has_no_race(mode, init):
     assert races(mode, init=init) == []
 
@@ -129,3 +173,12 @@ def test_the_third_state_copy_and_the_third_linear1_buffer_are_what_make_it_so()
     r = races("two", x1buf=2)                                                           # {linear1} runs up to a tick ahead of {rnn6, rnn4}
     assert r and all(b[0] == "x1" and b[1] in G0_NETS for b, _, _ in r)
     assert races("one", x1buf=2, init=False) == []                                      # on one stream two buffers were enough
+
+
+def test_the_regrouped_two_stream_tick_and_the_three_stream_tick_need_the_same_copies():
+    """Round 6: {rnn4} alone on the caller's stream with rnn6 + init_net beside the H = 512 nets (RC_SEQ_TRI=0), and the three-stream tick."""
+    assert races("two", g0_nets=("rnn4",), init_in="G2") == []
+    r = races("tri", hbuf=2, init=False)
+    assert r and all(b[0] == "h" for b, _, _ in r)
+    r = races("tri", x1buf=2)
+    assert r and all(b[0] == "x1" for b, _, _ in r)
