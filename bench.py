@@ -329,6 +329,9 @@ def live_b1(sd, body, frames=2000):
         pp, pt = C_.c_void_p(pose.data_ptr()), C_.c_void_p(tran.data_ptr())
         ptrs = [(C_.c_void_p(a.data_ptr()), C_.c_void_p(b.data_ptr()), C_.c_void_p(c.data_ptr())) for a, b, c in ins]
         lat = np.empty(n_frames + 50)
+        prof = np.zeros((n_frames + 50, 6))
+        last = (C_.c_double * 6)()
+        get_last = getattr(net._lib, "rc_get_live_last_profile", None) if period_s > 0 else None
         t_next = time.perf_counter() + period_s
         for i in range(n_frames + 50):
             a, b, c = ptrs[1 + i % (T - 1)]
@@ -346,25 +349,53 @@ def live_b1(sd, body, frames=2000):
             lat[i] = time.perf_counter() - t0
             if rc != 0:
                 raise RuntimeError(f"rc_live_step failed ({rc})")
+            if get_last is not None:                                        # (outside the clocked span)
+                get_last(ctx, last)
+                prof[i] = last[:]
         lat = lat[50:] * 1e6
         lean, full = net.live_stats()
         cap, aql, note = C_.c_int32(0), C_.c_int32(0), C_.create_string_buffer(256)
         net._lib.rc_get_live_backend(net._ctx, C_.byref(cap), C_.byref(aql), note, 256)
-        return lat, lean, full, bool(cap.value), bool(aql.value), note.value.decode()
+        extra = {"prof": prof[50:], "spin": net.live_spin_stats(), "replayed": net.live_replayed(), "presteps": net.live_prestep_stats()[0]}
+        return lat, lean, full, bool(cap.value), bool(aql.value), note.value.decode(), extra
 
-    lat, lean, full, cap, aql, note = run(frames, {})
+    def paced_record(env, what):
+        """config 5 as BASELINE states it: a frame every 16.67 ms, the device idle in between; latency from the frame's ARRIVAL. Beside the
+        percentiles: where the slowest 1 % of the frames spent their time on the host (rc_get_live_last_profile) -- a slow frame whose
+        `wait` segment (enqueue done -> completion seen; the device time is inside it) is as short as everybody's was late BEFORE it
+        reached the library (the pacing loop's own wake-up), one whose wait is long was slow on the queue / device."""
+        lat, lean, full, _, _, _, ex = run(PACED_FRAMES, env, 1.0 / 60.0)
+        pr = ex["prof"]
+        host_in = lat - pr[:, :4].sum(1)                                    # arrival -> rc_live_step entered + return -> clock read: the caller's side
+        slow = lat >= np.percentile(lat, 99)
+        seg = lambda sel: {k: round(float(v), 1) for k, v in zip(("stage_us", "enqueue_us", "wait_us", "copy_out_us"), pr[sel, :4].mean(0))}
+        edges = [0, 60, 70, 80, 90, 100, 125, 150, 200, 400, 1e9]
+        hist = np.histogram(lat, bins=edges)[0]
+        taken, lost = ex["spin"]
+        return {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
+                "p99_9_us": round(float(np.percentile(lat, 99.9)), 1), "max_us": round(float(lat.max()), 1),
+                "mean_us": round(float(lat.mean()), 1), "frames": len(lat), "period_ms": round(1e3 / 60.0, 3),
+                "histogram_us": {f"<{int(b)}" if b < 1e9 else f">={int(a)}": int(n) for a, b, n in zip(edges[:-1], edges[1:], hist)},
+                "lean_frames": lean, "full_frames": full, "spin_taken": taken, "spin_lost": lost, "replayed": ex["replayed"], "presteps": ex["presteps"],
+                "all_frames": dict(seg(slice(None)), outside_library_us=round(float(host_in.mean()), 1)),
+                "slowest_1pct": dict(seg(slow), outside_library_us=round(float(host_in[slow].mean()), 1), frames=int(slow.sum()),
+                                     library_max_us=round(float(pr[slow, :4].sum(1).max()), 1)),
+                "mode": what,
+                "note": "inputs arrive every 16.67 ms (sleep + spin to the arrival time), latency = arrival -> outputs on the host. wait_us = "
+                        "enqueue done -> completion seen by the polling host (the frame's device time is inside it); outside_library_us = the part "
+                        "of the latency spent before rc_live_step was entered and after it returned (the pacing loop's own wake-up)"}
+
+    lat, lean, full, cap, aql, note, _ = run(frames, {})
     out = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),
            "mean_us": round(float(lat.mean()), 1), "frames": frames, "value": round(1e6 / float(lat.mean()), 1),
            "unit": "body-frames/s", "weight_stream_floor_us": 38.6,
            "lean_frames": lean, "full_frames": full, "launches_per_lean_frame": 7 if cap else None,
            "dispatch": "AQL packet chain on the context's own HSA queue" if aql else ("hipGraphLaunch" + (f" ({note})" if note else "")),
            "workload": "BASELINE config 5: batch 1, captured frame (steady state: seven kernels), host tensors in / out through rc_live_step"}
-    # config 5 as BASELINE states it: 60 fps -- a frame every 16.67 ms, the device idle in between; latency from the frame's arrival
-    paced = run(PACED_FRAMES, {}, 1.0 / 60.0)[0]
-    out["paced_60fps"] = {"p50_us": round(float(np.percentile(paced, 50)), 1), "p99_us": round(float(np.percentile(paced, 99)), 1),
-                          "mean_us": round(float(paced.mean()), 1), "frames": len(paced), "period_ms": round(1e3 / 60.0, 3),
-                          "note": "inputs arrive every 16.67 ms (sleep + spin to the arrival time), latency = arrival -> outputs on the host; "
-                                  "p50_us / p99_us above are the same frames back to back"}
+    out["paced_60fps"] = paced_record({}, "default: idle-time pre-step + armed queue; no kernel left waiting on the device between frames")
+    if aql:
+        out["paced_60fps_spin"] = paced_record({"RC_LIVE_SPIN": "1"}, "RC_LIVE_SPIN=1 (opt-in): the next frame is queued ahead, its first kernel polls a "
+                                               "mailbox on the device until the inputs arrive (~84 workgroups busy between frames)")
     if aql:
         lat2 = run(max(200, frames // 4), {"RC_LIVE_AQL": "0"})[0]
         out["graph_replay"] = {"p50_us": round(float(np.percentile(lat2, 50)), 1), "p99_us": round(float(np.percentile(lat2, 99)), 1),

@@ -191,13 +191,17 @@ int rc_get_live_prestep(rc_ctx* ctx, int64_t* presteps, int32_t* available);
  * L264-271) and the conservative host-side mirror of those flags in rc_live_step did not foresee it. The plan's first kernel checks both on the
  * device; such a frame changes nothing and rc_live_step replays it on the full capture, so the caller only sees a slower frame. Expected: 0. */
 int rc_get_live_replayed(rc_ctx* ctx, int64_t* frames);
-/* RC_LIVE_SPIN=1: rc_live_step launches the first kernel of the NEXT lean frame before it returns; that kernel waits on the device for the
+/* RC_LIVE_SPIN=1 (opt-in since round 6; a back-to-back caller's queue-ahead, RC_LIVE_SPIN_B2B, stays on): rc_live_step launches the first kernel of the NEXT lean frame before it returns; that kernel waits on the device for the
  * frame's inputs, which the next call writes straight into device memory. taken: frames that started from a waiting kernel; lost: waiting
  * kernels sent away (the next frame was not the lean plan's, something touched the state in between) or that gave up after 100 ms. */
 int rc_get_live_spin(rc_ctx* ctx, int64_t* taken, int64_t* lost);
 /* Host time of rc_live_step averaged over the lean frames so far, microseconds: {staging the inputs + choosing the capture, enqueue
  * (hipGraphLaunch), waiting for the frame, copying the outputs}. The frame's GPU time is inside the third. */
 int rc_get_live_profile(rc_ctx* ctx, double* avg_us4);
+/* The same split for the MOST RECENT lean frame, plus {1 if it started from a kernel waiting on the device, 1 if it used a pre-step}:
+ * what bench.py attributes the slowest frames of a paced run with (host wake-up vs device time). Introspection; the reference's
+ * live loop (live_server.py:40-48) has no counterpart. */
+int rc_get_live_last_profile(rc_ctx* ctx, double* us6);
 /* What rc_live_step uses for steady-state frames after rc_live_begin: *lean_captured = the seven-launch capture exists;
  * *aql = its dispatches are pre-built AQL packets on an HSA queue of the context's own (csrc/rc_aql.cpp: ~0.5 us of host time per
  * frame instead of hipGraphLaunch's ~7 us; RC_LIVE_AQL=0 switches it off); note: why not, when it is not (may be NULL). With one row the

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rc_get_live_replayed": (_I32, [_P, _P]),
     "rc_get_live_spin": (_I32, [_P, _P, _P]),
     "rc_get_live_profile": (_I32, [_P, _P]),
+    "rc_get_live_last_profile": (_I32, [_P, _P]),
     "rc_get_live_backend": (_I32, [_P, _P, _P, _P, _I32]),
     "rc_get_fusion_state": (_I32, [_P, _P, _P]),
     "rc_r6d_to_rotmat": (_I32, [_P, _P, _I64, _P]),

@@ -15,7 +15,12 @@
 #include "rc_internal.h"
 
 #include <algorithm>
+#if defined(__x86_64__) || defined(_M_X64)
 #include <immintrin.h>
+#define RC_STORE_FENCE() _mm_sfence()          // posted writes to the device's BAR leave the write-combining buffers in program order
+#else
+#define RC_STORE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#endif
 
 #include <chrono>
 #include <cmath>
@@ -131,7 +136,8 @@ struct rc_ctx {
     // when the caller leaves the device idle between frames (a 60 fps stream: 16.6 ms)
     int live_prestep = 1;                                   // RC_LIVE_PRESTEP: 0 = never
     // RC_LIVE_SPIN: the first kernel of the NEXT lean frame is launched at the end of rc_live_step and waits on the device for the frame (rc_live.hip)
-    bool live_spin = true, live_spin_always = false;        // 1: behind frames of a paced caller (the pre-step's idle rule), 2: behind every lean frame
+    bool live_spin = false, live_spin_always = false;       // RC_LIVE_SPIN (opt-in since round 6: a paced caller's waiting kernel keeps ~84 workgroups polling between frames --
+                                                            // fine on a dedicated box, hostile on a shared one): 1 behind frames of a paced caller, 2 behind every lean frame
     volatile unsigned* spin_mb = nullptr;                   // mailbox, host-writable device memory: [0] command, [16] decision
     float* spin_in = nullptr;                               // the frame's inputs, same allocation
     unsigned* spin_state_h = nullptr;                       // pinned: 3 = the waiting kernel gave up
@@ -158,6 +164,7 @@ struct rc_ctx {
     bool live_blind = false;                                // RC_LIVE_MIRROR_BLIND=1 (tests): no host-side mirror of the transition / init_net flags
     double live_prof_us[4] = {0.0, 0.0, 0.0, 0.0};          // host time of rc_live_step: staging + choice | enqueue | wait | copy out (sums, lean frames)
     long long live_prof_n = 0;
+    double live_prof_last[6] = {0, 0, 0, 0, 0, 0};          // the same split of the most recent lean frame + {started from a waiting kernel, used a pre-step}
     // timing of the gate GEMM launches
     bool timing = false;
     int timing_mode = 1;                 // 1: every gate-GEMM launch, 2: only the wide-tile kernels, 3: only the shared-weight kernel (rc_gemm_lds_kernel)
@@ -236,9 +243,25 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
 
 // Eager work was enqueued on the caller's stream `st`: the next live-graph replay (private stream) must wait for it.
 // (The other direction needs nothing: rc_live_step synchronises its stream before it returns.)
+// A frame queued ahead of its inputs (RC_LIVE_SPIN / the back-to-back queue-ahead: its first kernel polls a mailbox on the device) is sent
+// away and waited for BEFORE anything else touches the context: its kernels change nothing once dismissed (LiveFrame.abort -- K4 skips
+// its relu(linear1) store as well since round 6), but a kernel left polling would hold CUs through a long rc_sequence and leave 100 ms later.
+int dismiss_queued_frame(rc_ctx* ctx) {
+    if (ctx->spin_pending < 0 || !ctx->live_aql || !ctx->spin_mb) return RC_OK;
+    const int par = ctx->spin_pending_par;
+    ctx->spin_mb[32 * par] = 2u;
+    RC_STORE_FENCE();
+    const int arc = rc_aql_wait_frame(ctx->live_aql);
+    ctx->spin_state_h[4 * par] = 0;
+    ctx->stat_live_spin_lost += 1;
+    ctx->spin_pending = -1;
+    return arc == 0 ? RC_OK : fail(ctx, RC_ERR_HIP, "the live frame queued ahead did not leave");
+}
+
 int mark_eager(rc_ctx* ctx, hipStream_t st) {
     ctx->live_pre_valid = false;         // the state the pre-step read is no longer the state the next live frame starts from
     ctx->spin_valid = false;
+    if (int rc = dismiss_queued_frame(ctx)) return rc;
     if (!ctx->eager_ev) return RC_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->eager_ev, st));
     ctx->eager_dirty = true;
@@ -657,6 +680,7 @@ int step_impl(rc_ctx* ctx, const FrameIO& io, uint32_t flags, hipStream_t st, bo
 int flush_pending(rc_ctx* ctx, hipStream_t st) {
     ctx->live_pre_valid = false;
     ctx->spin_valid = false;
+    if (int rc = dismiss_queued_frame(ctx)) return rc;
     if (!ctx->have_weights || !ctx->prm.use_vision_updater) return RC_OK;
     const FrameBuffers& fb = ctx->fb;
     rc_launch_flush_flags(fb, ctx->B, st);
@@ -1331,8 +1355,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->live_prestep = tune_env("RC_LIVE_PRESTEP", 1);
     ctx->live_prestep_idle_us = (double)tune_env("RC_LIVE_PRESTEP_IDLE_US", 500);
     ctx->live_arm = tune_env("RC_LIVE_ARM", 1) != 0;
-    ctx->live_spin = tune_env("RC_LIVE_SPIN", 1) != 0;
-    ctx->live_spin_always = tune_env("RC_LIVE_SPIN", 1) >= 2;
+    ctx->live_spin = tune_env("RC_LIVE_SPIN", 0) != 0;
+    ctx->live_spin_always = tune_env("RC_LIVE_SPIN", 0) >= 2;
     ctx->live_spin_b2b = tune_env("RC_LIVE_SPIN_B2B", 1) != 0;
     ctx->live_blind = tune_env("RC_LIVE_MIRROR_BLIND", 0) != 0;
     ctx->seq_mode = tune_env("RC_SEQ_MODE", 1);          // 0 frame-stepped, 1 plan + cost estimate, 2 wavefront whenever long enough
@@ -1901,7 +1925,7 @@ int rc_live_begin(rc_ctx* ctx) {
                 }
                 // RC_LIVE_SPIN: the same programs once more with the inputs and a mailbox in host-writable device memory; their first
                 // kernel is launched ahead of the frame and waits there (rc_live_k1)
-                if (ctx->live_aql && ctx->live_spin && ctx->aql_prog_lean >= 0 && RC_LIVE_KERNELS * 6 + 8 <= 64) {
+                if (ctx->live_aql && (ctx->live_spin || ctx->live_spin_b2b) && ctx->aql_prog_lean >= 0 && RC_LIVE_KERNELS * 6 + 8 <= 64) {
                     void* shared = nullptr;
                     unsigned* state_d = nullptr;
                     if (rc_aql_alloc_shared(ctx->live_aql, 4096 + B * 171 * sizeof(float), &shared) == 0 &&
@@ -2005,14 +2029,14 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         spin_go = lean && !gone && ctx->spin_valid && ctx->spin_pending == want && !waited_eager;
         if (spin_go) {
             std::memcpy(ctx->spin_in, ctx->live_in_h, B * 171 * sizeof(float));
-            _mm_sfence();
+            RC_STORE_FENCE();
             ctx->spin_mb[32 * par] = 1u;                                    // go: behind the inputs (stores to the device are posted in order; 0.1 us of host time)
-            _mm_sfence();
+            RC_STORE_FENCE();
         } else {
             // skip: the kernel leaves and the six behind it change nothing (LiveFrame.abort); frames on this queue are ordered behind them, a
             // frame on the HIP stream waits for them here (a kernel that has given up is no longer there to read the word)
             ctx->spin_mb[32 * par] = 2u;
-            _mm_sfence();
+            RC_STORE_FENCE();
             if (!(lean && ctx->live_aql) && rc_aql_wait_frame(ctx->live_aql) != 0) return fail(ctx, RC_ERR_HIP, "rc_live_step: the frame queued ahead did not leave");
             ctx->spin_state_h[4 * par] = 0;
             ctx->stat_live_spin_lost += 1;
@@ -2024,7 +2048,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
         const int par = ctx->spin_next_par;
         const int prog = (with_pre && ctx->aql_prog_spin_pre[par] >= 0) ? ctx->aql_prog_spin_pre[par] : ctx->aql_prog_spin[par];
         ctx->spin_mb[32 * par] = 0u; ctx->spin_mb[32 * par + 16] = 0u;
-        _mm_sfence();
+        RC_STORE_FENCE();
         ctx->spin_state_h[4 * par] = 0;
         if (rc_aql_submit_ahead(ctx->live_aql, prog, beside ? 1 : 0) == 0) {
             ctx->spin_pending = prog; ctx->spin_pending_par = par; ctx->spin_pending_seq = rc_aql_seq(ctx->live_aql);
@@ -2060,7 +2084,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
                 // (LiveFrame.abort) -- the frame runs on the ordinary program, in front of which nothing may be waiting
                 ctx->spin_state_h[4 * my_par] = 0;
                 ctx->stat_live_spin_lost += 1;
-                if (ctx->spin_pending >= 0) { ctx->spin_mb[32 * ctx->spin_pending_par] = 2u; _mm_sfence(); ctx->spin_pending = -1; ctx->stat_live_spin_lost += 1; }
+                if (ctx->spin_pending >= 0) { ctx->spin_mb[32 * ctx->spin_pending_par] = 2u; RC_STORE_FENCE(); ctx->spin_pending = -1; ctx->stat_live_spin_lost += 1; }
                 arc = rc_aql_run(ctx->live_aql, plain);
             } else if (spin_go && arc == 0) ctx->stat_live_spin += 1;
             if (arc != 0) {
@@ -2123,7 +2147,7 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
     if (ctx->live_aql && ctx->aql_prog_pre >= 0 && idle_us >= ctx->live_prestep_idle_us) {
         if (rc_aql_submit(ctx->live_aql, ctx->aql_prog_pre) == 0) { ctx->live_pre_valid = true; ctx->stat_live_pre += 1; }
     }
-    if (ctx->live_aql && ctx->aql_prog_spin[0] >= 0 && ctx->spin_pending < 0 && lean && idle_us < 50000.0 && (ctx->live_spin_always || idle_us >= ctx->live_prestep_idle_us)) {
+    if (ctx->live_aql && ctx->live_spin && ctx->aql_prog_spin[0] >= 0 && ctx->spin_pending < 0 && lean && idle_us < 50000.0 && (ctx->live_spin_always || idle_us >= ctx->live_prestep_idle_us)) {
         queue_ahead(ctx->live_pre_valid, false);                            // (RC_LIVE_SPIN) behind this frame and its pre-step
     } else if (ctx->live_aql && ctx->live_arm && ctx->spin_pending < 0 && idle_us >= ctx->live_prestep_idle_us) (void)rc_aql_arm(ctx->live_aql);
     if (lean) {
@@ -2131,8 +2155,12 @@ int rc_live_step(rc_ctx* ctx, const float* j2dc, const float* accc, const float*
             return std::chrono::duration<double, std::micro>(b - a).count();
         };
         ctx->live_prof_us[0] += us(t_in, t_staged); ctx->live_prof_us[1] += us(t_staged, t_enq); ctx->live_prof_us[2] += us(t_enq, t_done);
-        ctx->live_prof_us[3] += us(t_done, std::chrono::steady_clock::now());
+        const auto t_out = std::chrono::steady_clock::now();
+        ctx->live_prof_us[3] += us(t_done, t_out);
         ctx->live_prof_n += 1;
+        ctx->live_prof_last[0] = us(t_in, t_staged); ctx->live_prof_last[1] = us(t_staged, t_enq);
+        ctx->live_prof_last[2] = us(t_enq, t_done); ctx->live_prof_last[3] = us(t_done, t_out);
+        ctx->live_prof_last[4] = spin_go ? 1.0 : 0.0; ctx->live_prof_last[5] = use_pre ? 1.0 : 0.0;
     }
     ctx->live_last_return = std::chrono::steady_clock::now();
     ctx->live_have_return = true;
@@ -2167,6 +2195,11 @@ int rc_get_live_replayed(rc_ctx* ctx, int64_t* frames) {
     return RC_OK;
 }
 
+int rc_get_live_last_profile(rc_ctx* ctx, double* us6) {
+    if (!ctx || !us6) return RC_ERR_INVALID;
+    for (int q = 0; q < 6; ++q) us6[q] = ctx->live_prof_last[q];
+    return RC_OK;
+}
 int rc_get_live_profile(rc_ctx* ctx, double* avg_us4) {
     if (!ctx || !avg_us4) return RC_ERR_INVALID;
     for (int q = 0; q < 4; ++q) avg_us4[q] = ctx->live_prof_n ? ctx->live_prof_us[q] / (double)ctx->live_prof_n : 0.0;

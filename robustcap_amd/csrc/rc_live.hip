@@ -371,7 +371,9 @@ extern "C" __global__ __launch_bounds__(256) void rc_live_k4(const LiveFrame F) 
     }
     __syncthreads();
     RC_LT(1, 3);
-    lin1_tile(w, n, H, 256, n_tile, B, s_x, s_part, tid);
+    // (a frame K1 took off the lean plan, or one dismissed while it was queued ahead, writes NOTHING: relu(linear1) lives in buffers rc_step /
+    // rc_sequence use between their own linear1 and LSTM launches)
+    if (!off_plan) lin1_tile(w, n, H, 256, n_tile, B, s_x, s_part, tid);
     RC_LT(1, 4);
 }
 

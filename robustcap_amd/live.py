@@ -1,7 +1,8 @@
 """Live streaming front-end: the wire formats and the per-packet loop of the reference's ``live_server.py`` so that
 its own detector / IMU processes (live_detector.py, live_demo_sync.py) can drive the MI355X path unchanged.
 
-Wire formats (all ASCII text):
+Wire formats (ASCII text, except the IMU bridge's binary datagram):
+  IMU bridge -> sync process, UDP (live_demo_sync.py:262-268): 8 N float32 values [t x N | q x 4N | a x 3N] (parse_imu_packet).
   detector -> server, UDP 127.0.0.1:9999 (live_detector.py:57-61):  "uv#ori#acc#RCM" where each field is a
       comma-separated list of floats: uv 33x3 (x/z, y/z, visibility), ori 6x3x3, acc 6x3, RCM 3x3.
   server -> Unity, TCP 127.0.0.1:8888 (live_server.py:57-59):  "%g,"-joined 72 axis-angle values '#' 3 translation
@@ -36,6 +37,24 @@ def format_detector_packet(uv, ori, acc, rcm):
     """(live_detector.py:57-60) what the detector process sends; numpy float32 str() per element."""
     j = lambda a: ",".join(str(i) for i in np.asarray(a, np.float32).reshape(-1))
     return (j(uv) + "#" + j(ori) + "#" + j(acc) + "#" + j(rcm)).encode()
+
+
+def parse_imu_packet(data, n_imus):
+    """One UDP datagram of the IMU bridge (live_demo_sync.py:262-268 ``get_from_udp``): 8 N little-endian float32 values
+    ``[t x N | q x 4N | a x 3N]`` = per-sensor time stamps, orientation quaternions (N x 4, sensor order, w first as the Xsens Dot
+    SDK sends them) and accelerations (N x 3). Returns (t list[float], q [N, 4], a [N, 3]); raises ValueError on a datagram of
+    another length (the reference would fail in ``reshape``)."""
+    n = int(n_imus)
+    buf = np.frombuffer(data, np.float32)
+    if buf.size != 8 * n:
+        raise ValueError(f"IMU packet: {buf.size} float32 values, expected {8 * n} for {n} sensors")
+    buf = buf.copy()
+    return buf[:n].tolist(), torch.from_numpy(buf[n:5 * n].reshape(n, 4)), torch.from_numpy(buf[5 * n:].reshape(n, 3))
+
+
+def format_imu_packet(t, q, a):
+    """What the bridge sends (the inverse of parse_imu_packet): bytes of the float32 values [t | q | a]."""
+    return np.concatenate([np.asarray(t, np.float32).reshape(-1), np.asarray(q, np.float32).reshape(-1), np.asarray(a, np.float32).reshape(-1)]).tobytes()
 
 
 def format_unity_packet(pose_axis_angle, tran):

@@ -277,8 +277,8 @@ def test_prestep_frames_equal_plain_lean_frames(path, synth_assets, monkeypatch)
     outs = []
     # (the second leg also leaves the queue armed behind every frame -- rc_aql_arm, a barrier packet the next push releases; the first never)
     # ... and queues the NEXT frame ahead behind every lean frame, its first kernel waiting on the device for the inputs (RC_LIVE_SPIN)
-    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN"):
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0", "RC_LIVE_SPIN_B2B": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "1"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN", "RC_LIVE_SPIN_B2B"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -328,9 +328,9 @@ def test_prestep_is_discarded_by_whatever_touches_the_state(synth_assets, monkey
     outs = []
     # third leg: the armed queue alone (a barrier packet behind every frame, no pre-step), through the same script
     # fourth: the frame queued ahead alone (no pre-step): reset, eager steps, pokes and reloads send the waiting kernel away
-    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0"},
-                {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "0"}, {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0"}):
-        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN"):
+    for env in ({"RC_LIVE_PRESTEP": "0", "RC_LIVE_ARM": "0", "RC_LIVE_SPIN": "0", "RC_LIVE_SPIN_B2B": "0"}, {"RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "1"},
+                {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "0", "RC_LIVE_SPIN_B2B": "0"}, {"RC_LIVE_PRESTEP": "0", "RC_LIVE_PRESTEP_IDLE_US": "0", "RC_LIVE_SPIN": "1"}):
+        for k in ("RC_LIVE_PRESTEP", "RC_LIVE_PRESTEP_IDLE_US", "RC_LIVE_ARM", "RC_LIVE_SPIN", "RC_LIVE_SPIN_B2B"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

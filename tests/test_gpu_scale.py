@@ -89,6 +89,68 @@ def test_config2_rows_equal_single_sequence_runs_and_oracle(cfg2, synth_assets):
         assert float((ob.forward_kinematics(gp, gt)[1] - ob.forward_kinematics(p, tr)[1]).abs().max()) <= 1e-4, i
 
 
+def _trace8(ora, conf_lo=0.7, conf_hi=0.8):
+    """The oracle's per-row branch record of its last frame in rc_get_trace's layout: {regime, rnn4 steps, rnn6 steps, floor samples
+    held, reach fired, used velocity branch, stance foot, jump reset}."""
+    tr = ora.trace
+    c = tr["c"].double()
+    regime = (c > conf_lo).long() + (c >= conf_hi).long()
+    cols = [regime, tr["n4"].long(), tr["n6"].long(), tr["n_floor"].long(), tr["reach"].long(), tr["use_vel"].long(), tr["foot"].long(), tr["far"].long()]
+    return torch.stack([x.reshape(-1) for x in cols], 1)
+
+
+def test_config2_two_rows_against_the_oracle_over_all_512_frames(cfg2, synth_assets):
+    """Round-5 review: the oracle comparison of the full-size run covered 64 of its 512 frames. Here every frame of two rows of the
+    256 x 512 run (split products, wavefront engine, rows lagging through their occlusions) against the CPU restatement stepping the
+    same two sequences frame by frame: the only place where long-horizon drift AT BATCH is compared with the oracle, not with itself."""
+    from oracle import sig_mp_oracle as O
+    m, pose, tran = cfg2
+    rows = [9, 40]
+    ora = O.OracleNet(synth_assets["body"], batch=len(rows))
+    ora.load_numpy_state_dict(synth_assets["state_dict"])
+    ora.gravityc = t(m["gravityc"][rows])
+    ob = O.OracleBody(synth_assets["body"])
+    T = pose.shape[1]
+    worst = [0.0, 0.0, 0.0]
+    for i in range(T):
+        p, tr = ora.forward_batch(t(m["j2dc"][rows, i]), t(m["accc"][rows, i]), t(m["oric"][rows, i]),
+                                  t(m["first_tran"][rows]) if i == 0 else None)
+        gp, gt = pose[rows, i].cpu(), tran[rows, i].cpu()
+        worst[0] = max(worst[0], float((gt - tr).abs().max()))
+        worst[1] = max(worst[1], float(O.rotation_angle_deg(gp, p).max()))
+        if i % 8 == 0 or i == T - 1:
+            worst[2] = max(worst[2], float((ob.forward_kinematics(gp, gt)[1] - ob.forward_kinematics(p, tr)[1]).abs().max()))
+    assert worst[0] <= 1e-4 and worst[1] <= 0.1 and worst[2] <= 1e-4, worst
+    conf = m["conf"][rows]
+    assert all((c <= 0.7).mean() > 0.15 and (c >= 0.8).mean() > 0.3 for c in conf)       # both rows really change regime on the way
+
+
+def test_config4_rows_against_the_oracle_at_batch_1024(synth_assets):
+    """BASELINE config 4 at its own size (batch 1024, occlusion-masked keypoints): four sampled rows x 48 frames of the full run against
+    the CPU restatement (1e-4 m / 0.1 deg, joints 1e-4 m), and the branch record of their last frame."""
+    from oracle import sig_mp_oracle as O
+    B, T = 1024, 48
+    m = _inputs(synth_assets, B, T, "occ", 4)
+    net = _net(synth_assets, B)
+    pose, tran = _run(net, m, first_tran=False)
+    torch.cuda.synchronize()
+    low_any = (m["conf"] <= 0.7).any(1) & (m["conf"] > 0.7).any(1)                       # rows that enter or leave an occlusion inside the call
+    rows = [int(r) for r in np.flatnonzero(low_any)[[0, 5, -7, -1]]]
+    ora = O.OracleNet(synth_assets["body"], batch=len(rows))
+    ora.load_numpy_state_dict(synth_assets["state_dict"])
+    ora.gravityc = t(m["gravityc"][rows])
+    ob = O.OracleBody(synth_assets["body"])
+    for i in range(T):
+        p, tr = ora.forward_batch(t(m["j2dc"][rows, i]), t(m["accc"][rows, i]), t(m["oric"][rows, i]), None, i == 0)
+        gp, gt = pose[rows, i].cpu(), tran[rows, i].cpu()
+        assert float((gt - tr).abs().max()) <= 1e-4, i
+        assert float(O.rotation_angle_deg(gp, p).max()) <= 0.1, i
+        assert float((ob.forward_kinematics(gp, gt)[1] - ob.forward_kinematics(p, tr)[1]).abs().max()) <= 1e-4, i
+    got = net.get_trace()[rows].long()
+    want = _trace8(ora)
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+
+
 def test_config4_occluded_batch_1024(synth_assets):
     B, T = 1024, 48
     m = _inputs(synth_assets, B, T, "occ", 4)

@@ -1,5 +1,6 @@
 """Wire formats of the live front-end (CPU): packet parse/format round trip and the Unity string of live_server.py."""
 import numpy as np
+import pytest
 import torch
 
 from robustcap_amd import live
@@ -43,3 +44,20 @@ def test_session_logic_with_a_stand_in_net(monkeypatch):
     assert out1.endswith(b"#0,0,0$")                                         # translation relative to its first value
     t2 = [float(v) for v in out2[:-1].split(b"#")[1].split(b",")]
     assert np.allclose(t2, rcm.T @ np.array([1.0, 2.0, 3.0]))                # RCM^T (tran_2 - tran_1)
+
+
+def test_imu_udp_packet_round_trip_and_layout():
+    """live_demo_sync.py:262-268: [t x N | q x 4N | a x 3N] float32, 32 N bytes per datagram."""
+    from robustcap_amd import live
+    rng = np.random.default_rng(3)
+    for n in (1, 6):
+        t, q, a = rng.random(n).astype(np.float32), rng.standard_normal((n, 4)).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+        data = live.format_imu_packet(t, q, a)
+        assert len(data) == 32 * n
+        raw = np.frombuffer(data, np.float32)                               # the reference's own slicing
+        assert np.array_equal(raw[:n], t) and np.array_equal(raw[n:5 * n].reshape(n, 4), q) and np.array_equal(raw[5 * n:].reshape(n, 3), a)
+        t2, q2, a2 = live.parse_imu_packet(data, n)
+        assert t2 == t.tolist() and torch.equal(q2, torch.from_numpy(q)) and torch.equal(a2, torch.from_numpy(a))
+        assert q2.dtype == torch.float32 and q2.shape == (n, 4) and a2.shape == (n, 3)
+    with pytest.raises(ValueError):
+        live.parse_imu_packet(b"\0" * 28, 1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce the rocprofv3 --pmc databases written by tools/pmc_traffic.sh to fabric-side bytes per launch of the dominant
-kernel (the wide-tile gate GEMM: rc_gemm_split_kernel, or rc_gemm_kernel in fp32-MFMA mode), keyed by the workload
+kernel (the shared-weight kernel of the LSTM layer steps rc_gemm_lds_kernel where it runs, else the wide-tile gate GEMM rc_gemm_split_kernel / rc_gemm_kernel), keyed by the workload
 (batch, confidence schedule, frames per call) so that bench.py only quotes it for the run it belongs to.
     python tools/pmc_traffic.py gpurun_out/pmc128 [batch] [conf] [steps] > profiles/rNN_pmc_traffic_steps128.json"""
 import glob
@@ -36,7 +36,7 @@ for tag, cs in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), 
         res.update(per_launch(tag, cs))
     except Exception as e:  # noqa: BLE001
         print("pass", tag, "failed:", e, file=sys.stderr)
-wide = next((k for k in ("rc_gemm_split_kernel", "rc_gemm_kernel") if k in res.get("FETCH_SIZE", {})), None)
+wide = next((k for k in ("rc_gemm_lds_kernel", "rc_gemm_split_kernel", "rc_gemm_kernel") if k in res.get("FETCH_SIZE", {})), None)
 if wide and wide in res.get("WRITE_SIZE", {}):
     f, n = res["FETCH_SIZE"][wide]
     w, _ = res["WRITE_SIZE"][wide]
