@@ -368,7 +368,9 @@ def live_b1(sd, body, frames=2000):
         pr = ex["prof"]
         host_in = lat - pr[:, :4].sum(1)                                    # arrival -> rc_live_step entered + return -> clock read: the caller's side
         slow = lat >= np.percentile(lat, 99)
-        seg = lambda sel: {k: round(float(v), 1) for k, v in zip(("stage_us", "enqueue_us", "wait_us", "copy_out_us"), pr[sel, :4].mean(0))}
+        def seg(sel):                                                       # (the AQL path submits and polls in one call: its time is `frame_us`)
+            a = pr[sel, :4].mean(0)
+            return {"stage_us": round(float(a[0]), 1), "frame_us": round(float(a[1] + a[2]), 1), "copy_out_us": round(float(a[3]), 1)}
         edges = [0, 60, 70, 80, 90, 100, 125, 150, 200, 400, 1e9]
         hist = np.histogram(lat, bins=edges)[0]
         taken, lost = ex["spin"]
@@ -381,9 +383,11 @@ def live_b1(sd, body, frames=2000):
                 "slowest_1pct": dict(seg(slow), outside_library_us=round(float(host_in[slow].mean()), 1), frames=int(slow.sum()),
                                      library_max_us=round(float(pr[slow, :4].sum(1).max()), 1)),
                 "mode": what,
-                "note": "inputs arrive every 16.67 ms (sleep + spin to the arrival time), latency = arrival -> outputs on the host. wait_us = "
-                        "enqueue done -> completion seen by the polling host (the frame's device time is inside it); outside_library_us = the part "
-                        "of the latency spent before rc_live_step was entered and after it returned (the pacing loop's own wake-up)"}
+                "note": "inputs arrive every 16.67 ms (sleep + spin to the arrival time), latency = arrival -> outputs on the host. Host split of "
+                        "rc_live_step (rc_get_live_last_profile): stage_us = inputs staged + capture chosen, frame_us = packets pushed -> completion "
+                        "seen by the polling host (the frame's device time is inside it), copy_out_us; outside_library_us = the part of the latency "
+                        "spent before rc_live_step was entered and after it returned (the pacing loop's own wake-up); library_max_us = the longest "
+                        "time any of the slowest frames spent inside the library"}
 
     lat, lean, full, cap, aql, note, _ = run(frames, {})
     out = {"p50_us": round(float(np.percentile(lat, 50)), 1), "p99_us": round(float(np.percentile(lat, 99)), 1),

@@ -115,6 +115,11 @@ SIGNATURES = {
 _lib = None
 
 
+# entry points newer than round 4: the only ones an A/B library under RC_LIB_PATH may lack
+OPTIONAL_IN_AB_BUILDS = frozenset({"rc_get_launch_stats", "rc_get_live_spin", "rc_get_live_replayed", "rc_get_live_profile", "rc_get_live_last_profile",
+                                   "rc_get_live_prestep"})
+
+
 def load():
     """Load the shared library once and attach prototypes. Raises RobustcapLibraryError if it is absent."""
     global _lib
@@ -128,12 +133,22 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RobustcapLibraryError(f"cannot load {LIB_PATH}: {e}") from e
-    ab_build = bool(os.environ.get("RC_LIB_PATH"))     # an A/B build of another revision (tools/ab.py) may lack the newest entry points
+    # A library under RC_LIB_PATH (tools/ab.py: an A/B build of an older revision) may lack entry points added since -- but only those on the
+    # allow-list below, and it says so; anything else missing is a header / library mismatch and fails HERE, not at the first call.
+    ab_build = bool(os.environ.get("RC_LIB_PATH"))
+    skipped = []
     for name, (res, args) in SIGNATURES.items():
-        if ab_build and not hasattr(lib, name):
+        if ab_build and name in OPTIONAL_IN_AB_BUILDS and not hasattr(lib, name):
+            skipped.append(name)
             continue
-        fn = getattr(lib, name)            # AttributeError here = header / library mismatch: fail loudly
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RobustcapLibraryError(f"{LIB_PATH} does not export {name}: the library does not match include/robustcap_hip.h") from e
         fn.restype, fn.argtypes = res, args
+    if skipped:
+        import warnings
+        warnings.warn(f"RC_LIB_PATH={LIB_PATH}: entry points missing in this build (calls to them will fail): {', '.join(skipped)}")
     _lib = lib
     return lib
 

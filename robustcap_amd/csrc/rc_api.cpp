@@ -29,6 +29,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 // From this batch on a context defaults to the split-bf16 products. Round 2 (frame-stepped launches only) put the break-even
@@ -271,17 +272,30 @@ int mark_eager(rc_ctx* ctx, hipStream_t st) {
 // MFMA-B fragment order (v_mfma_f32_16x16x4_f32): for 16-column block cb and 16-wide k-chunk q, lane l = kq*16 + j
 // holds the float4 W'[cb*16 + j][16q + 4kq + 0..3]; blocks are laid out [cb][q][lane][4] so that a wave's K slice of
 // a column block is one contiguous stream of 1 KiB pieces. getW(n, k) returns the (padded) logical weight W'[n][k].
+// (both packings run over the 16-column blocks on up to 8 host threads: a context packs 63 M weights twice, ~3.5 s on one thread,
+// and bench.py / the tests create a dozen contexts)
+template <typename Body>
+void for_column_blocks(int n_cb, Body body) {
+    const int nt = std::max(1, std::min({8, n_cb / 8, (int)std::thread::hardware_concurrency()}));
+    if (nt <= 1) { for (int cb = 0; cb < n_cb; ++cb) body(cb); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([=] { for (int cb = t; cb < n_cb; cb += nt) body(cb); });
+    for (std::thread& x : th) x.join();
+}
+
 template <typename F>
 std::vector<float> pack_weights(int Np, int Kp, F getW) {
     std::vector<float> out((size_t)Np * Kp);
     const int Q = Kp / RC_KC;
-    for (int cb = 0; cb < Np / 16; ++cb)
+    for_column_blocks(Np / 16, [&](int cb) {
         for (int q = 0; q < Q; ++q)
             for (int l = 0; l < 64; ++l) {
                 const int kq = l >> 4, j = l & 15;
                 float* d = &out[(((size_t)cb * Q + q) * 64 + l) * 4];
                 for (int s = 0; s < 4; ++s) d[s] = getW(cb * 16 + j, RC_KC * q + 4 * kq + s);
             }
+    });
     return out;
 }
 
@@ -293,7 +307,7 @@ template <typename F>
 std::vector<uint16_t> pack_weights_split(int Np, int Kp, F getW) {
     std::vector<uint16_t> out((size_t)Np * Kp * 3);
     const int Qs = Kp / 32;
-    for (int cb = 0; cb < Np / 16; ++cb)
+    for_column_blocks(Np / 16, [&](int cb) {
         for (int kb = 0; kb < Qs; ++kb)
             for (int l = 0; l < 64; ++l) {
                 const int kq = l >> 4, j = l & 15;
@@ -320,6 +334,7 @@ std::vector<uint16_t> pack_weights_split(int Np, int Kp, F getW) {
                     out[base + 1024] = (uint16_t)(u2 >> 16);
                 }
             }
+    });
     return out;
 }
 

@@ -252,7 +252,11 @@ static void aql_push(AqlChain* c, const AqlProgram& P, int i0 = 0, int i1 = -1, 
     hsa_queue_t* q = c->q;
     if (i1 < 0) i1 = P.n;
     const uint32_t mask = q->size - 1;
-    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer; at most one frame + one background program are in the ring
+    const uint64_t base = hsa_queue_load_write_index_relaxed(q);           // single producer
+    // The ring may hold an armed barrier, a pre-step (1-2 packets), a dismissed queued-ahead frame (7), the plain frame (7), a frame queued
+    // ahead for a back-to-back caller (7) and a fence: ~25 of its 64 slots. Never write over a packet the processor has not consumed: wait for
+    // the read index (a stalled packet processor then shows as a frame that does not complete -- rc_live_step's timeout -- not as corruption).
+    while (base + (uint64_t)(i1 - i0) - hsa_queue_load_read_index_scacquire(q) > (uint64_t)q->size) { }
     for (int i = i0; i < i1; ++i) {
         hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((base + (i - i0)) & mask);
         std::memcpy((char*)p + 4, (const char*)&P.pkt[i] + 4, sizeof(*p) - 4);
