@@ -154,6 +154,16 @@ int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_fr
  * nothing in the reference: its per-frame loop (net/sig_mp.py:126-129) has no launch structure to mirror; this is introspection for
  * bench.py and the tests. (Round 5 counted its one-launch-per-tick kernel in the first slot; removed, profiles/r06_tick_path_removed.diff.) */
 int rc_get_launch_stats(rc_ctx* ctx, int64_t* lds_launches, int64_t* other_wide_launches);
+/* Resident layer-step kernel of the wavefront engine (round 6; north_star: "fused persistent kernel ... across timesteps"). With enable != 0
+ * a planned rc_sequence call of a context of 160 .. 256 rows in split-product mode runs the LSTM layer steps AND the linear1 layers of
+ * ALL its ticks (net/sig_mp.py:126-129 over every frame of the call; articulate/utils/torch/rnn.py:129-133 is the reference's own
+ * whole-sequence form) in ONE launch of `workgroups` (<= 224; 0 keeps the current value) resident workgroups that take work items from a
+ * queue in device memory, ordered by counters instead of stream events; prep / linear2 / fuse / tail stay launches of the second stream.
+ * Results are bitwise those of the stream engine. Default off (RC_SEQ_RESIDENT=1 switches it on at rc_create): measured slower than the
+ * three-stream ticks. A wait inside the kernel that runs out (RC_SEQ_RESIDENT_BOUND_MS, 2000) marks the call failed: the NEXT
+ * rc_sequence returns RC_ERR_STATE once and counts an abort. rc_get_resident_stats: segments run / aborts seen (either may be NULL). */
+int rc_set_resident(rc_ctx* ctx, int32_t enable, int32_t workgroups);
+int rc_get_resident_stats(rc_ctx* ctx, int64_t* segments, int64_t* aborts);
 int rc_plan_sequence(const int8_t* codes, int32_t B, int32_t T, const int32_t* pend, uint32_t flags, int32_t use_vision_updater,
                      uint8_t* mode_out);
 int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const int32_t* first_reach, const int32_t* pend,

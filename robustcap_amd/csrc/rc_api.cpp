@@ -216,6 +216,16 @@ struct rc_ctx {
     int* lds_tickets = nullptr;          // [kLdsRegions][lds_region_tiles]
     size_t lds_region_tiles = 0;
     unsigned lds_rot = 0;
+    // resident layer-step kernel of the wavefront engine (run_wave2_segment: `resident`)
+    ResidentTick* res_ticks_d = nullptr;     // [res_cap]
+    ResidentTick* res_ticks_h = nullptr;     // pinned
+    int* res_ints_d = nullptr;               // item_base [res_cap + 1] | done [res_cap][RC_RES_MAXP] | tick_done [res_cap] | head, flag_l1, flag_tail, abort
+    int* res_base_h = nullptr;               // pinned: item_base
+    int* res_abort_h = nullptr;              // pinned: the abort word of the last segment
+    size_t res_cap = 0;
+    long long stat_resident_segments = 0, stat_resident_aborts = 0;
+    bool resident_on = false;                // rc_set_resident / RC_SEQ_RESIDENT
+    int resident_wgs = 224;                  // workgroups of the resident kernel (RC_SEQ_RESIDENT_WGS; the CUs it leaves run the second stream)
     long long stat_lds_launches = 0;
 };
 
@@ -490,7 +500,7 @@ const int kLdsRegions = 12;               // launches whose half sums can be in 
 int ensure_lds_pool(rc_ctx* ctx) {
     if (ctx->lds_slab) return RC_OK;
     const size_t m_tiles = ((size_t)ctx->B + 255) / 256;
-    const size_t tiles = 272 * m_tiles;    // all twelve layer steps in one launch: 2 x (40 + 32 + 4 x 16) column tiles per row tile
+    const size_t tiles = 320 * m_tiles;    // all twelve layer steps in one launch: 2 x (40 + 32 + 4 x 16) column tiles per row tile; + 34 of linear1 (resident kernel)
     HIP_TRY(ctx, hipMalloc((void**)&ctx->lds_slab, (size_t)kLdsRegions * tiles * RC_LDS_SLAB_FLOATS * sizeof(float)));
     ctx->allocs.push_back(ctx->lds_slab);
     HIP_TRY(ctx, hipMalloc((void**)&ctx->lds_tickets, (size_t)kLdsRegions * tiles * sizeof(int)));
@@ -511,33 +521,69 @@ bool timing_pair(rc_ctx* ctx, hipEvent_t** a, hipEvent_t** b) {
     return true;
 }
 
-// LSTM layer steps on the shared-weight kernel (rc_gemm_lds.hip): problems marked mr = 16
-int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, hipStream_t st, hipEvent_t stop, bool* launched) {
-    if (int rc = ensure_lds_pool(ctx)) return rc;
-    LdsLaunch L{};
-    L.B = ctx->B; L.n = (int)ps.size();
-    const size_t region = ctx->lds_rot++ % kLdsRegions;
-    float* slab = ctx->lds_slab + region * ctx->lds_region_tiles * RC_LDS_SLAB_FLOATS;
-    int* tickets = ctx->lds_tickets + region * ctx->lds_region_tiles;
-    // longest items first (K' = 2560 rnn4, 2048 rnn6, 1024 the H = 512 nets): the launch ends on short ones
+// The problems `ps` (LSTM layer steps; for the resident kernel also relu(linear1)) as ONE launch of the shared-weight kernel: longest items
+// first, every problem's item range padded to a multiple of 8; *items = work items (workgroups) of the launch, *tiles = slab tiles it uses.
+// resident_order: the linear1 items between the rnn4 / rnn6 items and those of the H = 512 nets (run_wave2_segment).
+int build_lds_problems(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, float* slab, int* tickets,
+                       LdsProblem* out, int max_p, int* items, size_t* tiles_out, bool resident_order = false) {
     std::vector<GemmProblem> ord(ps);
-    std::stable_sort(ord.begin(), ord.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.Kp > b.Kp; });
+    auto key = [&](const GemmProblem& g) -> int {
+        if (g.epi == RC_EPI_LSTM) return (resident_order && g.H == 512) ? 0 : g.Kp;
+        return 1;                                                              // linear1: K' = 128 / 256
+    };
+    std::stable_sort(ord.begin(), ord.end(), [&](const GemmProblem& a, const GemmProblem& b) { return key(a) > key(b); });
+    if ((int)ord.size() > max_p) return 0;
     int base = 0;
     size_t tiles = 0;
     for (size_t i = 0; i < ord.size(); ++i) {
         const GemmProblem& g = ord[i];
-        LdsProblem& p = L.p[i];
+        LdsProblem& p = out[i];
+        p = LdsProblem{};
         p.seg[0] = g.seg[0]; p.seg[1] = g.seg[1];
         p.Ws = g.Ws; p.bias = g.bias; p.hstate = g.hstate; p.cstate = g.cstate; p.steps = g.steps;
         p.flags = flags_override ? flags_override : g.flags; p.flag_bit = g.flag_bit;
         p.h_par_stride = g.h_par_stride; p.H = g.H; p.step_off = g.step_off;
-        p.n_tiles = g.H / 32; p.m_tiles = g.m_tiles; p.Qs = g.Kp / 32;
-        p.ksplit = ctx->lds_ksplit[g.H == 512 ? 0 : (g.H == 1024 ? 1 : 2)];
+        p.m_tiles = g.m_tiles; p.Qs = g.Kp / 32;
+        p.epi = g.epi;
+        if (g.epi == RC_EPI_LSTM) {
+            p.n_tiles = g.H / 32;
+            p.ksplit = ctx->lds_ksplit[g.H == 512 ? 0 : (g.H == 1024 ? 1 : 2)];
+        } else {
+            // relu(linear1): ONE input of K' columns as two halves (rc_pk: 16 columns = 256 floats further)
+            const long long half = (long long)(g.Kp / 32) * 256;
+            p.seg[0].K = g.Kp / 2;
+            p.seg[1] = p.seg[0]; p.seg[1].base = g.seg[0].base + half;
+            p.alt[0] = g.alt_base; p.alt[1] = g.alt_base ? g.alt_base + half : nullptr;
+            p.sel_flags = g.sel_flags; p.sel_bit = g.alt_base ? g.sel_bit : 0;
+            p.out = g.out; p.ldo = g.ldo;
+            p.n_tiles = g.N / 128;
+            p.ksplit = 1;
+        }
         p.wg_base = base;
         p.slab = slab + tiles * RC_LDS_SLAB_FLOATS; p.tickets = tickets + tiles;
         tiles += (size_t)p.n_tiles * p.m_tiles;
         base += round_up(p.n_tiles * p.m_tiles * p.ksplit, 8);
     }
+    *items = base; *tiles_out = tiles;
+    return (int)ord.size();
+}
+void build_lds_launch(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, float* slab, int* tickets,
+                      LdsLaunch& L, int* items, size_t* tiles_out) {
+    L = LdsLaunch{};
+    L.B = ctx->B;
+    L.n = build_lds_problems(ctx, ps, flags_override, slab, tickets, L.p, RC_LDS_MAXP, items, tiles_out);
+}
+
+// LSTM layer steps on the shared-weight kernel (rc_gemm_lds.hip): problems marked mr = 16
+int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, hipStream_t st, hipEvent_t stop, bool* launched) {
+    if (int rc = ensure_lds_pool(ctx)) return rc;
+    LdsLaunch L{};
+    const size_t region = ctx->lds_rot++ % kLdsRegions;
+    float* slab = ctx->lds_slab + region * ctx->lds_region_tiles * RC_LDS_SLAB_FLOATS;
+    int* tickets = ctx->lds_tickets + region * ctx->lds_region_tiles;
+    int base = 0;
+    size_t tiles = 0;
+    build_lds_launch(ctx, ps, flags_override, slab, tickets, L, &base, &tiles);
     if (tiles > ctx->lds_region_tiles) return fail(ctx, RC_ERR_INVALID, "shared-weight launch: more tiles than its slab region holds");
     ctx->stat_lds_launches += 1;
     if (ctx->timing) {
@@ -554,12 +600,89 @@ int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned c
     return RC_OK;
 }
 
+// RC_DBG_DENSE_ITEMS=1 -- self-test of the resident kernel's relu(linear1) items (tests/test_gpu_resident.py): every linear1 launch of the
+// frame-stepped path first runs as ONE tick of the resident kernel, then as the launch of the wide-tile kernel it is; the two results
+// must agree bit for bit wherever the launch wrote (stderr: one line per problem).
+bool dense_items_selftest_wanted(rc_ctx* ctx, const std::vector<GemmProblem>& ps, hipStream_t st, bool fp32) {
+    static const int on = std::getenv("RC_DBG_DENSE_ITEMS") ? std::atoi(std::getenv("RC_DBG_DENSE_ITEMS")) : 0;
+    if (!on || !ctx->gemm_split || fp32 || ctx->B > 256 || st == ctx->aux_stream || (int)ps.size() > RC_RES_MAXP) return false;
+    for (const GemmProblem& p : ps)
+        if (!(p.epi == RC_EPI_RELU && p.out_packed && p.N % 128 == 0 && p.Kp % 128 == 0 && p.out_bit == 0 && p.out_col0 == 0 && p.seg[0].par_mode == 0)) return false;
+    return true;
+}
+int dense_items_selftest(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, hipStream_t st) {
+    if (int rc = ensure_lds_pool(ctx)) return rc;
+    static ResidentTick* tk_d = nullptr;
+    static int* ints_d = nullptr;
+    const int n_ints = 2 + RC_RES_MAXP + 1 + 4;
+    if (!tk_d) { HIP_TRY(ctx, hipMalloc((void**)&tk_d, sizeof(ResidentTick))); HIP_TRY(ctx, hipMalloc((void**)&ints_d, n_ints * sizeof(int))); }
+    ResidentTick T{};
+    std::vector<GemmProblem> q(ps);
+    for (GemmProblem& p : q) p.m_tiles = 1;
+    size_t tiles = 0;
+    T.B = ctx->B;
+    T.n = build_lds_problems(ctx, q, flags_override, ctx->lds_slab, ctx->lds_tickets, T.p, RC_RES_MAXP, &T.n_items, &tiles, true);
+    for (int i = 0; i < RC_RES_MAXP; ++i) T.dep[i][0] = T.dep[i][1] = -1;
+    const int base[2] = {0, T.n_items};
+    const size_t Bp = (size_t)ctx->Bp;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (const GemmProblem& p : ps) HIP_TRY(ctx, hipMemset(p.out, 0xff, Bp * p.N * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpy(tk_d, &T, sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ints_d, 0, n_ints * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(ints_d, base, sizeof(base), hipMemcpyHostToDevice));
+    ResidentArgs R{};
+    R.ticks = tk_d; R.item_base = ints_d; R.n_ticks = 1;
+    R.done = ints_d + 2; R.tick_done = ints_d + 2 + RC_RES_MAXP; R.head = ints_d + 3 + RC_RES_MAXP; R.flag_tail = R.head + 1; R.abort = R.head + 2;
+    R.spin_bound = 100000ull * 100;
+    rc_launch_gemm_resident(R, 64, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::vector<std::vector<float>> got(ps.size());
+    for (size_t i = 0; i < ps.size(); ++i) {
+        got[i].resize(Bp * ps[i].N);
+        HIP_TRY(ctx, hipMemcpy(got[i].data(), ps[i].out, got[i].size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemset(ps[i].out, 0xff, got[i].size() * sizeof(float)));
+    }
+    {   // the launch itself (it also opens the step)
+        GemmLaunch L{};
+        L.B = ctx->B; L.split = 1; L.live = ctx->live_launch ? 1 : 0;
+        int wg = 0;
+        std::vector<GemmProblem> ordered;
+        for (auto& p : ps) if ((p.n_tiles & 7) == 0) ordered.push_back(p);
+        for (auto& p : ps) if ((p.n_tiles & 7) != 0) ordered.push_back(p);
+        for (size_t i = 0; i < ordered.size(); ++i) {
+            ordered[i].wg_base = wg;
+            if (flags_override) ordered[i].flags = flags_override;
+            wg += round_up(ordered[i].n_tiles * ordered[i].m_tiles, 8);
+            ordered[i].trace_base = ctx->trace_next;
+            L.p[i] = ordered[i];
+        }
+        L.n = (int)ordered.size();
+        rc_launch_gemm(L, wg, st, nullptr);
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    for (size_t i = 0; i < ps.size(); ++i) {
+        std::vector<float> ref(got[i].size());
+        HIP_TRY(ctx, hipMemcpy(ref.data(), ps[i].out, ref.size() * sizeof(float), hipMemcpyDeviceToHost));
+        size_t bad = 0, written = 0;
+        for (size_t e = 0; e < ref.size(); ++e) {
+            uint32_t r, g;
+            std::memcpy(&r, &ref[e], 4); std::memcpy(&g, &got[i][e], 4);
+            if (r == 0xffffffffu && g == 0xffffffffu) continue;                 // neither wrote it (rows the launch does not select)
+            ++written;
+            if (r != g) ++bad;
+        }
+        std::fprintf(stderr, "[dbg dense] N %d Kp %d alt %d: %zu of %zu written elements differ\n", ps[i].N, ps[i].Kp, ps[i].alt_base ? 1 : 0, bad, written);
+    }
+    return RC_OK;
+}
+
 // stop: event to be signalled by this launch's completion (used only when the launch is not being timed); *launched tells the
 // caller whether a kernel went out at all
 int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned char* flags_override, hipStream_t st, bool fp32 = false,
                     hipEvent_t stop = nullptr, bool* launched = nullptr) {
     if (launched) *launched = false;
     if (ps.empty()) return RC_OK;
+    if (dense_items_selftest_wanted(ctx, ps, st, fp32)) return dense_items_selftest(ctx, ps, flags_override, st);
     // LSTM layer steps marked for the shared-weight kernel (mr = 16) leave in a launch of their own behind the rest (everything
     // handed to one call is independent of everything else in it); outside split-product mode they take the 64 x 128 tile instead
     {
@@ -996,6 +1119,11 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         HIP_TRY(ctx, hipDeviceSynchronize());                               // nothing in flight (on any of the engine's streams) may still read the old table
         if (ctx->frame_at_d) (void)hipFree(ctx->frame_at_d);
         if (ctx->frame_at_h) (void)hipHostFree(ctx->frame_at_h);
+    if (ctx->res_ticks_d) (void)hipFree(ctx->res_ticks_d);
+    if (ctx->res_ticks_h) (void)hipHostFree(ctx->res_ticks_h);
+    if (ctx->res_ints_d) (void)hipFree(ctx->res_ints_d);
+    if (ctx->res_base_h) (void)hipHostFree(ctx->res_base_h);
+    if (ctx->res_abort_h) (void)hipHostFree(ctx->res_abort_h);
         ctx->frame_at_d = nullptr; ctx->frame_at_h = nullptr; ctx->frame_at_cap = 0;
         const size_t cap = need + need / 4 + 4096;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->frame_at_d, cap * sizeof(int)));
@@ -1034,6 +1162,8 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     const bool tri = lin1_own && tri_env != 0;
     static const int tri_swap_env = tune_env("RC_SEQ_TRI_SWAP", 0);
     const bool tri_swap = tri && tri_swap_env != 0;
+    // prep in front of the second stream's waits for the layer steps (it reads none of them): all-visible 256 frames 1,374k -> 1,399k
+    static const int prep_early = tune_env("RC_SEQ_PREP_EARLY", 1);
     // 64-row tile shapes of the wide launches. With both launches of a tick on one stream rnn4 ran best on 64 x 80 tiles (256 tiles
     // per layer = whole rounds of the 256 CUs); on two streams the other launch fills what a round leaves idle and the 64 x 128 tile's
     // 13 % fewer operand bytes per MFMA win: mixed 512 frames 1,030k -> 1,120k, all-visible 1,208k -> 1,258k, batch 1024 999k -> 1,088k
@@ -1117,6 +1247,133 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     if (two) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[7], 0));
     if (split_main) HIP_TRY(ctx, hipStreamWaitEvent(s2, ctx->ev_main[7], 0));
     if (lin1_own) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_main[7], 0));
+    // ---- resident layer-step kernel ------------------------------------------------------------------------------------------------
+    // On streams, a tick's layer steps are launches: every launch ends in a drain of the CUs it held, starts behind an event, and its
+    // workgroups queue for CUs against the other streams' (one shared-weight workgroup holds a CU): the CUs hold an item 70-76 % of the
+    // time (profiles/r06_lds_kernel_notes.txt), and the second stream's short kernels wait for a CU at every launch of their chain
+    // (profiles/r06_timeline_tri_high.txt). Here ONE launch of `res_wgs` workgroups carries the layer steps of the whole segment
+    // (rc_gemm_lds.hip: rc_gemm_resident_kernel): its workgroups take items tick after tick from a queue in device memory, ordered by
+    // counters instead of events, and leave 256 - res_wgs CUs to the second stream, whose chain linear1 -> prep -> [all layer steps of
+    // the previous tick] -> linear2 -> fuse -> tail now talks to the layer steps through two flags and one counter per tick.
+    // Same items, same arithmetic: bitwise the streams' result.
+    const int res_wgs = std::min(224, std::max(8, ctx->resident_wgs));
+    const bool resident = tri && ctx->resident_on && B <= 256 && P.n_ticks > 0 && !(ctx->timing && ctx->timing_mode != 3);
+    if (resident) {
+        if (int rc = ensure_lds_pool(ctx)) return rc;
+        const size_t nt = (size_t)P.n_ticks;
+        if (nt > ctx->res_cap) {
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            if (ctx->res_ticks_d) (void)hipFree(ctx->res_ticks_d);
+            if (ctx->res_ticks_h) (void)hipHostFree(ctx->res_ticks_h);
+            if (ctx->res_ints_d) (void)hipFree(ctx->res_ints_d);
+            if (ctx->res_base_h) (void)hipHostFree(ctx->res_base_h);
+            ctx->res_ticks_d = nullptr; ctx->res_ticks_h = nullptr; ctx->res_ints_d = nullptr; ctx->res_base_h = nullptr; ctx->res_cap = 0;
+            const size_t cap = nt + nt / 4 + 64;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->res_ticks_d, cap * sizeof(ResidentTick)));
+            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_ticks_h, cap * sizeof(ResidentTick), hipHostMallocDefault));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->res_ints_d, (cap * (RC_RES_MAXP + 2) + 1 + 4) * sizeof(int)));
+            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_base_h, (cap + 1) * sizeof(int), hipHostMallocDefault));
+            if (!ctx->res_abort_h) {
+                HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_abort_h, sizeof(int), hipHostMallocDefault));
+                *ctx->res_abort_h = 0;
+            }
+            ctx->res_cap = cap;
+        }
+        const size_t cap = ctx->res_cap;
+        int* item_base_d = ctx->res_ints_d;
+        int* done_d = item_base_d + cap + 1;
+        int* tick_done_d = done_d + cap * RC_RES_MAXP;
+        int* words_d = tick_done_d + cap;                                    // head, (unused), flag_tail, abort
+        // The table: per tick its layer steps AND its linear1 problems as items (linear1 as its own launches on the 32 CUs the resident
+        // kernel leaves took 86-197 us of every tick, profiles/r06_timeline_resident_l1_*.txt; as items they are 34 of ~580 per tick),
+        // slab region = tick % 4 (a tick starts behind every item of the tick before the previous one), and what each problem reads of
+        // the previous tick. init_net's three layers stay launches of the second stream (a handful of ticks per sequence).
+        std::vector<std::vector<GemmProblem>> init_l(nt);
+        int run = 0;
+        for (int k = 0; k < P.n_ticks; ++k) {
+            std::vector<GemmProblem> ls;
+            for (int g = 0; g <= last_group; ++g)
+                for (GemmProblem& p : collect(k, g)) {
+                    if (p.epi == RC_EPI_LSTM) { p.mr = 16; p.nc = 8; }
+                    else if (p.epi == RC_EPI_RELU && p.out_packed && p.N % 128 == 0 && p.Kp % 128 == 0 && p.out_bit == 0 && p.out_col0 == 0 && p.seg[0].par_mode == 0 &&
+                             p.out != ctx->hid1 && p.out != ctx->hid2) { }
+                    else { init_l[k].push_back(p); continue; }
+                    p.m_tiles = 1;                                             // (B <= 256: one row tile, whatever the tick's row count)
+                    ls.push_back(p);
+                }
+            ResidentTick& T = ctx->res_ticks_h[k];
+            const size_t region = (size_t)(k & 3);
+            size_t tiles = 0;
+            T.B = B;
+            T.n = build_lds_problems(ctx, ls, nullptr, ctx->lds_slab + region * ctx->lds_region_tiles * RC_LDS_SLAB_FLOATS,
+                                     ctx->lds_tickets + region * ctx->lds_region_tiles, T.p, RC_RES_MAXP, &T.n_items, &tiles, true);
+            if (T.n != (int)ls.size()) return fail(ctx, RC_ERR_INVALID, "resident engine: more problems in a tick than its table holds");
+            if (tiles > ctx->lds_region_tiles) return fail(ctx, RC_ERR_INVALID, "resident engine: more tiles in a tick than a slab region holds");
+            const bool tail_wrote = cnt(P.n_reach, k - 1 - kTailStage) > 0;
+            for (int i = 0; i < RC_RES_MAXP; ++i) {
+                T.dep[i][0] = T.dep[i][1] = -1; T.dep_items[i][0] = T.dep_items[i][1] = 0;
+                T.need_tail[i] = 0;
+                if (i >= T.n) continue;
+                const bool lstm = T.p[i].epi == RC_EPI_LSTM;
+                T.need_tail[i] = lstm ? ((tail_wrote && T.p[i].H == 512) ? 1 : 0) : 1;
+                if (k == 0 || !lstm) continue;
+                const ResidentTick& Tp = ctx->res_ticks_h[k - 1];
+                for (int j = 0; j < Tp.n; ++j) {
+                    const int items_j = (j + 1 < Tp.n ? Tp.p[j + 1].wg_base : Tp.n_items) - Tp.p[j].wg_base;
+                    const bool lstm_j = Tp.p[j].epi == RC_EPI_LSTM;
+                    if (lstm_j && Tp.p[j].hstate == T.p[i].hstate) { T.dep[i][0] = j; T.dep_items[i][0] = items_j; }                           // its own h(t - 1), c
+                    if ((const float*)(lstm_j ? Tp.p[j].hstate : Tp.p[j].out) == T.p[i].seg[0].base) { T.dep[i][1] = j; T.dep_items[i][1] = items_j; }   // layer 0's h | relu(linear1)
+                }
+            }
+            ctx->res_base_h[k] = run;
+            run += T.n_items;
+        }
+        ctx->res_base_h[nt] = run;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->res_ticks_d, ctx->res_ticks_h, nt * sizeof(ResidentTick), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(item_base_d, ctx->res_base_h, (nt + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(done_d, 0, (cap * (RC_RES_MAXP + 1) + 4) * sizeof(int), st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_main[6], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[6], 0));
+        ResidentArgs R{};
+        R.ticks = ctx->res_ticks_d; R.item_base = item_base_d; R.n_ticks = P.n_ticks;
+        R.head = words_d; R.done = done_d; R.tick_done = tick_done_d;
+        R.flag_tail = words_d + 2; R.abort = words_d + 3;
+        R.spin_bound = (unsigned long long)std::max(1, tune_env("RC_SEQ_RESIDENT_BOUND_MS", 2000)) * 100000ull;   // wall_clock64: 100 MHz
+        {
+            hipEvent_t *ta = nullptr, *tb = nullptr;
+            if (ctx->timing && !timing_pair(ctx, &ta, &tb)) return fail(ctx, RC_ERR_HIP, "hipEventCreate");
+            if (ta) HIP_TRY(ctx, hipEventRecord(*ta, st));
+            rc_launch_gemm_resident(R, res_wgs, st);
+            if (tb) HIP_TRY(ctx, hipEventRecord(*tb, st));
+        }
+        ctx->stat_lds_launches += 1;
+        // second stream, tick k: [init_net] -> prep -> [every item of tick k - 1] -> linear2 -> fuse -> tail -> flag_tail = k + 1
+        for (int k = 0; k < P.n_ticks; ++k) {
+            if (int rc = launch_problems(ctx, init_l[k], nullptr, aux, false)) return rc;
+            if (k < P.n_prep) {
+                wp.frame_at = ctx->frame_at_d + (size_t)k * B;
+                wp.first_tick = k == 0 ? 1 : 0;
+                rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);
+            }
+            if (k > 0) rc_launch_flag_wait(tick_done_d + (k - 1), ctx->res_ticks_h[k - 1].n_items, words_d + 3, R.spin_bound, aux);
+            if (int rc = group(k, 5, aux)) return rc;
+            if (cnt(P.n_valid, k - kFuseStage) > 0) rc_launch_fuse(ctx->ring2[(k - kFuseStage) % kRing], io0, prm, B, aux);
+            if (cnt(P.n_valid, k - kTailStage) > 0) {
+                const FrameBuffers& tgt = ctx->ring2[k % kRing];
+                wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
+                rc_launch_tail(ctx->ring2[(k - kTailStage) % kRing], io0, prm, ctx->body, B, 0, aux, nullptr, &wt, nullptr);
+            }
+            rc_launch_flag_set(words_d + 2, k + 1, aux);
+            ctx->stat_ticks += 1;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[0], aux));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[0], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->res_abort_h, words_d + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->stat_resident_segments += 1;
+        ctx->stat_wave_frames += t_last - t0 + 1;
+        return RC_OK;
+    }
     for (int k = 0; k < P.n_ticks; ++k) {
         const int e = k & 3, ep = (k + 3) & 3;
         std::vector<GemmProblem> tri_l1, tri_ls6, tri_ls5;
@@ -1129,11 +1386,17 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (!sigl) HIP_TRY(ctx, hipEventRecord(ctx->ev_lin1[e], aux));
         }
         // ---- per-row kernels and linear2 of tick k (second stream: after the previous tick's wide launches)
+        const bool prep_first = tri && prep_early != 0 && k < P.n_prep;
+        if (prep_first) {
+            wp.frame_at = ctx->frame_at_d + (size_t)k * B;
+            wp.first_tick = k == 0 ? 1 : 0;
+            rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);
+        }
         if (tri && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_h5[ep], 0));
         if (two && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[ep], 0));
         if (split_main && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_h512[ep], 0));
         if (lin1_own && !tri && k > 0) HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_lin1[ep], 0));   // (init_net's last layer -> the tail)
-        if (k < P.n_prep) {
+        if (k < P.n_prep && !prep_first) {
             wp.frame_at = ctx->frame_at_d + (size_t)k * B;
             wp.first_tick = k == 0 ? 1 : 0;
             rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);   // (before the tail: it initialises the tail's target slot)
@@ -1381,6 +1644,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
     ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
     ctx->lds_min_rows = tune_env("RC_LDS_MIN_ROWS", ctx->lds_min_rows);
+    ctx->resident_on = tune_env("RC_SEQ_RESIDENT", 0) != 0;
+    ctx->resident_wgs = tune_env("RC_SEQ_RESIDENT_WGS", ctx->resident_wgs);
     ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 1) == 1 ? 1 : 2;
     ctx->lds_ksplit[1] = tune_env("RC_LDS_KSPLIT_1024", 2) == 1 ? 1 : 2;
     ctx->lds_ksplit[2] = tune_env("RC_LDS_KSPLIT_1280", 2) == 1 ? 1 : 2;
@@ -1703,6 +1968,12 @@ int rc_sequence(rc_ctx* ctx, int32_t T, const float* j2dc, int64_t rs_j2d, const
                    std::chrono::steady_clock::now() - t_spin < std::chrono::microseconds(300)) { }
         }
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (ctx->res_abort_h && *ctx->res_abort_h) {                           // (the copy sits behind the segment on this stream)
+            ctx->stat_resident_aborts += 1;
+            *ctx->res_abort_h = 0;
+            return fail(ctx, RC_ERR_STATE, "resident layer-step kernel: a wait ran out in the previous call (its outputs and the recurrent state are invalid); "
+                                           "RC_SEQ_RESIDENT=0 selects the stream engine");
+        }
         for (int b = 0; b < B; ++b) ctx->scan_state_h[B + b] = pend_b[b];
         const bool ff = (flags & RC_FLAG_FIRST_FRAME) != 0;
         const bool imu = ctx->prm.use_imu_updater != 0, vup = ctx->prm.use_vision_updater != 0;
@@ -1768,6 +2039,20 @@ int rc_get_sequence_stats(rc_ctx* ctx, int64_t* wave_frames, int64_t* stepped_fr
     if (wave_frames) *wave_frames = ctx->stat_wave_frames;
     if (stepped_frames) *stepped_frames = ctx->stat_stepped_frames;
     if (ticks) *ticks = ctx->stat_ticks;
+    return RC_OK;
+}
+
+int rc_set_resident(rc_ctx* ctx, int32_t enable, int32_t workgroups) {
+    if (!ctx) return RC_ERR_INVALID;
+    ctx->resident_on = enable != 0;
+    if (workgroups > 0) ctx->resident_wgs = workgroups;
+    return RC_OK;
+}
+
+int rc_get_resident_stats(rc_ctx* ctx, int64_t* segments, int64_t* aborts) {
+    if (!ctx) return RC_ERR_INVALID;
+    if (segments) *segments = ctx->stat_resident_segments;
+    if (aborts) *aborts = ctx->stat_resident_aborts;
     return RC_OK;
 }
 

@@ -69,6 +69,10 @@ extern "C" int rc_trace_lds_set(unsigned long long* buf, unsigned long long cap_
 #define LDS_TRACE_OUT(LAST) do { } while (0)
 #endif
 
+#ifndef RC_LAND
+#define RC_LAND 1         // (0: measurement builds only -- the resident kernel without its drains in front of the loop headers)
+#endif
+
 namespace {
 
 constexpr int kWaves = 8;                     // waves per workgroup
@@ -128,13 +132,14 @@ __device__ __forceinline__ void quad_transpose(const f32x4& v, const int q, f32x
     g[0] = hi ? y2 : a0; g[1] = hi ? y3 : a1; g[2] = hi ? a2 : y0; g[3] = hi ? a3 : y1;
 }
 
-__device__ __forceinline__ bool locate(const LdsLaunch& L, int& pi, int& m_tile, int& n_tile, int& kh0, int& kh1) {
+template <int MAXP, typename PP>
+__device__ __forceinline__ bool locate(const PP Lp, const int Ln, const int item, int& pi, int& m_tile, int& n_tile, int& kh0, int& kh1) {
     pi = 0;
 #pragma unroll
-    for (int q = 1; q < RC_LDS_MAXP; ++q)
-        if (q < L.n && (int)blockIdx.x >= L.p[q].wg_base) pi = q;
-    const LdsProblem& P = L.p[pi];
-    const int local = blockIdx.x - P.wg_base;
+    for (int q = 1; q < MAXP; ++q)
+        if (q < Ln && item >= Lp[q].wg_base) pi = q;
+    const auto& P = Lp[pi];
+    const int local = item - P.wg_base;
     // the two halves of a tile are neighbours in the grid (they finish together); tiles of one weight slice (same n_tile, row
     // tiles m) are a multiple of 8 apart: same XCD, the slice goes through that L2 once
     const int t = P.ksplit == 2 ? local >> 1 : local;
@@ -159,7 +164,7 @@ struct HalfArgs {
 // 8 slots: one column block each, its planes requested a slot earlier | at slot 7: B(Q + 1) landed, barrier].
 // Vector-memory operations complete in order, so with the issue order A(Q + 1), B(Q + 1), A(Q + 2), B(Q + 2) "all but the NA + 3
 // youngest" is exactly "A(Q + 1) and B(Q + 1) have landed".
-template <int NR>
+template <int NR, bool SHORT_OK>
 __device__ __forceinline__ void k_half(const HalfArgs& c, f32x4 (&acc0)[2][8], f32x4 (&acc1)[2][8]) {
     constexpr int NA = 2 * NR;                // activation loads per k-block
     f32x4 raw[2][2][2];                       // [buffer][row block][chunk of 16 k]
@@ -238,9 +243,35 @@ __device__ __forceinline__ void k_half(const HalfArgs& c, f32x4 (&acc0)[2][8], f
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (NR > 0) { dsread<0>(bf[0][0], c.rd0); dsread<1024>(bf[0][1], c.rd0); dsread<2048>(bf[0][2], c.rd0); }
-    for (int q = 0; q < c.Qq; q += 2) { ITER(0, q, acc0); ITER(1, q + 1, acc0); }
-    for (int q = c.Qq; q < Qh; q += 2) { ITER(0, q, acc1); ITER(1, q + 1, acc1); }
+    // Resident kernel (SHORT_OK). The loads of this loop are asm the compiler only sees REQUESTING a register (raw[]: two k-blocks ahead,
+    // bf[]: one column block ahead); it is free to copy or spill that register the next instruction. The launch-per-tick kernel never gave
+    // it a reason to; the resident kernel's longer-lived state does, and its register allocation spills in front of the loop headers -- a
+    // fragment not yet landed was spilled and reloaded as the register's OLD content: garbage in column block 0 of the first k-block
+    // (found with RC_DBG_DENSE_ITEMS, rc_api.cpp). So in front of a loop header everything lands and is tied to its registers. Cost: two
+    // exposed memory latencies per half, ~5 % of an item (RC_LAND=0 builds, profiles/r06_resident_notes.txt).
+#define LAND_ALL()                                                                                                          \
+    do {                                                                                                                    \
+        if constexpr (SHORT_OK && RC_LAND) {                                                                                \
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+            TIE_RAW(0); TIE_RAW(1);                                                                                         \
+            if constexpr (NR > 0) asm volatile("" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2])); \
+        }                                                                                                                   \
+    } while (0)
+    LAND_ALL();
+    if (SHORT_OK && c.Qq == 1) {                // a quarter = ONE k-block (linear1 with K' = 128): the two buffers are the two quarters
+        ITER(0, 0, acc0); ITER(1, 1, acc1);
+    } else {
+        for (int q = 0; q < c.Qq; q += 2) { ITER(0, q, acc0); ITER(1, q + 1, acc0); }
+        LAND_ALL();
+        for (int q = c.Qq; q < Qh; q += 2) { ITER(0, q, acc1); ITER(1, q + 1, acc1); }
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    // The last k-blocks' look-ahead loads (clamped, unused) are still landing up to here: their destination registers stay allocated until
+    // the wait above. (Without this the straight-line short-K path reused them -- for addresses -- while the loads were in flight: a memory
+    // fault two instructions later. The loop form kept them alive as loop-carried values by luck of structure, not by contract.)
+    TIE_RAW(0); TIE_RAW(1);
+    if constexpr (NR > 0) asm volatile("" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]));
+#undef LAND_ALL
 #undef ITER
 #undef SLOT
 #undef TIE_RAW
@@ -250,18 +281,30 @@ __device__ __forceinline__ void k_half(const HalfArgs& c, f32x4 (&acc0)[2][8], f
 
 }  // namespace
 
-__global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLaunch L) {
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[kRing * kStage];
-    __shared__ int s_rows[256];
-    __shared__ int s_cnt[kWaves];
+// One work item (a half tile, or a whole one with ksplit = 1; the padding of a problem's item range to a multiple of 8 included) of a launch:
+// the body of rc_gemm_lds_kernel, and of every turn of the resident kernel's loop. Returns 1 when the item wrote the tile's h / c (a
+// finisher), 0 otherwise; *pi_out = the item's problem.
+template <int MAXP, bool WITH_DENSE, typename PP>   // PP: pointer to the launch's problems -- kernel arguments, or the resident kernel's table in the constant address space
+__device__ __forceinline__ int lds_item(const PP Lp, const int Ln, const int LB, const int item, unsigned char* ring, int* s_rows, int* s_cnt, int* pi_out) {
 #ifdef RC_TRACE_TILES
     unsigned long long trace_t[4] = {0, 0, 0, 0};
 #endif
     LDS_T(0);
     int pi, m_tile, n_tile, kh0, kh1;
-    if (!locate(L, pi, m_tile, n_tile, kh0, kh1)) return;
-    const LdsProblem& P = L.p[pi];
-    const int B = L.B;
+    const bool in_range = locate<MAXP>(Lp, Ln, item, pi, m_tile, n_tile, kh0, kh1);
+    *pi_out = pi;
+    if (!in_range) return 0;
+#ifdef RC_SKIP_XHALF
+    // Measurement builds only (tools/hoist_bound.sh; results are wrong): the half of K that multiplies the layer's INPUT (x . W_ih, seg[0]) is
+    // left out -- what a tick costs when only the recurrent half h(t - 1) . W_hh runs per frame, i.e. the floor of a time-hoisted engine
+    // whose tall input GEMMs came for free.
+    if (Lp[pi].epi == RC_EPI_LSTM) {
+        if (Lp[pi].ksplit == 2 && kh0 == 0) return 0;
+        kh0 = 1;
+    }
+#endif
+    const auto& P = Lp[pi];
+    const int B = LB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
@@ -284,7 +327,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
     int nrows;
     if (P.flag_bit == 0) {
         nrows = min(256, B - lo);
-        if (nrows <= 0) return;
+        if (nrows <= 0) return 0;
         if (tid < 256) s_rows[tid] = lo + min(tid, nrows - 1);
         __syncthreads();
     } else {
@@ -308,7 +351,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
             __syncthreads();
         }
         nrows = min(256, total - lo);
-        if (nrows <= 0) return;                                     // (uniform: both halves of the tile leave, no flag is raised)
+        if (nrows <= 0) return 0;                                   // (uniform: both halves of the tile leave, no flag is raised)
         if (tid < 256 && tid >= nrows) s_rows[tid] = s_rows[0];
         __syncthreads();
     }
@@ -321,16 +364,19 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
     const bool need_st = (P.seg[0].par_mode | P.seg[1].par_mode) != 0;
     const int st_r[2] = {need_st ? P.steps[row_r[0]] + P.step_off : 0, need_st ? P.steps[row_r[1]] + P.step_off : 0};
 
+    const bool dense = WITH_DENSE && P.epi != RC_EPI_LSTM;      // (relu(linear1) items exist in the resident kernel's tables only)
     f32x4 acc0[2][8], acc1[2][8];             // the two quarter chains of the current half
     float* const my_slab = P.slab + ((long long)tile * 2) * 32768 + ((wave * 2) * 8 * 64 + lane) * 4;   // + kh * 32768 + (r * 8 + j) * 256
 
     for (int kh = kh0; kh < kh1; ++kh) {
-        const GemmSeg& sg = P.seg[kh];
+        const auto& sg = P.seg[kh];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int st = st_r[r];
             const int par = sg.par_mode == RC_PAR_SRC ? ((st - 1) % RC_HBUF) : (sg.par_mode == RC_PAR_DST ? (st % RC_HBUF) : 0);
-            hc.pa[r] = sg.base + (long long)par * sg.par_stride + rc_pk(row_r[r], 4 * kq, sg.ld);
+            const float* a_base = sg.base;
+            if (WITH_DENSE && P.sel_bit != 0 && !(P.sel_flags[row_r[r]] & P.sel_bit)) a_base = P.alt[kh];      // a rider's row: its deferred input
+            hc.pa[r] = a_base + (long long)par * sg.par_stride + rc_pk(row_r[r], 4 * kq, sg.ld);
         }
         hc.pw = reinterpret_cast<const u32x4*>(P.Ws) + ((long long)(n_tile * 8 + wave) * Qs + (long long)kh * Qh) * 192 + lane;
         hc.primed = kh == kh0;
@@ -339,14 +385,29 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
 #pragma unroll
             for (int j = 0; j < 8; ++j) { acc0[r][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[r][j] = acc0[r][j]; }
         if (kh == kh0) LDS_T(1);
-        if (nr == 2) k_half<2>(hc, acc0, acc1);
-        else if (nr == 1) k_half<1>(hc, acc0, acc1);
-        else k_half<0>(hc, acc0, acc1);
-        // the half sum p_a + p_b
+        if (nr == 2) k_half<2, WITH_DENSE>(hc, acc0, acc1);
+        else if (nr == 1) k_half<1, WITH_DENSE>(hc, acc0, acc1);
+        else k_half<0, WITH_DENSE>(hc, acc0, acc1);
+        if (dense && kh == 1) {
+            // a dense layer sums its quarters in sequence, ((p0 + p1) + p2) + p3 as gemm_tile's dense epilogue does: the parked p0 + p1 (this
+            // workgroup's own stores: ksplit = 1) comes back here and the epilogue finds the finished sum in acc0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r)
+                if (r < nr) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc0[r][j] += acc1[r][j];
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(my_slab + (r * 8 + j) * 256);
+                        acc0[r][j] = (o + acc0[r][j]) + acc1[r][j];
+                    }
+                }
+        } else {
+            // the half sum p_a + p_b
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc0[r][j] += acc1[r][j];
+        }
         if (kh == 0) {                         // parked for the workgroup that finishes the tile (ksplit = 1: this one itself)
             float* s = my_slab;
 #pragma unroll
@@ -365,7 +426,16 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
     int rr_[2], r2_[2], dst_[2];
     float c_prev[2][8], bias[8];
     const bool finisher = P.ksplit != 2 || kh0 == 1;
-    if (finisher) {
+    if (dense) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            rr_[r] = 16 * (wave + 8 * r) + 4 * kq + q;
+            r2_[r] = s_rows[rr_[r] < nrows ? rr_[r] : 0];
+            dst_[r] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias[j] = P.bias[n_tile * 128 + 16 * j + i];
+    } else if (finisher) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             rr_[r] = 16 * (wave + 8 * r) + 4 * kq + q;
@@ -384,7 +454,11 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
     // it waits for nothing itself. (A bound on the wait turns a can't-happen into a trap, not a hang.) Measured against the symmetric
     // form -- both halves write, a ticket decides who finishes, nobody waits: +4.8 % end to end (both paid the slab store, its
     // acknowledgement and an atomic round trip; profiles/r06_lds_kernel_notes.txt).
+#ifdef RC_SKIP_XHALF
+    if (false) {
+#else
     if (P.ksplit == 2) {
+#endif
         if (kh0 == 0) {                        // writer
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's slab stores have left
             __syncthreads();
@@ -394,7 +468,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
                 __hip_atomic_store(&P.tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             LDS_T(3); LDS_TRACE_OUT(0);
-            return;
+            return 0;
         }
         if (tid == 0) {
             const unsigned long long t_give_up = wall_clock64() + 200000000ull;   // 2 s at 100 MHz
@@ -415,6 +489,19 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
     for (int r = 0; r < 2; ++r) {
         if (r >= nr) continue;
         const bool ok = rr_[r] < nrows;
+        if (dense) {
+            // relu(sum + bias) -> x1 in rc_pk order: after the quad transpose a lane holds four consecutive columns of one row, one 16-byte store
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 v = acc0[r][j];
+                v[0] += bias[j]; v[1] += bias[j]; v[2] += bias[j]; v[3] += bias[j];
+                f32x4 g;
+                quad_transpose(v, q, g);
+                g[0] = fmaxf(g[0], 0.0f); g[1] = fmaxf(g[1], 0.0f); g[2] = fmaxf(g[2], 0.0f); g[3] = fmaxf(g[3], 0.0f);
+                if (ok) *reinterpret_cast<f32x4*>(&P.out[rc_pk(r2_[r], n_tile * 128 + 16 * j + 4 * u, P.ldo)]) = g;
+            }
+            continue;
+        }
         f32x4 o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const f32x4*>(my_slab + (r * 8 + j) * 256);
@@ -434,6 +521,111 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLa
         }
     }
     LDS_TRACE_OUT(1);
+    return 1;
+}
+
+__global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_lds_kernel(const LdsLaunch L) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[kRing * kStage];
+    __shared__ int s_rows[256];
+    __shared__ int s_cnt[kWaves];
+    int pi;
+    (void)lds_item<RC_LDS_MAXP, false, const LdsProblem*>(L.p, L.n, L.B, (int)blockIdx.x, ring, s_rows, s_cnt, &pi);
+}
+
+// ================================================================================================ resident kernel
+// The workgroups of ONE launch carry the layer steps of every tick of a segment (ResidentArgs, rc_internal.h). A workgroup takes the next
+// position of the queue, finds its tick and item, requests the item's first weight planes and then waits -- thread 0 polls, the workgroup
+// stands at a barrier -- until what the item reads is there:
+//   * the second stream's chain (prep -> linear2 -> fuse -> tail, which raises flag_tail behind it) of the tick before the previous one --
+//     of the PREVIOUS tick for linear1, which reads what that chain wrote, and for rnn2 behind an init_net state write;
+//   * every item of the tick before the previous one (covers every write-after-read two ticks apart: the third copies of h and of
+//     relu(linear1) are what makes one tick of slack enough, tests/test_wave_streams.py);
+//   * the problems of the previous tick it reads: its own h(t - 1) and its input -- layer 0's h, or relu(linear1), itself an item.
+// Everything an item waits for sits EARLIER in the queue or on the second stream, whose kernels never wait for a later item: whoever holds
+// an item can finish it, no matter how many workgroups are resident. Waits are bounded (spin_bound): a wait that runs out raises *abort,
+// every other wait ends at once and the host reports the segment as failed.
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// (The wait stands in FRONT of the item, not behind its first weight requests: everything it holds -- the tick's table entry, the counters'
+// addresses -- is dead before the item's registers are live; inside the item it cost 68 bytes of scratch per lane.)
+__device__ __forceinline__ void resident_wait(const ResidentArgs& R, const __attribute__((address_space(4))) ResidentTick* T, const int k, const int pi) {
+    if (threadIdx.x == 0) {
+        const unsigned long long give_up = wall_clock64() + R.spin_bound;
+        const int prev_items = k >= 2 ? R.item_base[k - 1] - R.item_base[k - 2] : 0;
+        bool ok = false;
+        for (;;) {
+            ok = ld_agent(R.flag_tail) >= (T->need_tail[pi] ? k : k - 1);
+            if (ok && k >= 2) ok = ld_agent(R.tick_done + (k - 2)) >= prev_items;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                if (ok && T->dep[pi][d] >= 0) ok = ld_agent(R.done + (long long)(k - 1) * RC_RES_MAXP + T->dep[pi][d]) >= T->dep_items[pi][d];
+            if (ok || ld_agent(R.abort) != 0) break;
+            if (wall_clock64() > give_up) { __hip_atomic_store(R.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_resident_kernel(const ResidentArgs R) {
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[kRing * kStage];
+    __shared__ int s_rows[256];
+    __shared__ int s_cnt[kWaves];
+    __shared__ int s_item;
+    const int total = R.item_base[R.n_ticks];
+    int k = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(R.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int g = __builtin_amdgcn_readfirstlane(s_item);
+        if (g >= total) return;
+        while (g >= R.item_base[k + 1]) ++k;
+        // The tick's table entry is read through the CONSTANT address space (scalar loads into SGPRs on demand, like the kernel arguments of
+        // the launch-per-tick kernel): nothing on the device ever writes it. Read as ordinary global memory -- behind this loop's own
+        // stores the compiler must assume it changed -- the fields of the problem sat in VGPRs for the length of the item.
+        typedef const __attribute__((address_space(4))) ResidentTick* TickC;
+        const TickC T = (TickC)(unsigned long long)(R.ticks + k);
+        const int item = g - R.item_base[k];
+        int pi = 0;
+        for (int q = 1; q < T->n; ++q) if (item >= T->p[q].wg_base) pi = q;
+        resident_wait(R, T, k, pi);
+        typedef const __attribute__((address_space(4))) LdsProblem* ProbC;
+        (void)lds_item<RC_RES_MAXP, true, ProbC>(T->p, T->n, T->B, item, ring, s_rows, s_cnt, &pi);
+        // the item's stores (h, c; a writer's half sum went out behind its own flag) are visible before it counts as finished
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(R.done + (long long)k * RC_RES_MAXP + pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(R.tick_done + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (nothing of this wave is in flight when the next item starts: its K loop counts outstanding vector-memory operations)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+// second-stream side of the counters: a one-thread kernel raises a flag behind the kernels in front of it, another waits for a counter in
+// front of the kernels behind it
+__global__ void rc_flag_set_kernel(int* flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void rc_flag_wait_kernel(const int* counter, int target, int* abort, unsigned long long spin_bound) {
+    const unsigned long long give_up = wall_clock64() + spin_bound;
+    while (ld_agent(counter) < target && ld_agent(abort) == 0) {
+        if (wall_clock64() > give_up) { __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+void rc_launch_gemm_resident(const ResidentArgs& R, int workgroups, hipStream_t s) {
+    hipLaunchKernelGGL(rc_gemm_resident_kernel, dim3(workgroups), dim3(kWaves * 64), 0, s, R);
+}
+void rc_launch_flag_set(int* flag, int value, hipStream_t s) { hipLaunchKernelGGL(rc_flag_set_kernel, dim3(1), dim3(1), 0, s, flag, value); }
+void rc_launch_flag_wait(const int* counter, int target, int* abort, unsigned long long spin_bound, hipStream_t s) {
+    hipLaunchKernelGGL(rc_flag_wait_kernel, dim3(1), dim3(1), 0, s, counter, target, abort, spin_bound);
 }
 
 void rc_launch_gemm_lds(const LdsLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop) {

@@ -112,12 +112,46 @@ struct LdsProblem {
     int* tickets;           // [tiles], zero between launches
     long long h_par_stride;
     int H, flag_bit, n_tiles, m_tiles, wg_base, Qs, step_off, ksplit;
+    // relu(linear1) as an item of the resident kernel (epi = RC_EPI_RELU; ksplit 1, seg[0] | seg[1] = the two halves of ONE input): out
+    // [rows, ldo] in rc_pk order; rows without sel_bit in sel_flags read alt[0] | alt[1] instead (a rider's deferred input)
+    float* out;
+    const float* alt[2];
+    const unsigned char* sel_flags;
+    int epi, ldo, sel_bit, pad_;
 };
 struct LdsLaunch {
     int n, B;
     LdsProblem p[RC_LDS_MAXP];
 };
+#define RC_RES_MAXP 20    // problems of a tick of the resident kernel: twelve layer steps + six linear1
 void rc_launch_gemm_lds(const LdsLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
+
+// ---- resident layer-step kernel (rc_gemm_lds.hip: rc_gemm_resident_kernel) ----------------------------------
+// One launch carries the LSTM layer steps of EVERY tick of a wavefront-engine segment: its workgroups stay on their CUs and take work
+// items (the items of rc_gemm_lds_kernel, tick after tick, longest first inside a tick) from one queue in device memory. What stream
+// order and events did between launches, counters in device memory do between items (rc_api.cpp: run_wave2_resident).
+struct ResidentTick {
+    int n, B;                             // the tick's problems, as one launch of the shared-weight kernel would carry them
+    LdsProblem p[RC_RES_MAXP];
+    int n_items;                          // work items of the tick (every problem's range padded to a multiple of 8)
+    int dep[RC_RES_MAXP][2];              // per problem: up to two problems of the PREVIOUS tick it reads (own h(t - 1); its input: layer 0's h, relu(linear1)), -1 = none
+    int dep_items[RC_RES_MAXP][2];        // ... and their item counts
+    int need_tail[RC_RES_MAXP];           // 1: the problem reads what the previous tick's second-stream chain wrote (linear1: fuse / tail / prep; rnn2 behind an init_net state write)
+};
+struct ResidentArgs {
+    const ResidentTick* ticks;
+    const int* item_base;                 // [n_ticks + 1] first queue position of every tick
+    int n_ticks;
+    int* head;                            // queue head
+    int* done;                            // [n_ticks][RC_RES_MAXP] items finished per (tick, problem)
+    int* tick_done;                       // [n_ticks] items finished per tick
+    const int* flag_tail;                 // second stream: tails finished (the chain of tick k done -> k + 1)
+    int* abort;                           // set by whoever waited longer than the bound; everybody else stops waiting
+    unsigned long long spin_bound;        // wall_clock64 ticks (100 MHz)
+};
+void rc_launch_gemm_resident(const ResidentArgs& R, int workgroups, hipStream_t s);
+void rc_launch_flag_set(int* flag, int value, hipStream_t s);
+void rc_launch_flag_wait(const int* counter, int target, int* abort, unsigned long long spin_bound, hipStream_t s);
 
 // ---- per-frame small kernels -------------------------------------------------------------------------------
 struct BodyConst {          // device copy of the body constants the path needs

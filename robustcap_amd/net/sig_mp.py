@@ -31,6 +31,44 @@ _PARAM_ATTRS = {"use_flat_floor", "use_vision_updater", "use_imu_updater", "live
                 "smooth"}
 
 
+class _ModuleView:
+    """Read-only view of one node of the reference's module tree (net.rnn2, net.rnn2.rnn, net.rnn2.init_net[0] ...)."""
+
+    def __init__(self, net, prefix):
+        self.__dict__["_net"], self.__dict__["_prefix"] = net, prefix
+
+    def _keys(self):
+        return [k for k, _ in cfg.state_dict_spec() if k.startswith(self._prefix + ".")]
+
+    def __getattr__(self, name):
+        full = self._prefix + "." + name
+        sd = self._net._sd_cpu
+        if any(k == full for k, _ in cfg.state_dict_spec()):
+            if full not in sd:
+                raise AttributeError(f"{full}: not loaded yet")
+            return torch.from_numpy(sd[full])
+        if any(k.startswith(full + ".") for k, _ in cfg.state_dict_spec()):
+            return _ModuleView(self._net, full)
+        raise AttributeError(f"no parameter or sub-module {full!r}")
+
+    def __getitem__(self, i):                       # nn.Sequential indexing: init_net[0], init_net[2], init_net[4]
+        return self.__getattr__(str(int(i)))
+
+    def __setattr__(self, name, value):
+        raise AttributeError("read-only view: change weights through Net.load_state_dict")
+
+    def state_dict(self):
+        from collections import OrderedDict
+        n = len(self._prefix) + 1
+        return OrderedDict((k[n:], torch.from_numpy(self._net._sd_cpu[k])) for k in self._keys() if k in self._net._sd_cpu)
+
+    def parameters(self):
+        return iter(self.state_dict().values())
+
+    def __repr__(self):
+        return f"<view of {self._prefix}: {len(self._keys())} tensors>"
+
+
 class Net:
     # class attributes callers read or poke on the reference (net/sig_mp.py:27-45)
     hidden_size = 512
@@ -160,6 +198,35 @@ class Net:
         self.__dict__["_live_on"] = False          # the library dropped its captured frame (it held the old weight pointers)
         self.__dict__["_loaded"] = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ------------------------------------------------------------------------------------------ module introspection
+    # The reference's Net is a torch.nn.Module (net/sig_mp.py:23); its callers on the path only load weights and call it (evaluate.py:56-93,
+    # live_server.py:62-67). What introspects a module finds the same names here: state_dict() / named_parameters() / parameters() in the
+    # reference's key order and the attribute tree net.rnn2.linear1.weight, net.rnn4.rnn.weight_hh_l1, net.rnn2.init_net[4].bias ... as
+    # read-only views of the loaded tensors (the weights live packed in device memory; an edit goes through load_state_dict).
+    def state_dict(self):
+        from collections import OrderedDict
+        return OrderedDict((k, torch.from_numpy(self._sd_cpu[k])) for k, _ in cfg.state_dict_spec() if k in self._sd_cpu)
+
+    def named_parameters(self, prefix="", recurse=True):
+        for k, v in self.state_dict().items():
+            yield (prefix + ("." if prefix else "") + k, v)
+
+    def parameters(self, recurse=True):
+        for _, v in self.named_parameters():
+            yield v
+
+    def train(self, mode=True):
+        if mode:
+            raise _lib.RobustcapLibraryError("robustcap_amd.Net is the inference path only (net/sig_mp.py:301-560, the training half, is out of scope)")
+        return self
+
+    def __getattr__(self, name):
+        # (only reached when normal lookup fails) sub-module views: rnn2 ... rnn8
+        sd = self.__dict__.get("_sd_cpu")
+        if sd is not None and name.startswith("rnn") and any(k.startswith(name + ".") for k, _ in cfg.state_dict_spec()):
+            return _ModuleView(self, name)
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     def reset_states(self, rows=None):
         """net/sig_mp.py:95-104. rows: optional bool/uint8 mask [batch] (batched API)."""
@@ -378,6 +445,17 @@ class Net:
         """(launches of the shared-weight kernel rc_gemm_lds_kernel, launches of the other wide-tile kernels) since construction."""
         a, b = C.c_int64(), C.c_int64()
         _lib.check(self._ctx, self._lib.rc_get_launch_stats(self._ctx, C.byref(a), C.byref(b)), "rc_get_launch_stats")
+        return a.value, b.value
+
+    def set_resident(self, enable=True, workgroups=0):
+        """Resident layer-step kernel of the wavefront engine (include/robustcap_hip.h: rc_set_resident): one launch carries the LSTM layer
+        steps and linear1 layers of every tick of a planned forward_sequence call. Bitwise the stream engine's results; off by default."""
+        _lib.check(self._ctx, self._lib.rc_set_resident(self._ctx, 1 if enable else 0, int(workgroups)), "rc_set_resident")
+
+    def resident_stats(self):
+        """(segments run on the resident kernel, aborted ones) since construction."""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self._ctx, self._lib.rc_get_resident_stats(self._ctx, C.byref(a), C.byref(b)), "rc_get_resident_stats")
         return a.value, b.value
 
     def gemm_timing(self, enable):

@@ -1,0 +1,44 @@
+"""The reference's Net is a torch.nn.Module (net/sig_mp.py:23): what introspects it -- state_dict(), parameters(), the attribute tree
+net.rnn2.linear1.weight / net.rnn4.rnn.weight_hh_l1 / net.rnn2.init_net[4].bias -- finds the same names, order and values here."""
+import pytest
+import torch
+
+from robustcap_amd import config as cfg
+from robustcap_amd import synth
+from robustcap_amd.net.sig_mp import Net
+
+pytestmark = pytest.mark.gpu
+
+
+def test_state_dict_parameters_and_the_attribute_tree():
+    sd, body = synth.make_state_dict(0), synth.make_body(1)
+    net = Net(body=body, batch=2)
+    assert list(net.state_dict()) == []                                   # nothing loaded yet
+    net.load_state_dict(sd)
+    out = net.state_dict()
+    assert list(out) == [k for k, _ in cfg.state_dict_spec()]             # the reference's keys in torch's order
+    for k, shape in cfg.state_dict_spec():
+        assert tuple(out[k].shape) == tuple(shape) and out[k].dtype == torch.float32
+        assert torch.equal(out[k], torch.as_tensor(sd[k]))
+    assert sum(p.numel() for p in net.parameters()) == 63_424_546        # the reference's parameter count
+    names = [n for n, _ in net.named_parameters()]
+    assert names == list(out)
+    assert torch.equal(net.rnn2.linear1.weight, out["rnn2.linear1.weight"])
+    assert torch.equal(net.rnn4.rnn.weight_hh_l1, out["rnn4.rnn.weight_hh_l1"])
+    assert torch.equal(net.rnn2.init_net[4].bias, out["rnn2.init_net.4.bias"])
+    assert list(net.rnn8.state_dict()) == [k[5:] for k in out if k.startswith("rnn8.")]
+    with pytest.raises(AttributeError):
+        net.rnn5                                                           # the reference has no rnn5 either (slot quirk)
+    with pytest.raises(AttributeError):
+        net.rnn2.linear1.weight2
+    with pytest.raises(AttributeError):
+        net.rnn2.linear1.weight = torch.zeros(1)                          # read-only: weights change through load_state_dict
+    assert net.eval() is net and net.train(False) is net
+    # a round trip through the surface reproduces the context
+    net2 = Net(body=body, batch=2)
+    net2.load_state_dict(net.state_dict())
+    m = synth.make_motion(4, 2, 3, body, conf="high")
+    t = torch.from_numpy
+    a = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    b = net2.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_frame=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
