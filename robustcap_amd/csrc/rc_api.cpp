@@ -1437,7 +1437,14 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s_r6, ctx->ev_lin1[ep], 0));
             if (int rc = launch_problems(ctx, tri_ls6, nullptr, s_r6, false, ctx->ev_h512[e], &sig6)) return rc;
             if (!sig6) HIP_TRY(ctx, hipEventRecord(ctx->ev_h512[e], s_r6));
-            if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_aux[ep], 0));      // (rnn2 l0 behind the tail's init_net state write; linear1(k - 1) sits in front of it)
+            // The H = 512 nets' stream waits for the END of the second stream's previous tick. It NEEDS only linear1(k - 1) -- the head of
+            // that tick, behind that stream's tick k - 2, which covers every buffer the layer steps rewrite -- and the end only behind an
+            // init_net state write of its tail (rnn2 l0). RC_SEQ_H5_EARLY=1 issues exactly that (race free on the stream model), and is
+            // SLOWER: all-visible 1,458k -> 1,405k, mixed 1,211k -> 1,182k body-frames/s -- the three layer-step launches of a tick do
+            // better in step with each other than spread over the tick (profiles/r06_resident_notes.txt).
+            static const int h5_early = tune_env("RC_SEQ_H5_EARLY", 0);
+            if (k > 0 && h5_early && cnt(P.n_reach, k - 1 - kTailStage) == 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_lin1[ep], 0));
+            else if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s4, ctx->ev_aux[ep], 0));
             if (int rc = launch_problems(ctx, tri_ls5, nullptr, s4, false, ctx->ev_h5[e], &sig5)) return rc;
             if (!sig5) HIP_TRY(ctx, hipEventRecord(ctx->ev_h5[e], s4));
             if (k > 0) HIP_TRY(ctx, hipStreamWaitEvent(s_r4, ctx->ev_lin1[ep], 0));

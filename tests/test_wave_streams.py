@@ -80,11 +80,16 @@ def build_tri(hbuf, x1buf, init=True):
         if k:
             edge((k - 1, "tail"), (k, "L1"))
             for g in ("G4", "G6", "G5"):
-                edge((k - 1, g), (k, "prep"))                                          # the per-row kernels wait for every layer step of the previous tick
-                edge((k - 1, g), (k, g))                                               # each stream in order
+                edge((k - 1, g), (k, "lin2"))                                          # linear2 (and fuse, tail behind it) waits for every layer step of the previous tick;
+                edge((k - 1, g), (k, g))                                               # prep stands in front of that wait (round 6: it reads none of them). Each stream in order
             edge((k - 1, "L1"), (k, "G4"))
             edge((k - 1, "L1"), (k, "G6"))
-            edge((k - 1, "tail"), (k, "G5"))                                           # (rnn2 l0 behind the tail's init_net state write; L1(k - 1) sits in front of it)
+            # The H = 512 nets' stream: what it NEEDS is linear1 like the other two, and the END of the second stream's tick only behind an
+            # init_net state write of its tail -- the edges modelled here (RC_SEQ_H5_EARLY=1). The default waits for the end on every tick
+            # (measured faster): more ordering, never less.
+            edge((k - 1, "L1"), (k, "G5"))
+            if init:
+                edge((k - 1, "tail"), (k, "G5"))
     for m in range(n):
         hb |= np.outer(hb[:, m], hb[m, :])
     return nodes, hb
