@@ -1256,7 +1256,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // counters instead of events, and leave 256 - res_wgs CUs to the second stream, whose chain linear1 -> prep -> [all layer steps of
     // the previous tick] -> linear2 -> fuse -> tail now talks to the layer steps through two flags and one counter per tick.
     // Same items, same arithmetic: bitwise the streams' result.
-    const int res_wgs = std::min(224, std::max(8, ctx->resident_wgs));
+    const int res_wgs = std::min(248, std::max(8, ctx->resident_wgs));
     const bool resident = tri && ctx->resident_on && B <= 256 && P.n_ticks > 0 && !(ctx->timing && ctx->timing_mode != 3);
     if (resident) {
         if (int rc = ensure_lds_pool(ctx)) return rc;
