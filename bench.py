@@ -359,12 +359,12 @@ def live_b1(sd, body, frames=2000):
         extra = {"prof": prof[50:], "spin": net.live_spin_stats(), "replayed": net.live_replayed(), "presteps": net.live_prestep_stats()[0]}
         return lat, lean, full, bool(cap.value), bool(aql.value), note.value.decode(), extra
 
-    def paced_record(env, what):
+    def paced_record(env, what, frames=None):
         """config 5 as BASELINE states it: a frame every 16.67 ms, the device idle in between; latency from the frame's ARRIVAL. Beside the
         percentiles: where the slowest 1 % of the frames spent their time on the host (rc_get_live_last_profile) -- a slow frame whose
         `wait` segment (enqueue done -> completion seen; the device time is inside it) is as short as everybody's was late BEFORE it
         reached the library (the pacing loop's own wake-up), one whose wait is long was slow on the queue / device."""
-        lat, lean, full, _, _, _, ex = run(PACED_FRAMES, env, 1.0 / 60.0)
+        lat, lean, full, _, _, _, ex = run(frames or PACED_FRAMES, env, 1.0 / 60.0)
         pr = ex["prof"]
         host_in = lat - pr[:, :4].sum(1)                                    # arrival -> rc_live_step entered + return -> clock read: the caller's side
         slow = lat >= np.percentile(lat, 99)
@@ -399,7 +399,8 @@ def live_b1(sd, body, frames=2000):
     out["paced_60fps"] = paced_record({}, "default: idle-time pre-step + armed queue; no kernel left waiting on the device between frames")
     if aql:
         out["paced_60fps_spin"] = paced_record({"RC_LIVE_SPIN": "1"}, "RC_LIVE_SPIN=1 (opt-in): the next frame is queued ahead, its first kernel polls a "
-                                               "mailbox on the device until the inputs arrive (~84 workgroups busy between frames)")
+                                               "mailbox on the device until the inputs arrive (~84 workgroups busy between frames)",
+                                               frames=max(250, PACED_FRAMES * 2 // 5))       # (the opt-in leg: 6.7 s of the default run instead of 16.7)
     if aql:
         lat2 = run(max(200, frames // 4), {"RC_LIVE_AQL": "0"})[0]
         out["graph_replay"] = {"p50_us": round(float(np.percentile(lat2, 50)), 1), "p99_us": round(float(np.percentile(lat2, 99)), 1),
