@@ -157,7 +157,7 @@ int rc_get_launch_stats(rc_ctx* ctx, int64_t* lds_launches, int64_t* other_wide_
 /* Resident layer-step kernel of the wavefront engine (round 6; north_star: "fused persistent kernel ... across timesteps"). With enable != 0
  * a planned rc_sequence call of a context of 160 .. 256 rows in split-product mode runs the LSTM layer steps AND the linear1 layers of
  * ALL its ticks (net/sig_mp.py:126-129 over every frame of the call; articulate/utils/torch/rnn.py:129-133 is the reference's own
- * whole-sequence form) in ONE launch of `workgroups` (default 224, at most 248; 0 keeps the current value) resident workgroups that take work items from a
+ * whole-sequence form) in ONE launch of `workgroups` (default 224, at most 240; 0 keeps the current value) resident workgroups that take work items from a
  * queue in device memory, ordered by counters instead of stream events; prep / linear2 / fuse / tail stay launches of the second stream.
  * Results are bitwise those of the stream engine. Default off (RC_SEQ_RESIDENT=1 switches it on at rc_create): measured slower than the
  * three-stream ticks. A wait inside the kernel that runs out (RC_SEQ_RESIDENT_BOUND_MS, 2000) marks the call failed: the NEXT

@@ -1256,7 +1256,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     // counters instead of events, and leave 256 - res_wgs CUs to the second stream, whose chain linear1 -> prep -> [all layer steps of
     // the previous tick] -> linear2 -> fuse -> tail now talks to the layer steps through two flags and one counter per tick.
     // Same items, same arithmetic: bitwise the streams' result.
-    const int res_wgs = std::min(248, std::max(8, ctx->resident_wgs));
+    const int res_wgs = std::min(240, std::max(8, ctx->resident_wgs));
     const bool resident = tri && ctx->resident_on && B <= 256 && P.n_ticks > 0 && !(ctx->timing && ctx->timing_mode != 3);
     if (resident) {
         if (int rc = ensure_lds_pool(ctx)) return rc;
@@ -1271,7 +1271,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             const size_t cap = nt + nt / 4 + 64;
             HIP_TRY(ctx, hipMalloc((void**)&ctx->res_ticks_d, cap * sizeof(ResidentTick)));
             HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_ticks_h, cap * sizeof(ResidentTick), hipHostMallocDefault));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->res_ints_d, (cap * (RC_RES_MAXP + 2) + 1 + 4) * sizeof(int)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->res_ints_d, (cap * (RC_RES_MAXP + 2) + 1 + 4 + 16) * sizeof(int)));   // (+ 16: the sums of a -DRC_RES_PROF build)
             HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_base_h, (cap + 1) * sizeof(int), hipHostMallocDefault));
             if (!ctx->res_abort_h) {
                 HIP_TRY(ctx, hipHostMalloc((void**)&ctx->res_abort_h, sizeof(int), hipHostMallocDefault));
@@ -1331,7 +1331,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         ctx->res_base_h[nt] = run;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->res_ticks_d, ctx->res_ticks_h, nt * sizeof(ResidentTick), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(item_base_d, ctx->res_base_h, (nt + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemsetAsync(done_d, 0, (cap * (RC_RES_MAXP + 1) + 4) * sizeof(int), st));
+        HIP_TRY(ctx, hipMemsetAsync(done_d, 0, (cap * (RC_RES_MAXP + 1) + 4 + 16) * sizeof(int), st));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_main[6], st));
         HIP_TRY(ctx, hipStreamWaitEvent(aux, ctx->ev_main[6], 0));
         ResidentArgs R{};
@@ -1370,6 +1370,17 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_aux[0], 0));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->res_abort_h, words_d + 3, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipGetLastError());
+#ifdef RC_RES_PROF
+        {   // profiling builds (tools/probe_resprof.so): where the resident workgroups' time went, per item
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            unsigned long long ph[5];
+            const unsigned long long* pd = (const unsigned long long*)(((unsigned long long)(words_d + 4) + 7ull) & ~7ull);
+            if (hipMemcpy(ph, pd, sizeof(ph), hipMemcpyDeviceToHost) == hipSuccess && ph[2] > 0)
+                std::fprintf(stderr, "[res prof] %d ticks, %llu items on %d workgroups; per item: wait %.2f us, item %.2f us, release %.2f us, take %.2f us; per workgroup %.2f ms\n",
+                             P.n_ticks, ph[2], res_wgs, ph[0] / 100.0 / ph[2], ph[1] / 100.0 / ph[2], ph[3] / 100.0 / ph[2], ph[4] / 100.0 / ph[2],
+                             (ph[0] + ph[1] + ph[3] + ph[4]) / 100.0 / 1000.0 / res_wgs);
+        }
+#endif
         ctx->stat_resident_segments += 1;
         ctx->stat_wave_frames += t_last - t0 + 1;
         return RC_OK;

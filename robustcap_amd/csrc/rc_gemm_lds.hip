@@ -108,7 +108,8 @@ __device__ __forceinline__ void split_block(const f32x4& x0, const f32x4& x1, u3
 __device__ __forceinline__ void gload(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void gload1k(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(d) : "v"(p) : "memory"); }
 template <int OFF>   // the instruction offset moves the global AND the LDS address: plane p of a column block sits 1 KiB further in both
-__device__ __forceinline__ void glds(const u32x4* g, unsigned lds) {
+__device__ __forceinline__ void glds(const u32x4* g, unsigned lds_) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_);   // m0 takes a scalar register: said here, where it is used (free when it already is one)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds), "n"(OFF) : "memory");
@@ -575,10 +576,29 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_resident_kernel(const 
     __shared__ int s_item;
     const int total = R.item_base[R.n_ticks];
     int k = 0;
+#ifdef RC_RES_PROF
+    __shared__ unsigned long long s_prof[6];      // (in LDS: the kernel has no register to spare)
+    enum { p_wait = 0, p_item = 1, p_n = 2, p_rel = 3, p_grab = 4, p_t = 5 };
+    if (threadIdx.x == 0) { for (int i = 0; i < 5; ++i) s_prof[i] = 0; s_prof[p_t] = wall_clock64(); }
+#define RES_STAMP(ACC) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); s_prof[ACC] += n_ - s_prof[p_t]; s_prof[p_t] = n_; } } while (0)
+#else
+#define RES_STAMP(ACC) do { } while (0)
+#endif
     for (;;) {
         if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(R.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int g = __builtin_amdgcn_readfirstlane(s_item);
+#ifdef RC_RES_PROF
+        if (g >= total) {
+            if (threadIdx.x == 0) {
+                // (-DRC_RES_PROF builds: five 64-bit sums behind the abort word -- [0] ticks waited for dependencies, [1] in items, [2] items, [3] in the release, [4] taking items)
+                unsigned long long* prof = (unsigned long long*)(((unsigned long long)(R.abort + 1) + 7ull) & ~7ull);
+                for (int i = 0; i < 5; ++i) atomicAdd(prof + i, s_prof[i]);
+            }
+            return;
+        }
+        RES_STAMP(p_grab);
+#endif
         if (g >= total) return;
         while (g >= R.item_base[k + 1]) ++k;
         // The tick's table entry is read through the CONSTANT address space (scalar loads into SGPRs on demand, like the kernel arguments of
@@ -590,8 +610,13 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_resident_kernel(const 
         int pi = 0;
         for (int q = 1; q < T->n; ++q) if (item >= T->p[q].wg_base) pi = q;
         resident_wait(R, T, k, pi);
+        RES_STAMP(p_wait);
         typedef const __attribute__((address_space(4))) LdsProblem* ProbC;
         (void)lds_item<RC_RES_MAXP, true, ProbC>(T->p, T->n, T->B, item, ring, s_rows, s_cnt, &pi);
+        RES_STAMP(p_item);
+#ifdef RC_RES_PROF
+        if (threadIdx.x == 0) s_prof[p_n] += 1;
+#endif
         // the item's stores (h, c; a writer's half sum went out behind its own flag) are visible before it counts as finished
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -603,6 +628,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void rc_gemm_resident_kernel(const 
             // (nothing of this wave is in flight when the next item starts: its K loop counts outstanding vector-memory operations)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        RES_STAMP(p_rel);
     }
 }
 
