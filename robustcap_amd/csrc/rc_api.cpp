@@ -575,8 +575,13 @@ void build_lds_launch(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const uns
 }
 
 // LSTM layer steps on the shared-weight kernel (rc_gemm_lds.hip): problems marked mr = 16
-int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps, const unsigned char* flags_override, hipStream_t st, hipEvent_t stop, bool* launched) {
+int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps_in, const unsigned char* flags_override, hipStream_t st, hipEvent_t stop, bool* launched) {
     if (int rc = ensure_lds_pool(ctx)) return rc;
+    // RC_DBG_REPLICATE=n (tools/lds_load_probe.sh; timing only -- the copies write the same outputs): the launch carries every problem n
+    // times: how long one and the same item takes with 1x, 2x, 3x, 4x as many CUs in a K loop beside it
+    static const int replicate = std::getenv("RC_DBG_REPLICATE") ? std::atoi(std::getenv("RC_DBG_REPLICATE")) : 1;
+    std::vector<GemmProblem> ps(ps_in);
+    for (int r = 1; r < replicate && (int)ps.size() + (int)ps_in.size() <= RC_LDS_MAXP; ++r) ps.insert(ps.end(), ps_in.begin(), ps_in.end());
     LdsLaunch L{};
     const size_t region = ctx->lds_rot++ % kLdsRegions;
     float* slab = ctx->lds_slab + region * ctx->lds_region_tiles * RC_LDS_SLAB_FLOATS;
