@@ -178,7 +178,11 @@ int rc_plan_wave(const int8_t* codes, int32_t B, int32_t T, int32_t t0, const in
  * rc_live_step replays the short one when the confidences it was handed rule out a transition step, else the full one
  * (frames with first_tran / RC_FLAG_FIRST_FRAME take the ordinary enqueue path) and returns when the outputs are in
  * host memory. j2dc[batch,33,3], accc[batch,6,3], oric[batch,6,3,3], first_tran[batch,3]|NULL -> pose[batch,24,3,3],
- * tran[batch,3]. */
+ * tran[batch,3].
+ * Round 6: before the pre-built AQL packet chain of the lean frame (batch <= 4) is trusted, rc_live_begin runs ONE probe frame through it
+ * and through the graph replay of the same launches from the same state (every small device buffer of the context is saved and put back:
+ * the check leaves no trace) and requires the same bits; otherwise the chain is dropped and live frames replay the graph
+ * (rc_get_live_backend: aql = 0 and the reason). RC_LIVE_AQL_SELFCHECK=0 skips the check. */
 int rc_live_begin(rc_ctx* ctx);
 int rc_live_step(rc_ctx* ctx, const float* j2dc_host, const float* accc_host, const float* oric_host,
                  const float* first_tran_host, uint32_t flags, float* pose_host, float* tran_host);

@@ -105,6 +105,7 @@ struct rc_ctx {
     std::map<std::string, std::vector<float>> staged;    // host copy of the tensors loaded since the last rc_finalize_weights
                                                          // (released there: a context does not hold 254 MB of host memory)
     std::vector<void*> allocs;
+    std::vector<std::pair<void*, size_t>> alloc_bytes;   // (pointer, bytes) of every dev_alloc that is not a weight: state + scratch
     std::vector<void*> weight_allocs;    // packed weights of the current rc_finalize_weights (freed by the next one)
     bool alloc_weights = false;          // dev_alloc books into weight_allocs
     // ordering between the eager entry points (caller's stream) and the live graph (private stream)
@@ -224,6 +225,7 @@ struct rc_ctx {
     int* res_abort_h = nullptr;              // pinned: the abort word of the last segment
     size_t res_cap = 0;
     long long stat_resident_segments = 0, stat_resident_aborts = 0;
+    bool live_selfcheck_ran = false;         // rc_live_begin compared the packet chain with the graph replay (live_selfcheck)
     bool resident_on = false;                // rc_set_resident / RC_SEQ_RESIDENT
     int resident_wgs = 224;                  // workgroups of the resident kernel (RC_SEQ_RESIDENT_WGS; the CUs it leaves run the second stream)
     long long stat_lds_launches = 0;
@@ -248,6 +250,7 @@ int dev_alloc(rc_ctx* ctx, T** p, size_t count, bool zero = true) {
     HIP_TRY(ctx, hipMalloc(&q, count * sizeof(T)));
     if (zero) HIP_TRY(ctx, hipMemset(q, 0, count * sizeof(T)));
     (ctx->alloc_weights ? ctx->weight_allocs : ctx->allocs).push_back(q);
+    if (!ctx->alloc_weights) ctx->alloc_bytes.emplace_back(q, count * sizeof(T));      // (what live_selfcheck saves and puts back: state + scratch)
     *p = static_cast<T*>(q);
     return RC_OK;
 }
@@ -1618,6 +1621,67 @@ int rc_ctx_fail(rc_ctx* ctx, int code, const char* msg) { return fail(ctx, code,
 SmplifyState*& rc_ctx_smplify(rc_ctx* ctx) { return ctx->smplify; }
 unsigned long long rc_ctx_ign_mask(rc_ctx* ctx) { return ctx->ign_mask; }
 
+// Begin-time self-check of the AQL packet chain (round-4/5 review): ONE lean frame on a fixed synthetic input, once as the graph replay
+// of the captured launches and once as the pre-built packets on the context's own HSA queue, from the same state -- every small device
+// buffer of the context (recurrent state, fusion state, scratch; weights excluded) is saved first and put back after each run, so the
+// check leaves no trace. Outputs must agree bit for bit (same kernels, same arguments); if they do not, or the chain does not retire, the
+// chain is dropped and live frames replay the graph (rc_get_live_backend tells). RC_LIVE_AQL_SELFCHECK=0 skips it, =2 forces the
+// mismatch path (tests/test_gpu_live.py). live_server.py:40-48 is the loop this protects.
+std::string live_selfcheck(rc_ctx* ctx) {
+    static const int mode = std::getenv("RC_LIVE_AQL_SELFCHECK") ? std::atoi(std::getenv("RC_LIVE_AQL_SELFCHECK")) : 1;
+    if (mode == 0 || !ctx->live_aql || ctx->aql_prog_lean < 0 || !ctx->live_exec_lean || !ctx->live_zero_copy) return std::string();
+    const size_t B = ctx->B;
+    hipStream_t st = ctx->live_stream;
+    if (hipDeviceSynchronize() != hipSuccess) return "self-check: device synchronisation failed";
+    // save
+    const size_t kMaxBytes = 8u << 20;
+    std::vector<std::pair<void*, size_t>> regs;
+    size_t total = 0;
+    for (const auto& r : ctx->alloc_bytes) if (r.second <= kMaxBytes) { regs.push_back(r); total += r.second; }
+    std::vector<char> save(total);
+    size_t off = 0;
+    for (const auto& r : regs) { if (hipMemcpy(save.data() + off, r.first, r.second, hipMemcpyDeviceToHost) != hipSuccess) return "self-check: state read-back failed"; off += r.second; }
+    auto restore = [&]() -> bool {
+        size_t o = 0;
+        for (const auto& r : regs) { if (hipMemcpy(r.first, save.data() + o, r.second, hipMemcpyHostToDevice) != hipSuccess) return false; o += r.second; }
+        *ctx->live_status_h = 0;
+        return hipDeviceSynchronize() == hipSuccess;
+    };
+    // a mid-confidence frame (no init_net trigger, no deferred updater step): identity orientations, small accelerations, a plausible skeleton
+    std::vector<float> in_keep(ctx->live_in_h, ctx->live_in_h + B * 171), out_keep(ctx->live_out_h, ctx->live_out_h + B * 219);
+    for (size_t b = 0; b < B; ++b) {
+        float* j = ctx->live_in_h + b * 99;
+        for (int k = 0; k < 33; ++k) { j[3 * k] = 0.05f * (float)((k * 7) % 11 - 5) / 5.0f; j[3 * k + 1] = 0.08f * (float)((k * 5) % 13 - 6) / 6.0f; j[3 * k + 2] = 0.75f; }
+        float* a = ctx->live_in_h + B * 99 + b * 18;
+        for (int k = 0; k < 18; ++k) a[k] = 0.01f * (float)(k % 5 - 2);
+        float* o = ctx->live_in_h + B * 117 + b * 54;
+        for (int k = 0; k < 54; ++k) o[k] = (k % 9 == 0 || k % 9 == 4 || k % 9 == 8) ? 1.0f : 0.0f;
+    }
+    std::string verdict;
+    std::vector<float> out_graph(B * 219), out_aql(B * 219);
+    int status_graph = 0, status_aql = 0;
+    for (size_t q = 0; q < B * 219; ++q) ctx->live_out_h[q] = -7.0f;
+    if (hipGraphLaunch(ctx->live_exec_lean, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) verdict = "self-check: graph replay of the lean frame failed";
+    status_graph = *ctx->live_status_h;
+    std::copy(ctx->live_out_h, ctx->live_out_h + B * 219, out_graph.begin());
+    if (!restore() && verdict.empty()) verdict = "self-check: state restore failed";
+    if (verdict.empty()) {
+        for (size_t q = 0; q < B * 219; ++q) ctx->live_out_h[q] = -7.0f;
+        if (rc_aql_run(ctx->live_aql, ctx->aql_prog_lean) != 0) verdict = "self-check: the packet chain did not retire";
+        status_aql = *ctx->live_status_h;
+        std::copy(ctx->live_out_h, ctx->live_out_h + B * 219, out_aql.begin());
+        if (mode == 2) { uint32_t u; std::memcpy(&u, &out_aql[0], 4); u ^= 1u; std::memcpy(&out_aql[0], &u, 4); }      // forced mismatch (test hook)
+        if (!restore() && verdict.empty()) verdict = "self-check: state restore failed";
+    }
+    std::copy(in_keep.begin(), in_keep.end(), ctx->live_in_h);
+    std::copy(out_keep.begin(), out_keep.end(), ctx->live_out_h);
+    if (verdict.empty() && (status_graph != status_aql || std::memcmp(out_graph.data(), out_aql.data(), B * 219 * sizeof(float)) != 0)) {
+        verdict = "self-check: packet chain and graph replay disagree on the probe frame";
+    }
+    ctx->live_selfcheck_ran = true;
+    return verdict;
+}
+
 extern "C" {
 
 int rc_default_params(int32_t live, rc_params* out) {
@@ -2286,6 +2350,16 @@ int rc_live_begin(rc_ctx* ctx) {
             if (ctx->live_exec_lean) { (void)hipGraphExecDestroy(ctx->live_exec_lean); ctx->live_exec_lean = nullptr; }
             if (ctx->live_graph_lean) { (void)hipGraphDestroy(ctx->live_graph_lean); ctx->live_graph_lean = nullptr; }
             ctx->live_aql_note = why;
+        } else if (ctx->live_aql) {
+            const std::string bad = live_selfcheck(ctx);
+            if (!bad.empty()) {                                            // drop the chain, keep the lean graph: frames replay it
+                rc_aql_destroy(ctx->live_aql); ctx->live_aql = nullptr;
+                ctx->spin_mb = nullptr; ctx->spin_in = nullptr; ctx->spin_pending = -1; ctx->spin_valid = false;
+                for (int q = 0; q < 2; ++q) ctx->aql_prog_spin[q] = ctx->aql_prog_spin_pre[q] = -1;
+                ctx->aql_prog_lean = ctx->aql_prog_lean_pre = ctx->aql_prog_pre = -1;
+                ctx->live_pre_valid = false;
+                ctx->live_aql_note = bad;
+            }
         }
     }
     ctx->timing = timing;

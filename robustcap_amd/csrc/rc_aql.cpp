@@ -13,7 +13,12 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 
+#if defined(__x86_64__) || defined(_M_X64)
 #include <immintrin.h>
+#define RC_STORE_FENCE() _mm_sfence()          // posted writes to the device's BAR leave the write-combining buffers in program order
+#else
+#define RC_STORE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#endif
 
 #include <chrono>
 #include <cstdio>
@@ -419,7 +424,7 @@ int rc_aql_run(AqlChain* c, int prog) {
 // the last frame has retired (its dispatch packets are consumed, its release fence has run): before anything else touches the queue
 static void aql_drain(AqlChain* c) {
     if (!c || !c->q) return;
-    if (c->mailbox) { c->mailbox[0] = 2u; c->mailbox[32] = 2u; _mm_sfence(); }                  // a K1 still spinning (rc_live.hip) leaves: nothing is queued behind it
+    if (c->mailbox) { c->mailbox[0] = 2u; c->mailbox[32] = 2u; RC_STORE_FENCE(); }                  // a K1 still spinning (rc_live.hip) leaves: nothing is queued behind it
     aql_release(c);
     if (c->mailbox && !c->dead) (void)rc_aql_fence_background(c);           // ... and the wait below covers it
     if (c->seq) (void)hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, (hsa_signal_value_t)(c->sig0 - (long long)c->seq) + 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
