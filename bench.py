@@ -237,7 +237,7 @@ class Workload:
             raise RuntimeError("no gate-GEMM launch was timed")
         flop_per_launch = B * (C.FLOPS_LSTM_PER_BODY_FRAME if lds else C.FLOPS_PER_BODY_FRAME - C.FLOPS_LINEAR2_PER_BODY_FRAME) * K / launches
         avg_s = ms * 1e-3 / launches
-        # The wavefront engine issues the two wide launches of a tick on two streams: they share the chip, so a launch's own
+        # The wavefront engine issues the wide launches of a tick on two / three streams: they share the chip, so a launch's own
         # duration covers time in which the other one holds part of the CUs. The kernel's rate is its FLOPs over the time during
         # which it runs at all (union of the launch intervals); the per-launch figure is kept beside it (it is what a rocprofv3
         # kernel summary shows: avg_launch_us there = avg_launch_us here).
@@ -265,9 +265,12 @@ class Workload:
                 "note": "achieved: the algorithmic fp32 FLOPs of one wide-tile gate-GEMM launch / the average HIP-event duration of such a "
                         "launch (avg_launch_us: what a rocprofv3 --kernel-trace --stats summary of the same command shows for the kernel); "
                         "peak: the roof of the instructions the kernel issues (split mode: dense bf16 MFMA peak / 6 partial products = "
-                        "416.7 TFLOP/s fp32-equivalent; fp32 mode: the 157.3 TFLOP/s fp32-input MFMA peak); frac = achieved / peak, the "
-                        "figure to read as MFMA utilisation. union: the same FLOPs over the time during which at least one such launch "
-                        "runs (launches on two streams overlap: concurrency = sum of the launch durations / that time); frac_fp32_roof: "
+                        "416.7 TFLOP/s fp32-equivalent; fp32 mode: the 157.3 TFLOP/s fp32-input MFMA peak); frac = achieved / peak PER "
+                        "LAUNCH. Since round 6 a tick is THREE launches of this kernel on three streams (rnn4 | rnn6 | the H = 512 nets) "
+                        "that run side by side, each on its share of the CUs: a launch's own duration is `concurrency` (= sum of the "
+                        "launch durations / the time at least one runs) times what its work takes on the whole chip, so the kernel's MFMA "
+                        "utilisation ON THE CHIP is union.frac = the same FLOPs over the time during which at least one such launch runs "
+                        "(round 5: two launches per tick, per-launch 0.21, union 0.33); frac_fp32_roof: "
                         "the union rate against the fp32-input roof (rounds 1-4 quoted it as frac; it may exceed 1 in split mode); "
                         "path_frac: whole frame incl. the weight-streaming 16-row launches and the per-frame logic kernels, against peak"}
 
