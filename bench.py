@@ -85,6 +85,24 @@ def make_inputs(body, B, T, conf, seed, unique=32):
     return out
 
 
+def make_inputs_device(body, B, T, conf, seed, unique=32):
+    """``make_inputs`` with forward kinematics, IMU synthesis and projection on the GPU (robustcap_amd.preprocess.make_motion_device: SURVEY.md
+    8(f) rank 3); the inputs are born in HBM. Same seeds, same trajectories, same tiling of `unique` motions with per-body confidence
+    schedules; equal to the host generator to fp32 rounding (tests/test_gpu_evaluate.py). Returns device tensors j2dc / accc / oric and
+    host arrays gravityc / first_tran."""
+    from robustcap_amd import preprocess
+    u = min(B, unique)
+    m = preprocess.make_motion_device(seed, u, T, body, conf=conf)
+    rep = (B + u - 1) // u
+    out = {k: (torch.cat([v] * rep, 0)[:B].clone() if torch.is_tensor(v) else np.concatenate([v] * rep, 0)[:B].copy()) for k, v in m.items()}
+    if B > u:   # decorrelate the regimes of the tiled copies: per-body confidence schedule
+        c_new = np.stack([synth.conf_schedule(seed * 7919 + b, 7, T, conf) for b in range(u, B)]).astype(np.float32)           # [B-u, T]
+        shift = torch.from_numpy(c_new - out["conf"][u:]).to(out["j2dc"].device)
+        out["j2dc"][u:, :, :, 2] = torch.clamp(out["j2dc"][u:, :, :, 2] + shift[:, :, None], 0.0, 1.0)
+        out["conf"] = out["j2dc"][..., 2].mean(-1).cpu().numpy()
+    return out
+
+
 def cpu_baseline(sd, body, m, frames_batched=CPU_FRAMES_BATCHED, frames_single=CPU_FRAMES_SINGLE, samples=CPU_SAMPLES):
     """The oracle (a port, parity-pinned to the reference) on this host's cores: batched (median of ``samples``
     back-to-back samples of ``frames_batched`` frames each) and batch-1 frame by frame like evaluate.py.
@@ -150,10 +168,14 @@ class Workload:
     def __init__(self, sd, body, conf, B, W, frames, rank, world, seed_base=2, split=None):
         from robustcap_amd.net.sig_mp import Net
         self.conf, self.B, self.W, self.rank, self.world = conf, B, W, rank, world
-        self.m = make_inputs(body, B, W + frames, conf, seed=seed_base + rank)
         dev = torch.device("cuda")
         self.dev = dev
-        self.j2d, self.acc, self.ori = (torch.from_numpy(self.m[k]).to(dev) for k in ("j2dc", "accc", "oric"))
+        if os.environ.get("RC_BENCH_HOST_INPUTS"):                          # (A/B: the host generator)
+            self.m = make_inputs(body, B, W + frames, conf, seed=seed_base + rank)
+            self.j2d, self.acc, self.ori = (torch.from_numpy(self.m[k]).to(dev) for k in ("j2dc", "accc", "oric"))
+        else:
+            self.m = make_inputs_device(body, B, W + frames, conf, seed=seed_base + rank)
+            self.j2d, self.acc, self.ori = (self.m[k] for k in ("j2dc", "accc", "oric"))
         self.ft = torch.from_numpy(self.m["first_tran"]).to(dev)
         self.net = Net(body=body, batch=B)
         self.net.load_state_dict(sd)

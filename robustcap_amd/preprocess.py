@@ -48,3 +48,39 @@ def synthesize_imu(model, pose, tran, smooth_n=2, vertex_ids=cfg.vi_mask, joint_
                                  _lib.ptr(joint), _lib.ptr(vert6), _lib.stream_ptr())
     _lib.check(model._ctx, rc, "rc_synth_imu")
     return ori, acc, joint, vert6
+
+
+def make_motion_device(seed, B, T, body, conf="mixed", noise=0.003, model=None, device="cuda"):
+    """``synth.make_motion`` with the heavy part on the GPU ("on-device generator for benchmark inputs (FK -> ori /
+    acc / 2D), removes host prep from large-B runs"; the recipe is preprocess.py:22-33, 206-222 + the projection of evaluate.py:70-72).
+
+    The seeded random walks (24 axis-angles, root yaw / tilt, root translation, confidence schedule, unit keypoint noise) are a few
+    hundred floats per frame and stay host numpy -- the SAME numbers as ``make_motion``; forward kinematics + the 33 landmarks
+    (``rc_body_fk``), the six virtual IMUs (``rc_synth_imu``: global orientation of joints ji_mask, smoothed second difference of vertices
+    vi_mask) and the projection run on the device and the outputs stay there. Returns the dict of ``make_motion`` with device tensors for
+    j2dc / accc / oric / pose / tran and host arrays for gravityc / first_tran / conf; equal to the host generator to fp32 rounding."""
+    from . import synth
+    dev = torch.device(device)
+    model = model or _body.ParametricModel(body=body, device=device)
+    R, tr, ck, unit, grav = [], [], [], [], []
+    for b in range(B):
+        s = seed * 7919 + b
+        r, g, t_ = synth.motion_trajectory(s, T)
+        c, u = synth.motion_confidence(s, T, conf)
+        R.append(r); tr.append(t_); ck.append(c); unit.append(u); grav.append(g)
+    pose = torch.from_numpy(np.stack(R).astype(np.float32)).to(dev)                      # [B,T,24,3,3]
+    tran = torch.from_numpy(np.stack(tr).astype(np.float32)).to(dev)                      # [B,T,3]
+    ckd = torch.from_numpy(np.stack(ck).astype(np.float32)).to(dev)                       # [B,T,33]
+    unitd = torch.from_numpy(np.stack(unit).astype(np.float32)).to(dev)                   # [B,T,33,2]
+    _, _, j33 = model.forward_kinematics(pose.view(-1, 24, 3, 3), tran=tran.view(-1, 3), calc_mesh=True)
+    j33 = j33.view(B, T, 33, 3)
+    uv = j33[..., :2] / j33[..., 2:] + noise * (1.0 - ckd)[..., None] * unitd
+    j2dc = torch.cat([uv, ckd[..., None]], -1).contiguous()
+    ori = torch.empty(B, T, 6, 3, 3, device=dev)
+    acc = torch.empty(B, T, 6, 3, device=dev)
+    for b in range(B):                                                                    # (the stencil runs along one sequence)
+        o, a, _, _ = synthesize_imu(model, pose[b], tran[b], smooth_n=2 if T > 4 else 1)
+        ori[b], acc[b] = o, a
+    return {"j2dc": j2dc, "accc": acc, "oric": ori, "pose": pose, "tran": tran,
+            "gravityc": np.stack(grav).astype(np.float32), "first_tran": np.stack(tr)[:, 0].astype(np.float32),
+            "conf": np.stack(ck).mean(-1).astype(np.float32)}

@@ -207,6 +207,37 @@ def conf_schedule(seed, stream, T, kind):
     return c
 
 
+def motion_trajectory(s, T):
+    """One body's seeded trajectory (float64): local rotations R [T,24,3,3] with the root expressed in the camera frame, the gravity
+    direction g [3] in that frame and the root translation tr [T,3] (a smooth walk inside x,y in [-1,1], z in [3,8])."""
+    # smooth local axis-angle trajectories, amplitude ~0.5 rad
+    aa = np.cumsum(0.02 * normal(s, 1, T * 72).reshape(T, 24, 3).astype(np.float64), 0)
+    aa = _smooth(aa, 9)
+    aa = 0.7 * np.tanh(aa / 0.7)
+    R = _rodrigues(aa)
+    # root: camera looks along +z, image y points down -> body up (+y) maps to -y; slow yaw + small tilt
+    yaw = _smooth(np.cumsum(0.03 * normal(s, 2, T).astype(np.float64)), 15) + 6.28 * uniform01(s, 3, 1)[0]
+    tilt = 0.15 * (uniform01(s, 4, 3).astype(np.float64) - 0.5)
+    Rtilt = _rodrigues(tilt)
+    flip = np.diag([1.0, -1.0, -1.0])
+    Ry = _rodrigues(np.stack([np.zeros(T), yaw, np.zeros(T)], -1))
+    R[:, 0] = Rtilt @ flip @ Ry @ R[:, 0]
+    g = Rtilt @ flip @ np.array([0.0, -1.0, 0.0])
+    u0 = uniform01(s, 5, 3).astype(np.float64)
+    start = np.array([-0.8 + 1.6 * u0[0], -0.5 + 1.0 * u0[1], 3.5 + 3.5 * u0[2]])
+    walk = _smooth(np.cumsum(0.012 * normal(s, 6, T * 3).reshape(T, 3).astype(np.float64), 0), 15)
+    tr = start + 1.2 * np.tanh(walk / 1.2)
+    return R, g, tr
+
+
+def motion_confidence(s, T, conf):
+    """Per-keypoint confidences ck [T,33] of one body (schedule + per-keypoint spread) and the unit keypoint noise [T,33,2]."""
+    c = conf_schedule(s, 7, T, conf) if isinstance(conf, str) else np.asarray(conf, np.float64)
+    dk = 0.04 * (uniform01(s, 8, T * 33).reshape(T, 33).astype(np.float64) - 0.5)
+    dk -= dk.mean(1, keepdims=True)
+    return np.clip(c[:, None] + dk, 0.0, 1.0), normal(s, 9, T * 66).reshape(T, 33, 2)
+
+
 def make_motion(seed, B, T, body, conf="mixed", noise=0.003):
     """Synthetic 60 fps camera-frame sequences for B bodies x T frames (all float32):
 
@@ -214,29 +245,13 @@ def make_motion(seed, B, T, body, conf="mixed", noise=0.003):
     gravityc [B,3]   first_tran [B,3]            plus ground truth pose [B,T,24,3,3], tran [B,T,3].
     IMU recipe: ori = global rotation of joints ji_mask, acc = smoothed second difference * 3600 of vertices
     vi_mask (preprocess.py:22-33, 221-222), both expressed in the camera frame.
+    (robustcap_amd.preprocess.make_motion_device: the same sequences with FK, IMU synthesis and projection on the GPU.)
     """
     ids = list(C.mp_mask) + list(C.vi_mask)
     out = {k: [] for k in ("j2dc", "accc", "oric", "gravityc", "first_tran", "pose", "tran", "conf")}
     for b in range(B):
         s = seed * 7919 + b
-        # smooth local axis-angle trajectories, amplitude ~0.5 rad
-        aa = np.cumsum(0.02 * normal(s, 1, T * 72).reshape(T, 24, 3).astype(np.float64), 0)
-        aa = _smooth(aa, 9)
-        aa = 0.7 * np.tanh(aa / 0.7)
-        R = _rodrigues(aa)
-        # root: camera looks along +z, image y points down -> body up (+y) maps to -y; slow yaw + small tilt
-        yaw = _smooth(np.cumsum(0.03 * normal(s, 2, T).astype(np.float64)), 15) + 6.28 * uniform01(s, 3, 1)[0]
-        tilt = 0.15 * (uniform01(s, 4, 3).astype(np.float64) - 0.5)
-        Rtilt = _rodrigues(tilt)
-        flip = np.diag([1.0, -1.0, -1.0])
-        Ry = _rodrigues(np.stack([np.zeros(T), yaw, np.zeros(T)], -1))
-        R[:, 0] = Rtilt @ flip @ Ry @ R[:, 0]
-        g = Rtilt @ flip @ np.array([0.0, -1.0, 0.0])
-        # root translation: smooth walk inside x,y in [-1,1], z in [3,8]
-        u0 = uniform01(s, 5, 3).astype(np.float64)
-        start = np.array([-0.8 + 1.6 * u0[0], -0.5 + 1.0 * u0[1], 3.5 + 3.5 * u0[2]])
-        walk = _smooth(np.cumsum(0.012 * normal(s, 6, T * 3).reshape(T, 3).astype(np.float64), 0), 15)
-        tr = start + 1.2 * np.tanh(walk / 1.2)
+        R, g, tr = motion_trajectory(s, T)
         G, joint, vert = body_fk_numpy(body, R, tr, ids)
         v33, v6 = vert[:, :33].copy(), vert[:, 33:]
         for row, j in C.mp_joint_override.items():
@@ -247,12 +262,9 @@ def make_motion(seed, B, T, body, conf="mixed", noise=0.003):
             acc[1:-1] = (v6[:-2] + v6[2:] - 2 * v6[1:-1]) * 3600
         if T > 4:
             acc[2:-2] = (v6[:-4] + v6[4:] - 2 * v6[2:-2]) * 3600 / 4
-        c = conf_schedule(s, 7, T, conf) if isinstance(conf, str) else np.asarray(conf, np.float64)
-        dk = 0.04 * (uniform01(s, 8, T * 33).reshape(T, 33).astype(np.float64) - 0.5)
-        dk -= dk.mean(1, keepdims=True)
-        ck = np.clip(c[:, None] + dk, 0.0, 1.0)
+        ck, unit = motion_confidence(s, T, conf)
         uv = v33[..., :2] / v33[..., 2:]
-        uv = uv + noise * (1 - ck)[..., None] * normal(s, 9, T * 66).reshape(T, 33, 2)
+        uv = uv + noise * (1 - ck)[..., None] * unit
         out["j2dc"].append(np.concatenate([uv, ck[..., None]], -1))
         out["accc"].append(acc)
         out["oric"].append(ori)
