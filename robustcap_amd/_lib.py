@@ -56,6 +56,7 @@ SIGNATURES = {
     "rc_set_sequence_mode": (_I32, [_P, _I32, _I32]),
     "rc_get_sequence_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64)]),
     "rc_get_launch_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "rc_get_launch_stats_w32": (_I32, [_P, C.POINTER(_I64)]),
     "rc_set_resident": (_I32, [_P, _I32, _I32]),
     "rc_get_resident_stats": (_I32, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "rc_plan_sequence": (_I32, [_P, _I32, _I32, _P, _U32, _I32, _P]),
@@ -118,7 +119,7 @@ _lib = None
 
 
 # entry points newer than round 4: the only ones an A/B library under RC_LIB_PATH may lack
-OPTIONAL_IN_AB_BUILDS = frozenset({"rc_set_resident", "rc_get_resident_stats", "rc_get_launch_stats", "rc_get_live_spin", "rc_get_live_replayed", "rc_get_live_profile", "rc_get_live_last_profile",
+OPTIONAL_IN_AB_BUILDS = frozenset({"rc_get_launch_stats_w32", "rc_set_resident", "rc_get_resident_stats", "rc_get_launch_stats", "rc_get_live_spin", "rc_get_live_replayed", "rc_get_live_profile", "rc_get_live_last_profile",
                                    "rc_get_live_prestep"})
 
 

@@ -229,6 +229,7 @@ struct rc_ctx {
     bool resident_on = false;                // rc_set_resident / RC_SEQ_RESIDENT
     int resident_wgs = 224;                  // workgroups of the resident kernel (RC_SEQ_RESIDENT_WGS; the CUs it leaves run the second stream)
     long long stat_lds_launches = 0;
+    long long stat_w32_launches = 0;         // of the wide launches: those on rc_gemm_split48_w32_kernel (contexts of 33-64 rows)
 };
 
 namespace {
@@ -598,7 +599,8 @@ int launch_lds(rc_ctx* ctx, const std::vector<GemmProblem>& ps_in, const unsigne
         hipEvent_t *a, *b;
         if (!timing_pair(ctx, &a, &b)) return fail(ctx, RC_ERR_HIP, "hipEventCreate");
         HIP_TRY(ctx, hipEventRecord(*a, st));
-        rc_launch_gemm_lds(L, base, st);
+        rc_launch_gemm_lds(L, base, st, stop);      // (the hand-over event rides on the dispatch as in an untimed run: the instrumented pass issues the same tick)
+        if (launched && stop) *launched = true;
         HIP_TRY(ctx, hipEventRecord(*b, st));
     } else {
         rc_launch_gemm_lds(L, base, st, stop);
@@ -732,11 +734,13 @@ int launch_problems(rc_ctx* ctx, std::vector<GemmProblem> ps, const unsigned cha
     L.n = (int)ordered.size();
     ctx->trace_next = (ctx->trace_next + base) & 0x3fffffff;
     if (!rc_gemm_is_small(L)) ctx->stat_wide_launches += 1;
+    if (rc_gemm_is_w32(L)) ctx->stat_w32_launches += 1;
     if (ctx->timing && ctx->timing_mode != 3 && !(ctx->timing_mode == 2 && rc_gemm_is_small(L))) {
         hipEvent_t *a, *b;
         if (!timing_pair(ctx, &a, &b)) return fail(ctx, RC_ERR_HIP, "hipEventCreate");
         HIP_TRY(ctx, hipEventRecord(*a, st));
-        rc_launch_gemm(L, base, st);
+        rc_launch_gemm(L, base, st, stop);
+        if (launched && stop) *launched = true;
         HIP_TRY(ctx, hipEventRecord(*b, st));
     } else {
         rc_launch_gemm(L, base, st, stop);
@@ -2143,6 +2147,12 @@ int rc_get_resident_stats(rc_ctx* ctx, int64_t* segments, int64_t* aborts) {
     return RC_OK;
 }
 
+int rc_get_launch_stats_w32(rc_ctx* ctx, int64_t* w32_launches) {
+    if (!ctx || !w32_launches) return RC_ERR_INVALID;
+    *w32_launches = ctx->stat_w32_launches;
+    return RC_OK;
+}
+
 int rc_get_launch_stats(rc_ctx* ctx, int64_t* tick_launches, int64_t* other_wide_launches) {
     if (!ctx) return RC_ERR_INVALID;
     if (tick_launches) *tick_launches = ctx->stat_lds_launches;   // round 6: launches of the shared-weight kernel (rc_gemm_lds_kernel); round 5 counted its
@@ -2971,7 +2981,7 @@ int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream) {
 int rc_gemm_timing(rc_ctx* ctx, int32_t enable) {
     if (!ctx) return RC_ERR_INVALID;
     ctx->timing = enable != 0;
-    if (enable) ctx->timing_mode = enable == 2 ? 2 : 1;
+    if (enable) ctx->timing_mode = enable == 2 ? 2 : (enable == 3 ? 3 : 1);   // (3 used to fall through to 1: every gate-GEMM launch was timed and averaged as if it were the shared-weight kernel's)
     if (enable) { ctx->ev_used = 0; ctx->timed_ms = 0.0; ctx->timed_launches = 0; ctx->timed_busy_ms = 0.0; }
     return RC_OK;
 }

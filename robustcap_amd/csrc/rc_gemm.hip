@@ -660,6 +660,15 @@ bool rc_gemm_is_mid(const GemmLaunch& L) {
 }
 
 // stop: optional event signalled by THIS dispatch's completion (hipExtLaunchKernelGGL: no separate marker packet in the queue)
+// true: a wide-tile split-product launch that rc_launch_gemm puts on rc_gemm_split48_w32_kernel (every problem 64 x 128 tiles, one row tile)
+bool rc_gemm_is_w32(const GemmLaunch& L) {
+    if (rc_gemm_is_small(L) || rc_gemm_is_mid(L)) return false;
+    bool one_reader = L.split != 0;
+    for (int q = 0; q < L.n; ++q) one_reader = one_reader && L.p[q].mr == 4 && L.p[q].nc == 8 && L.p[q].m_tiles == 1;
+    static const bool w32 = !std::getenv("RC_GEMM_W32") || std::atoi(std::getenv("RC_GEMM_W32")) != 0;
+    return one_reader && w32;
+}
+
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop) {
     const dim3 g(total_wg), b(RC_NW * 64);
 #define RC_GO(K) do { if (stop) hipExtLaunchKernelGGL(K, g, b, 0, s, nullptr, stop, 0, L); else hipLaunchKernelGGL(K, g, b, 0, s, L); } while (0)
@@ -673,10 +682,7 @@ void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t
         if (L.split) RC_GO(rc_gemm_mid_split_kernel);
         else RC_GO(rc_gemm_mid_kernel);
     } else {
-        bool one_reader = L.split != 0;
-        for (int q = 0; q < L.n; ++q) one_reader = one_reader && L.p[q].mr == 4 && L.p[q].nc == 8 && L.p[q].m_tiles == 1;
-        static const bool w32 = !std::getenv("RC_GEMM_W32") || std::atoi(std::getenv("RC_GEMM_W32")) != 0;
-        if (one_reader && w32) RC_GO(rc_gemm_split48_w32_kernel);
+        if (rc_gemm_is_w32(L)) RC_GO(rc_gemm_split48_w32_kernel);
         else if (L.split) RC_GO(rc_gemm_split_kernel);
         else RC_GO(rc_gemm_kernel);
     }

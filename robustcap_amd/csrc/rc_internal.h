@@ -312,6 +312,7 @@ void rc_aql_destroy(AqlChain* c);
 void rc_launch_gemm(const GemmLaunch& L, int total_wg, hipStream_t s, hipEvent_t stop = nullptr);
 void rc_launch_scan_conf(const float* j2d, long long row_stride, int B, int T, double conf_lo, double conf_hi, signed char* codes, hipStream_t s);
 void rc_launch_advance_steps(int* const* steps6, int n_frames, int B, hipStream_t s);
+bool rc_gemm_is_w32(const GemmLaunch& L);       // true: the launch runs on rc_gemm_split48_w32_kernel
 bool rc_gemm_is_small(const GemmLaunch& L);     // true: the launch runs on rc_gemm_small_kernel (16-row tiles only)
 void rc_launch_prep(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, int first_frame, hipStream_t s);
 void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, int B, hipStream_t s);

@@ -439,6 +439,13 @@ class Net:
             lds, other = 0, 0
         if lds > 0:
             return "rc_gemm_lds_kernel"
+        try:
+            w = C.c_int64()
+            _lib.check(self._ctx, self._lib.rc_get_launch_stats_w32(self._ctx, C.byref(w)), "rc_get_launch_stats_w32")
+            if w.value > 0:                                                 # contexts of 33-64 rows: the layer steps run as one-reader launches
+                return "rc_gemm_split48_w32_kernel"
+        except AttributeError:
+            pass
         return "rc_gemm_split_kernel" if self.gemm_mode else "rc_gemm_kernel"
 
     def launch_stats(self):
