@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host side of the wavefront engine at batch 256: when rc_sequence returned (everything enqueued) and when the streams were done, per tick.
-    RC_SEQ_QUAD=0/1 [GPU_MAX_HW_QUEUES=8] python tools/host_enqueue_ab.py [conf]"""
+    [RC_SEQ_RESIDENT=1] [RC_SEQ_H5_EARLY=1] ... python tools/host_enqueue_ab.py [conf]     (the quick A/B of this round's engine experiments,
+    profiles/r06_resident_notes.txt: ~3 s per setting)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,5 +24,5 @@ for rep in range(4):
     res.append((t1 - t0, t2 - t0))
 e, c = min(r[0] for r in res), min(r[1] for r in res)
 w, s, ticks = net.sequence_stats()
-print(f"{os.environ.get('RC_SEQ_QUAD','-')} {os.environ.get('RC_SEQ_SA_PRIO','-')} {os.environ.get('GPU_MAX_HW_QUEUES','-')} {conf}: enqueue returned after {e*1e3:.2f} ms, complete after {c*1e3:.2f} ms "
+print(f"resident={os.environ.get('RC_SEQ_RESIDENT','0')} {conf}: enqueue returned after {e*1e3:.2f} ms, complete after {c*1e3:.2f} ms "
       f"({(T-16)*B/c:.0f} bf/s; {c/(T-16)*1e6:.1f} us/frame, host {e/(T-16)*1e6:.1f} us/frame)")
