@@ -210,7 +210,12 @@ struct rc_ctx {
     int trace_next = 0;                  // tile-trace slot counter (tools/tile_trace.py)
     long long stat_wide_launches = 0;    // launches of the wide-tile kernels (rc_get_launch_stats)
     // shared-weight gate GEMM (rc_gemm_lds.hip): LSTM layer steps of >= lds_min_rows rows in split-product mode
-    int lds_min_rows = 160;              // RC_LDS_MIN_ROWS (0 = never): below, a 256-row tile is mostly padding and the 64-row tiles win
+    // Two thresholds (round 6, second session; tools/ab_batch.py): a CONTEXT takes the shared-weight kernel and the three-stream tick from
+    // lds_min_batch rows (batch 64 loses a third with them: 673k -> 569k mixed), and inside such a context a PROBLEM runs on it from
+    // lds_min_rows rows (the rnn4 / rnn6 problems of a mixed batch hold only the rows that see the camera). One threshold of 160 for both
+    // (first session) left batch 96-128 on the 64-row tiles: batch 128 mixed 858k -> 933k, all-visible 1,073k -> 1,173k; 96: 691k -> 752k.
+    int lds_min_rows = 64;               // RC_LDS_MIN_ROWS (0 = never); default: half the batch, within 64 .. 160 (batch 256: 128 = 160 within the noise, 64 costs 0.7 %)
+    int lds_min_batch = 96;              // RC_LDS_MIN_BATCH
     int lds_ksplit[3] = {1, 2, 2};       // RC_LDS_KSPLIT_512 / _1024 / _1280: workgroups per tile (1: both K halves in one workgroup; the H = 512
                                          // nets' items are short -- 2 x 16 k-blocks -- and a hand-over per tile costs more than it levels: +1 %)
     float* lds_slab = nullptr;           // [kLdsRegions][lds_region_tiles][RC_LDS_SLAB_FLOATS]: half sums in flight, one region per launch
@@ -483,7 +488,7 @@ GemmProblem lstm_problem(const rc_ctx* c, const Stage& s, int layer) {
         if (s.net == N4 && c->tile4[0]) { mr = c->tile4[0]; nc = c->tile4[1]; }
     }
     const int rows = s.rows_hint < 0 ? c->B : (s.rows_hint < c->B ? s.rows_hint : c->B);
-    if (c->gemm_split && c->lds_min_rows > 0 && rows >= c->lds_min_rows) { mr = 16; nc = 8; }   // the shared-weight kernel (rc_gemm_lds.hip)
+    if (c->gemm_split && c->lds_min_rows > 0 && c->B >= c->lds_min_batch && rows >= c->lds_min_rows) { mr = 16; nc = 8; }   // the shared-weight kernel (rc_gemm_lds.hip)
     p.n_tiles = n.H / (4 * nc); p.m_tiles = (rows + 16 * mr - 1) / (16 * mr); p.Kp = 2 * n.H; p.nc = nc; p.mr = mr;
     p.nt = (c->live_nt_mask >> s.net) & 1u;
     return p;
@@ -1166,7 +1171,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
     hipStream_t s2 = ctx->h512_stream, s4 = ctx->lin1_stream;
     static const int regroup_env = tune_env("RC_SEQ_REGROUP", 1);
     static const int lin1_env = tune_env("RC_SEQ_LIN1_STREAM", 1);
-    const bool regroup = split_main && regroup_env != 0 && ctx->gemm_split && ctx->lds_min_rows > 0 && B >= ctx->lds_min_rows;   // (with the shared-weight kernel only)
+    const bool regroup = split_main && regroup_env != 0 && ctx->gemm_split && ctx->lds_min_rows > 0 && B >= ctx->lds_min_batch;   // (with the shared-weight kernel only)
     const bool lin1_own = regroup && lin1_env != 0;
     // tri: THREE streams of layer steps -- rnn4 | rnn6 | the H = 512 nets -- and {linear1, init_net} at the head of the second stream's
     // tick. Each net's chain h(t) -> h(t + 1) then follows its own predecessor only; the drain of one launch is filled by the other two.
@@ -1207,7 +1212,7 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             if (kind == 1 || kind == 2) {
                 const NetDev& n = ctx->net[net];
                 int mr, nc;
-                if (ctx->gemm_split && ctx->lds_min_rows > 0 && rows >= ctx->lds_min_rows) {   // the shared-weight kernel (rc_gemm_lds.hip)
+                if (ctx->gemm_split && ctx->lds_min_rows > 0 && B >= ctx->lds_min_batch && rows >= ctx->lds_min_rows) {   // the shared-weight kernel (rc_gemm_lds.hip)
                     mr = 16; nc = 8;
                 } else if (ctx->gemm_split && rows >= tile64_rows) {           // (split products: the K loop is operand-bound, 64-row tiles)
                     const int* t = n.H == 512 ? t5 : (n.H == 1024 ? t6 : t4);
@@ -1734,7 +1739,8 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->cost_tick_small_us = tune_env("RC_COST_HANDOVER_US", (int)ctx->cost_tick_small_us);
     ctx->cost_frame_us = tune_env("RC_COST_FRAME_US", (int)ctx->cost_frame_us);
     ctx->cost_tr_us = tune_env("RC_COST_TR_US", (int)ctx->cost_tr_us);
-    ctx->lds_min_rows = tune_env("RC_LDS_MIN_ROWS", ctx->lds_min_rows);
+    ctx->lds_min_rows = tune_env("RC_LDS_MIN_ROWS", std::min(160, std::max(64, batch / 2)));
+    ctx->lds_min_batch = tune_env("RC_LDS_MIN_BATCH", ctx->lds_min_batch);
     ctx->resident_on = tune_env("RC_SEQ_RESIDENT", 0) != 0;
     ctx->resident_wgs = tune_env("RC_SEQ_RESIDENT_WGS", ctx->resident_wgs);
     ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 1) == 1 ? 1 : 2;
