@@ -158,7 +158,7 @@ int rc_get_launch_stats(rc_ctx* ctx, int64_t* lds_launches, int64_t* other_wide_
  * weights): bench.py names the kernel whose launches it timed (round-5 advisor item). */
 int rc_get_launch_stats_w32(rc_ctx* ctx, int64_t* w32_launches);
 /* Resident layer-step kernel of the wavefront engine (round 6; north_star: "fused persistent kernel ... across timesteps"). With enable != 0
- * a planned rc_sequence call of a context of 96 .. 256 rows in split-product mode runs the LSTM layer steps AND the linear1 layers of
+ * a planned rc_sequence call of a context of 65 .. 256 rows in split-product mode runs the LSTM layer steps AND the linear1 layers of
  * ALL its ticks (net/sig_mp.py:126-129 over every frame of the call; articulate/utils/torch/rnn.py:129-133 is the reference's own
  * whole-sequence form) in ONE launch of `workgroups` (default 224, at most 240; 0 keeps the current value) resident workgroups that take work items from a
  * queue in device memory, ordered by counters instead of stream events; prep / linear2 / fuse / tail stay launches of the second stream.
@@ -413,7 +413,7 @@ int rc_get_trace(rc_ctx* ctx, int32_t* trace_host, void* stream);
 /* Timing hook for bench.py: accumulate HIP-event time of the gate-GEMM launches on their own stream.
  * enable = 1 records every gate-GEMM launch, enable = 2 only those of the wide-tile kernel rc_gemm_kernel (the 16-row
  * launches run on rc_gemm_small_kernel), enable = 3 only those of the shared-weight kernel rc_gemm_lds_kernel (round 6: the LSTM layer
- * steps of contexts of >= 96 rows), 0 stops; rc_gemm_timing_read returns total milliseconds and launch count so far. */
+ * steps of contexts of more than 64 rows), 0 stops; rc_gemm_timing_read returns total milliseconds and launch count so far. */
 int rc_gemm_timing(rc_ctx* ctx, int32_t enable);
 int rc_gemm_timing_read(rc_ctx* ctx, double* total_ms, int64_t* launches);
 /* Time (ms) during which at least one of the launches read so far was running: the wavefront engine issues the two wide launches

@@ -211,11 +211,12 @@ struct rc_ctx {
     long long stat_wide_launches = 0;    // launches of the wide-tile kernels (rc_get_launch_stats)
     // shared-weight gate GEMM (rc_gemm_lds.hip): LSTM layer steps of >= lds_min_rows rows in split-product mode
     // Two thresholds (round 6, second session; tools/ab_batch.py): a CONTEXT takes the shared-weight kernel and the three-stream tick from
-    // lds_min_batch rows (batch 64 loses a third with them: 673k -> 569k mixed), and inside such a context a PROBLEM runs on it from
+    // lds_min_batch rows (batch 64 loses a sixth with them: 688k -> 576k mixed), and inside such a context a PROBLEM runs on it from
     // lds_min_rows rows (the rnn4 / rnn6 problems of a mixed batch hold only the rows that see the camera). One threshold of 160 for both
     // (first session) left batch 96-128 on the 64-row tiles: batch 128 mixed 858k -> 933k, all-visible 1,073k -> 1,173k; 96: 691k -> 752k.
     int lds_min_rows = 64;               // RC_LDS_MIN_ROWS (0 = never); default: half the batch, within 64 .. 160 (batch 256: 128 = 160 within the noise, 64 costs 0.7 %)
-    int lds_min_batch = 96;              // RC_LDS_MIN_BATCH
+    int lds_min_batch = 65;              // RC_LDS_MIN_BATCH: batch 72 / 80 / 88 mixed 528 / 587 / 653k on 64-row tiles (two row tiles, the second mostly padding) -> 585 / 654 / 691k;
+                                         // 64 rows and fewer keep the one-reader 64-row launches (688k against 576k)
     int lds_ksplit[3] = {1, 2, 2};       // RC_LDS_KSPLIT_512 / _1024 / _1280: workgroups per tile (1: both K halves in one workgroup; the H = 512
                                          // nets' items are short -- 2 x 16 k-blocks -- and a hand-over per tile costs more than it levels: +1 %)
     float* lds_slab = nullptr;           // [kLdsRegions][lds_region_tiles][RC_LDS_SLAB_FLOATS]: half sums in flight, one region per launch

@@ -1,6 +1,6 @@
 // Gate GEMM of the LSTM layer steps with the WEIGHTS SHARED BY THE WORKGROUP (round 6) -- gfx950 only.
 //
-// Replaces, for contexts of >= RC_LDS_MIN_BATCH (96) rows in split-product mode and problems of >= RC_LDS_MIN_ROWS (half the batch) rows, the 64-row tiles of rc_gemm.hip on the twelve LSTM
+// Replaces, for contexts of >= RC_LDS_MIN_BATCH (65) rows in split-product mode and problems of >= RC_LDS_MIN_ROWS (half the batch) rows, the 64-row tiles of rc_gemm.hip on the twelve LSTM
 // layer steps of a frame (net/sig_mp.py:126-129 -> articulate/utils/torch/rnn.py:129-133, aten::lstm; 96 % of the path's FLOPs).
 //
 // Why. rc_gemm.hip splits K over the four waves of a 64 x 128 tile; nothing is shared inside a workgroup, so every weight byte is

@@ -44,10 +44,10 @@ def test_state_dict_parameters_and_the_attribute_tree():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("B,want", [(48, "rc_gemm_split48_w32_kernel"), (256, "rc_gemm_lds_kernel"), (128, "rc_gemm_lds_kernel"), (80, "rc_gemm_split_kernel")])
+@pytest.mark.parametrize("B,want", [(48, "rc_gemm_split48_w32_kernel"), (256, "rc_gemm_lds_kernel"), (128, "rc_gemm_lds_kernel"), (80, "rc_gemm_lds_kernel"), (24, "rc_gemm_split_kernel")])
 def test_gemm_kernel_name_follows_the_kernel_that_ran(B, want):
     """bench.py's roofline names the kernel whose launches it timed (round-5 advisor item): contexts of 33-64 rows run one-reader launches
-    on rc_gemm_split48_w32_kernel, from 96 rows the shared-weight kernel, in between the 64 x 128 K-split tiles."""
+    on rc_gemm_split48_w32_kernel, from 65 rows the shared-weight kernel; small contexts run the K-split tile kernels."""
     sd, body = synth.make_state_dict(0), synth.make_body(1)
     net = Net(body=body, batch=B)
     net.load_state_dict(sd)

@@ -36,7 +36,7 @@ def main():
     t = torch.from_numpy
     bad = 0
     for case in range(cases):
-        B = int(rng.choice([3, 17, 48, 64, 100, 130, 256]))
+        B = int(rng.choice([3, 17, 48, 64, 72, 88, 100, 130, 256]))
         T = int(rng.integers(12, 72))
         cut = int(rng.integers(9, T - 2)) if T > 24 and rng.random() < 0.5 else T        # the call split in two
         m = synth.make_motion(1000 + case, min(B, 16), T, body, conf="high")
