@@ -1745,7 +1745,9 @@ int rc_create(int32_t batch, int32_t live, rc_ctx** out) {
     ctx->resident_on = tune_env("RC_SEQ_RESIDENT", 0) != 0;
     ctx->resident_wgs = tune_env("RC_SEQ_RESIDENT_WGS", ctx->resident_wgs);
     ctx->lds_ksplit[0] = tune_env("RC_LDS_KSPLIT_512", 1) == 1 ? 1 : 2;
-    ctx->lds_ksplit[1] = tune_env("RC_LDS_KSPLIT_1024", 2) == 1 ? 1 : 2;
+    // rnn6: one workgroup per tile up to 160 rows (batch 80 / 128 mixed 642 -> 675k / 910 -> 956k, 128 all-visible 1,123 -> 1,165k, 160: +1.4 %),
+    // the K halves on two workgroups above (batch 256: 1,400 vs 1,384k all-visible, 1,189 vs 1,182k mixed)
+    ctx->lds_ksplit[1] = tune_env("RC_LDS_KSPLIT_1024", batch <= 160 ? 1 : 2) == 1 ? 1 : 2;
     ctx->lds_ksplit[2] = tune_env("RC_LDS_KSPLIT_1280", 2) == 1 ? 1 : 2;
     // Full-batch LSTM stages (batch >= 128), measured on MI355X with the split-bf16 products (profiles/r02_tile_sweep.txt):
     // rnn4 64 x 80, rnn6 64 x 128, rnn3 / rnn7 / rnn8 64 x 64, rnn2 32 x 64 (beside rnn4's 256 tiles a 64-row rnn2 tile
