@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""One batch size, one confidence schedule, 256-frame calls on the wavefront engine: body-frames/s (best of 4). The quick A/B behind the
+thresholds of the shared-weight kernel (RC_LDS_MIN_BATCH / RC_LDS_MIN_ROWS / RC_LDS_KSPLIT_*; rc_api.cpp, profiles/r06_batch_sweep.json):
+    [RC_LDS_MIN_BATCH=..] [RC_LDS_KSPLIT_1024=1] python tools/ab_batch.py <batch> <mixed|high|occ>"""
 import sys, os, time, torch
 sys.path.insert(0, '/root/repo')
 import bench as bn
