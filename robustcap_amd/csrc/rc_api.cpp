@@ -1431,9 +1431,19 @@ int run_wave2_segment(rc_ctx* ctx, const WavePlan& P, const FrameIO& io0, int t0
             rc_launch_prep_wave(ctx->ring2[k % kRing], io0, prm, B, wp, aux);   // (before the tail: it initialises the tail's target slot)
         }
         if (int rc = group(k, 5, aux)) return rc;                               // linear2 of stages 4 and 8 ...
-        if (cnt(P.n_valid, k - kFuseStage) > 0) rc_launch_fuse(ctx->ring2[(k - kFuseStage) % kRing], io0, prm, B, aux);   // ... then their consumers
         bool aux_signalled = false;
-        if (cnt(P.n_valid, k - kTailStage) > 0) {
+        static const int fuse_tail_env = tune_env("RC_SEQ_FUSE_TAIL", 1);
+        bool merged = false;
+        if (fuse_tail_env && tri && cnt(P.n_valid, k - kFuseStage) > 0 && cnt(P.n_valid, k - kTailStage) > 0) {     // ... then their consumers, in ONE launch
+            const FrameBuffers& tgt = ctx->ring2[k % kRing];
+            wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
+            aux_signalled = two && ext_events;
+            merged = rc_launch_fuse_tail(ctx->ring2[(k - kTailStage) % kRing], ctx->ring2[(k - kFuseStage) % kRing], io0, prm, ctx->body, B, wt, aux,
+                                         aux_signalled ? ctx->ev_aux[e] : nullptr);
+            if (!merged) aux_signalled = false;
+        }
+        if (!merged && cnt(P.n_valid, k - kFuseStage) > 0) rc_launch_fuse(ctx->ring2[(k - kFuseStage) % kRing], io0, prm, B, aux);
+        if (!merged && cnt(P.n_valid, k - kTailStage) > 0) {
             const FrameBuffers& tgt = ctx->ring2[k % kRing];
             wt.x4l = tgt.x4l; wt.x6l = tgt.x6l; wt.flags2 = tgt.flags2; wt.wsteps = tgt.wsteps;
             aux_signalled = two && ext_events;

@@ -70,8 +70,7 @@ __global__ __launch_bounds__(64 * RPB) void rc_prep_wave_kernel(FrameBuffers fb,
 }
 
 // =================================================================================== fuse (L154-167, L178-180)
-__global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void fuse_body(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const int B, const int idx) {
     const int row = idx / 24, j = idx % 24;
     if (row >= B) return;
     int frame = 0;
@@ -113,6 +112,24 @@ __global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO i
         fb.x78[rc_pk(row, 72 + 3 * j + c, LD_X78)] = out[c];
         fb.xi[rc_pk(row, 3 * j + c, LD_XI)] = out[c];
     }
+}
+
+__global__ __launch_bounds__(256) void rc_fuse_kernel(FrameBuffers fb, FrameIO io, rc_params_dev prm, int B) {
+    fuse_body(fb, io, prm, B, blockIdx.x * 256 + threadIdx.x);
+}
+
+// Wavefront engine: fuse (the frame started 4 ticks ago) and tail (the one started 8 ticks ago) of a tick are independent -- different ring
+// slots, disjoint state -- and each of the two launches queued for a CU behind the shared-weight workgroups of the layer steps (fuse 26-46 us
+// for 4 us of work, profiles/r06_timeline_final_high.txt). One launch: the tail's workgroups first, the fuse's behind them.
+__global__ __launch_bounds__(256) void rc_fuse_tail_kernel(FrameBuffers fb_tail, FrameBuffers fb_fuse, FrameIO io, rc_params_dev prm,
+                                                           const BodyConst* __restrict__ body_g, int B, WaveTail wt, int n_tail_blocks) {
+    __shared__ WaveScratch s_all[4];
+    __shared__ __attribute__((aligned(16))) BodyConst s_body;
+    if ((int)blockIdx.x >= n_tail_blocks) {
+        fuse_body(fb_fuse, io, prm, B, ((int)blockIdx.x - n_tail_blocks) * 256 + (int)threadIdx.x);
+        return;
+    }
+    tail_impl<4, false>(fb_tail, io, prm, body_g, B, 0, io, 0, wt, s_all, s_body, nullptr);
 }
 
 // ================================================================================================== reset
@@ -397,6 +414,15 @@ void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
         if (stop) hipExtLaunchKernelGGL(rc_tail_kernel<1>, dim3(B), dim3(64), 0, st, nullptr, stop, 0, fb, io, prm, body, B, first_frame, nx, has_next, w);
         else hipLaunchKernelGGL(rc_tail_kernel<1>, dim3(B), dim3(64), 0, st, fb, io, prm, body, B, first_frame, nx, has_next, w);
     }
+}
+bool rc_launch_fuse_tail(const FrameBuffers& fb_tail, const FrameBuffers& fb_fuse, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
+                         const WaveTail& wt, hipStream_t st, hipEvent_t stop) {
+    if (rc_wave_rows_per_wg() != 4) return false;
+    const int n_tail = (B + 3) / 4, n_fuse = (B * 24 + 255) / 256;
+    const dim3 g(n_tail + n_fuse), b(256);
+    if (stop) hipExtLaunchKernelGGL(rc_fuse_tail_kernel, g, b, 0, st, nullptr, stop, 0, fb_tail, fb_fuse, io, prm, body, B, wt, n_tail);
+    else hipLaunchKernelGGL(rc_fuse_tail_kernel, g, b, 0, st, fb_tail, fb_fuse, io, prm, body, B, wt, n_tail);
+    return true;
 }
 void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t st) {
     if (rc_wave_rows_per_wg() == 4) hipLaunchKernelGGL(rc_prep_wave_kernel<4>, dim3((B + 3) / 4), dim3(256), 0, st, slot, io0, prm, B, w);

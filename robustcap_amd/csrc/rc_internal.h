@@ -319,6 +319,8 @@ void rc_launch_fuse(const FrameBuffers& fb, const FrameIO& io, const rc_params_d
 void rc_launch_tail(const FrameBuffers& fb, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
                     int first_frame, hipStream_t s, const FrameIO* io_next = nullptr,    // io_next: also the next frame's prep
                     const WaveTail* wt = nullptr, hipEvent_t stop = nullptr);   // stop: event signalled by this dispatch
+bool rc_launch_fuse_tail(const FrameBuffers& fb_tail, const FrameBuffers& fb_fuse, const FrameIO& io, const rc_params_dev& prm, const BodyConst* body, int B,
+                         const WaveTail& wt, hipStream_t s, hipEvent_t stop);   // fuse + tail of a tick in one launch (false: not available, launch them apart)
 void rc_launch_prep_wave(const FrameBuffers& slot, const FrameIO& io0, const rc_params_dev& prm, int B, const WavePrep& w, hipStream_t s);
 void rc_launch_reset(const FrameBuffers& fb, float* const* h, float* const* c, const int* hidden, const unsigned char* mask,
                      int B, hipStream_t s);
