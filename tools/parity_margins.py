@@ -5,6 +5,7 @@ error (m), max joint-angle error (deg) and max |h - ref| of rnn4's final state, 
   split_b1     batch 1, split-bf16 products (rc_set_gemm_mode 1), forward_sequence
   split_b64    the fixture as row 17 of a batch-64 context (split products by default from 48 rows; the tick's two wide launches on
                two streams, 64-row tiles), the other 63 rows synthetic motions of their own -- the headline arithmetic and engine
+  split_b256   the same as row 17 of a batch-256 context: the shared-weight kernel rc_gemm_lds_kernel, three layer-step streams (round 6)
   live_lean    batch 1, forward_online with use_graph: rc_live_step, steady-state frames on the lean seven-launch capture
 Used to A/B numerics-affecting kernel changes against the 1e-4 m / 0.1 deg budget before they are adopted.
     python tools/parity_margins.py > profiles/rNN_parity_margins.json"""
@@ -65,22 +66,26 @@ def main():
                     rec[name] = margins(ob, s, p[0].cpu(), tr[0].cpu(), net.get_state("rnn4")[0][:, 0])
                     rec[name]["engine_frames"] = net.sequence_stats()[0]
                     del net
-                # row ROW of a batch of BIG
-                m = synth.make_motion(1000 + T, BIG, T, body, conf="mixed")
-                for k, src in (("j2dc", "j2dc"), ("accc", "accc"), ("oric", "oric")):
-                    m[k][ROW] = s[src]
-                m["gravityc"][ROW] = s["gravityc"]
-                net = make_net(s, sd, body, BIG)
-                assert net.gemm_mode, "batch 64 defaults to the split products"
-                net.gravityc = t(m["gravityc"])
-                ft = None
-                if s["first_tran"].size:
-                    ft = t(m["first_tran"].copy())
-                    ft[ROW] = t(s["first_tran"])
-                p, tr = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_tran=ft, first_frame=ff)
-                rec["split_b64"] = margins(ob, s, p[ROW].cpu(), tr[ROW].cpu(), net.get_state("rnn4")[0][:, ROW])
-                rec["split_b64"]["engine_frames"] = net.sequence_stats()[0]
-                del net
+                # row ROW of a batch of BIG (64-row tiles) and of 256 (round 6: the shared-weight kernel on three streams -- the headline engine)
+                for big, key in ((BIG, "split_b64"), (256, "split_b256")):
+                    mu = synth.make_motion(1000 + T, min(big, 32), T, body, conf="mixed")
+                    rep = (big + 31) // 32
+                    m = {k: np.concatenate([v] * rep, 0)[:big].copy() for k, v in mu.items()}
+                    for k, src in (("j2dc", "j2dc"), ("accc", "accc"), ("oric", "oric")):
+                        m[k][ROW] = s[src]
+                    m["gravityc"][ROW] = s["gravityc"]
+                    net = make_net(s, sd, body, big)
+                    assert net.gemm_mode, "batches from 48 rows default to the split products"
+                    net.gravityc = t(m["gravityc"])
+                    ft = None
+                    if s["first_tran"].size:
+                        ft = t(m["first_tran"].copy())
+                        ft[ROW] = t(s["first_tran"])
+                    p, tr = net.forward_sequence(t(m["j2dc"]), t(m["accc"]), t(m["oric"]), first_tran=ft, first_frame=ff)
+                    rec[key] = margins(ob, s, p[ROW].cpu(), tr[ROW].cpu(), net.get_state("rnn4")[0][:, ROW])
+                    rec[key]["engine_frames"] = net.sequence_stats()[0]
+                    rec[key]["kernel"] = net.gemm_kernel_name()
+                    del net
             # the live path, frame by frame
             net = make_net(s, sd, body, 1)
             net.gravityc = t(s["gravityc"])
